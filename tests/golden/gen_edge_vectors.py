@@ -1,0 +1,176 @@
+"""Build tests/golden/edge_vectors.json: the edge-case set SURVEY.md 8(c) asks
+for (the reference holds no such vectors).  Verdicts come from the big-int
+ground truth oracle/ed25519_ref.py, i.e. from the dalek 1.0.1 rules restated
+there; they are "parity unpinned" by the reference itself.
+
+Each vector: name, class, msg, pk, sig (hex) and three verdicts:
+  strict        Signature::verify        (crypto/src/lib.rs:200-204)
+  cofactorless  the per-signature equation verify_batch sums (lib.rs:206-219)
+  cofactored    [8](sB - kA - R) == O
+Batch law: a batch containing the vector is accepted by
+dalek iff cofactorless (class ii), rejected iff not cofactored (class i), and
+is "dalek-nondeterministic" when cofactored and not cofactorless (class iii);
+this engine rejects class iii.
+
+    python tests/golden/gen_edge_vectors.py
+"""
+import hashlib
+import json
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "oracle"))
+import ed25519_ref as E  # noqa: E402
+
+
+def H(tag, i=0):
+    return hashlib.sha512(tag + struct.pack("<Q", i)).digest()
+
+
+def le32(v):
+    return int(v).to_bytes(32, "little")
+
+
+VEC = []
+
+
+def add(name, cls, msg, pk, sig):
+    VEC.append({
+        "name": name, "class": cls, "msg": msg.hex(), "pk": pk.hex(), "sig": sig.hex(),
+        "strict": E.verify_strict(msg, pk, sig),
+        "cofactorless": E.verify_cofactorless(msg, pk, sig),
+        "cofactored": E.verify_cofactored(msg, pk, sig),
+    })
+
+
+def main():
+    seed = H(b"edge-seed")[:32]
+    msg = H(b"edge-msg")[:32]
+    pk = E.public_key(seed)
+    sig = E.sign(seed, msg)
+    a, _ = E.secret_expand(seed)
+    a %= E.L
+    A = E.decompress(pk)
+    add("honest", "honest", msg, pk, sig)
+    add("default-signature-64-zero-bytes (crypto_tests.rs:111)", "format", msg, pk, bytes(64))
+
+    # ---- scalar range
+    s = int.from_bytes(sig[32:], "little")
+    for nm, sv in [("s+L", s + E.L), ("s=L", E.L), ("s=L-1", E.L - 1), ("s=L+1", E.L + 1),
+                   ("s=2^253", 1 << 253), ("s=2^255", 1 << 255), ("s=2^256-1", (1 << 256) - 1),
+                   ("s+2L", s + 2 * E.L), ("s=0", 0)]:
+        if sv < (1 << 256):
+            add("scalar:" + nm, "scalar-range", msg, pk, sig[:32] + le32(sv))
+    # s in [2^252, L) (slow path of dalek's check_scalar) can only be reached by a crafted
+    # signature: with A = identity, R = [s]B satisfies the cofactorless equation for any s.
+    ident = le32(1)
+    for nm, sv in [("s=2^252", 1 << 252), ("s=L-1", E.L - 1)]:
+        add("scalar:identity-A crafted " + nm, "small-order-crafted", msg, ident,
+            E.compress(E.pt_mul(sv, E.B)) + le32(sv))
+    add("scalar:identity-A crafted s=L (must fail the range check)", "scalar-range", msg, ident,
+        E.compress(E.pt_mul(E.L, E.B)) + le32(E.L))
+
+    # ---- off-curve encodings
+    y = 2
+    offs = []
+    while len(offs) < 2:
+        if E._recover_x(y, 0) is None:
+            offs.append(y)
+        y += 1
+    for y in offs:
+        add("offcurve:A y=%d" % y, "off-curve", msg, le32(y), sig)
+        add("offcurve:R y=%d" % y, "off-curve", msg, pk, le32(y) + sig[32:])
+        add("offcurve:R y=%d sign=1" % y, "off-curve", msg, pk, le32(y | (1 << 255)) + sig[32:])
+
+    # ---- small-order points, canonical and non-canonical encodings
+    tors = E.eight_torsion()
+    enc = []
+    for t in tors:
+        c = E.compress(t)
+        enc.append(("canon", c))
+    # non-canonical: y + p for y in {0, 1} (y < 19), both sign bits; and -0 forms
+    for yv in (0, 1):
+        for sign in (0, 1):
+            enc.append(("noncanon-y+p", le32((yv + E.P) | (sign << 255))))
+    enc.append(("neg-zero-y=1", le32(1 | (1 << 255))))
+    enc.append(("neg-zero-y=-1", le32((E.P - 1) | (1 << 255))))
+    seen = set()
+    r = int.from_bytes(H(b"edge-r")[:32], "little") % E.L
+    for kind, e in enc:
+        if e in seen:
+            continue
+        seen.add(e)
+        T = E.decompress(e)
+        assert T is not None and E.pt_is_small_order(T)
+        # as A, honest-looking R: almost surely fails
+        add("smallorder:A=%s %s" % (kind, e.hex()[:8] + ".." + e.hex()[-4:]), "small-order", msg, e, sig)
+        # as A with crafted (R, s) satisfying the cofactorless equation:
+        #   R = rB + T', s = r, need -[k]A == T'
+        found = False
+        for j in range(400):
+            rj = (r + j) % E.L
+            for Tp in tors:
+                Rpt = E.pt_add(E.pt_mul(rj, E.B), Tp)
+                Rb = E.compress(Rpt)
+                k = E.sha512_modl(Rb, e, msg)
+                if E.pt_eq(E.pt_neg(E.pt_mul(k, T)), Tp):
+                    add("smallorder:A=%s crafted-cofactorless %s" % (kind, e.hex()[:8]), "small-order-crafted",
+                        msg, e, Rb + le32(rj))
+                    found = True
+                    break
+            if found:
+                break
+        assert found
+        # as R with s = k a (so that sB - kA == O) shifted by the torsion point:
+        # need sB - kA == T  ->  only possible if T == O; for T != O it is class iii.
+        k = E.sha512_modl(e, pk, msg)
+        add("smallorder:R=%s s=k*a %s" % (kind, e.hex()[:8] + ".." + e.hex()[-4:]), "small-order-R",
+            msg, pk, e + le32((k * a) % E.L))
+
+    # ---- mixed-order A = aB + T8, honest-style signature (class iii unless k = 0 mod 8)
+    T8 = next(t for t in tors if not E.pt_is_identity(E.pt_mul(4, t)))
+    Amix = E.compress(E.pt_add(A, T8))
+    _, prefix = E.secret_expand(seed)
+    got0 = got1 = False
+    i = 0
+    while not (got0 and got1):
+        m2 = H(b"edge-mixA", i)[:32]
+        i += 1
+        rr = E.sha512_modl(prefix, m2)
+        Rb = E.compress(E.pt_mul(rr, E.B))
+        k = E.sha512_modl(Rb, Amix, m2)
+        sg = Rb + le32((rr + k * a) % E.L)
+        if k % 8 == 0 and not got0:
+            add("mixedorder:A k=0mod8", "mixed-order", m2, Amix, sg)
+            got0 = True
+        elif k % 8 != 0 and not got1:
+            add("mixedorder:A k!=0mod8 (dalek-nondeterministic in batch)", "mixed-order", m2, Amix, sg)
+            got1 = True
+    # ---- mixed-order R = rB + T8
+    rr = E.sha512_modl(prefix, msg)
+    Rb = E.compress(E.pt_add(E.pt_mul(rr, E.B), T8))
+    k = E.sha512_modl(Rb, pk, msg)
+    add("mixedorder:R (dalek-nondeterministic in batch)", "mixed-order", msg, pk, Rb + le32((rr + k * a) % E.L))
+
+    # ---- non-canonical y on R for a NON-small-order point cannot be built (needs y < 19 with
+    # known dlog); covered by the small-order non-canonical forms above.
+
+    # ---- wrong key / wrong message / swapped halves
+    seed2 = H(b"edge-seed2")[:32]
+    add("wrong-key", "tamper", msg, E.public_key(seed2), sig)
+    add("wrong-msg", "tamper", H(b"edge-other")[:32], pk, sig)
+    add("swapped-R-s", "tamper", msg, pk, sig[32:] + sig[:32])
+    add("R-negated", "tamper", msg, pk, bytes([*sig[:31], sig[31] ^ 0x80]) + sig[32:])
+    add("A-negated", "tamper", msg, bytes([*pk[:31], pk[31] ^ 0x80]), sig)
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "edge_vectors.json")
+    with open(path, "w") as f:
+        json.dump({"generator": "tests/golden/gen_edge_vectors.py", "vectors": VEC}, f, indent=1)
+    print("wrote", path, len(VEC), "vectors")
+    for v in VEC:
+        print("%-72s strict=%d cl=%d cf=%d" % (v["name"][:72], v["strict"], v["cofactorless"], v["cofactored"]))
+
+
+if __name__ == "__main__":
+    main()
