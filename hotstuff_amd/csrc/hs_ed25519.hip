@@ -1,0 +1,290 @@
+// hs_ed25519.hip - gfx950 kernels and the C-ABI host side of the batch Ed25519
+// verification engine (include/hs_ed25519.h).  Replaces the ed25519-dalek calls at
+// /root/reference/crypto/src/lib.rs:203 (verify_strict) and :218 (verify_batch).
+//
+// Device side: two kernels per call, one wavefront (64 lanes) per workgroup so that
+// even a 1,024-signature batch spreads over 16-32 CUs; the workspace between them is
+// structure-of-arrays so every lane-strided access is a coalesced 256-byte row.
+//   k_prepare : 2n lanes  (decompress A / R, hram, scalar checks, recoding)
+//   k_verify  : n lanes   (joint double-scalar multiplication, compare, ballot -> bitmap)
+// Host side: a pool of stream contexts (pinned staging + device buffers), no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <mutex>
+#include <condition_variable>
+#include <vector>
+#include "verify.h"
+#include "../../include/hs_ed25519.h"
+
+using namespace hs;
+
+// ------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------
+__device__ ge_niels g_btab[9];      // j*B, j = 0..8 (uploaded by hs_ed25519_init)
+
+__global__ void __launch_bounds__(64)
+k_prepare(workspace ws, const u32 *__restrict__ digests, u32 digest_stride_words,
+          const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool is_r = t >= n;
+    const u32 i = is_r ? t - n : t;
+    prepare_point(ws, i, is_r, pks + (size_t)8 * i, sigs + (size_t)16 * i,
+                  digests + (size_t)digest_stride_words * i, mode);
+}
+
+__global__ void __launch_bounds__(64)
+k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject) {
+    // LDS-staged base-point window table (9 entries x 30 limbs)
+    __shared__ ge_niels s_btab[9];
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(g_btab);
+        u32 *dst = reinterpret_cast<u32 *>(s_btab);
+        for (u32 j = threadIdx.x; j < sizeof(s_btab) / 4; j += 64) dst[j] = src[j];
+    }
+    __syncthreads();
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    const bool active = i < n;
+    // inactive tail lanes run lane min(i, n-1)'s data so the wavefront stays convergent
+    const bool ok = verify_lane(ws, active ? i : n - 1, mode, s_btab) && active;
+    const unsigned long long mask = __ballot(ok);
+    if (threadIdx.x == 0) {
+        bitmap[blockIdx.x] = mask;
+        if (nreject) {
+            const u32 lanes = min(64u, n - blockIdx.x * 64);
+            const u32 bad = lanes - (u32)__popcll(mask);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------
+static thread_local char t_err[256] = "";
+static int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) snprintf(t_err, sizeof t_err, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(t_err, sizeof t_err, "%s", what);
+    return code;
+}
+#define HS_HIP(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(HS_ED25519_E_DEVICE, what, e_); } while (0)
+
+struct hs_ed25519_ctx {
+    hipStream_t stream = nullptr;
+    size_t cap = 0;               // signatures
+    u32 *d_ws = nullptr;          // workspace
+    uint8_t *d_in = nullptr;      // digests | pks | sigs   (host API only)
+    uint8_t *d_out = nullptr;     // bitmap (8*ceil(cap/64)) | nreject (4) padded
+    uint8_t *h_in = nullptr;      // pinned mirror of d_in
+    uint8_t *h_out = nullptr;     // pinned mirror of d_out
+    bool staging = false;
+    // optional profiling: a ring of (start, after-prepare, after-verify) HIP events recorded
+    // on the launch stream, read back by hs_ed25519_ctx_kernel_times after a synchronize
+    std::vector<hipEvent_t> ev;
+    size_t ev_slots = 0, ev_calls = 0;
+};
+
+static std::mutex g_mu;
+static std::condition_variable g_cv;
+static bool g_init = false;
+static int g_device = 0;
+static size_t g_max_batch = 0;
+static std::vector<hs_ed25519_ctx *> g_free;
+static int g_live = 0;
+static const int kMaxPool = 8;
+
+static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+static size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }
+
+static void ctx_release(hs_ed25519_ctx *c) {
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    c->d_ws = nullptr; c->d_in = c->d_out = c->h_in = c->h_out = nullptr; c->cap = 0;
+}
+static int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging) {
+    if (n <= c->cap && (!staging || c->staging)) return 0;
+    size_t cap = round_up(n < 64 ? 64 : n, 64);
+    if (cap < c->cap) cap = c->cap;
+    ctx_release(c);
+    HS_HIP(hipMalloc((void **)&c->d_ws, workspace_words(cap) * 4), "hipMalloc workspace");
+    if (staging) {
+        const size_t in_bytes = cap * 128, out_bytes = bitmap_bytes(cap) + 16;
+        HS_HIP(hipMalloc((void **)&c->d_in, in_bytes), "hipMalloc inputs");
+        HS_HIP(hipMalloc((void **)&c->d_out, out_bytes), "hipMalloc outputs");
+        HS_HIP(hipHostMalloc((void **)&c->h_in, in_bytes, hipHostMallocDefault), "hipHostMalloc inputs");
+        HS_HIP(hipHostMalloc((void **)&c->h_out, out_bytes, hipHostMallocDefault), "hipHostMalloc outputs");
+    }
+    c->cap = cap; c->staging = staging;
+    return 0;
+}
+
+extern "C" int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch) {
+    if (!out) return fail(HS_ED25519_E_ARG, "ctx_create: null out");
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    hs_ed25519_ctx *c = new (std::nothrow) hs_ed25519_ctx();
+    if (!c) return fail(HS_ED25519_E_NOMEM, "ctx_create: out of memory");
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, "hipStreamCreate", e); }
+    int rc = ctx_reserve(c, max_batch ? max_batch : 64, false);
+    if (rc) { (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
+    *out = c;
+    return 0;
+}
+extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
+    if (!c) return;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    ctx_release(c);
+    delete c;
+}
+
+extern "C" int hs_ed25519_init(int device, size_t max_batch) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) { if (max_batch > g_max_batch) g_max_batch = max_batch; return 0; }
+    int count = 0;
+    HS_HIP(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    if (device < 0 || device >= count) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
+    HS_HIP(hipSetDevice(device), "hipSetDevice");
+    ge_niels tab[9];
+    make_base_table(tab, 9);
+    HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
+    HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
+    return 0;
+}
+extern "C" void hs_ed25519_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (hs_ed25519_ctx *c : g_free) hs_ed25519_ctx_destroy(c);
+    g_free.clear(); g_live = 0; g_init = false;
+}
+extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
+extern "C" const char *hs_ed25519_dominant_kernel(void) { return "k_verify"; }
+
+static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+
+extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
+                                        const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
+                                        uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device: null context");
+    if (n == 0) return 0;
+    if (!d_digests || !d_pks || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
+    if (misaligned(d_digests, 16) || misaligned(d_pks, 16) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) ||
+        misaligned(d_nreject, 4))
+        return fail(HS_ED25519_E_ARG, "verify_device: misaligned pointer");
+    if ((digest_stride != 0 && digest_stride != 32) || mode > 1 || n > 0x3fffffffu)
+        return fail(HS_ED25519_E_ARG, "verify_device: bad digest_stride / mode / n");
+    int rc = ctx_reserve(ctx, n, ctx->staging);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const u32 np = (u32)round_up(n, 64);
+    workspace ws;
+    ws.np = np; ws.pt = ctx->d_ws; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    const u32 nn = (u32)n;
+    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
+    if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
+    hipLaunchKernelGGL(k_prepare, dim3((2 * nn + 63) / 64), dim3(64), 0, st, ws, (const u32 *)d_digests,
+                       (u32)(digest_stride / 4), (const u32 *)d_pks, (const u32 *)d_sigs, nn, mode);
+    hipLaunchKernelGGL(k_verify, dim3(np / 64), dim3(64), 0, st, ws, nn, mode, (unsigned long long *)d_bitmap, d_nreject);
+    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
+    HS_HIP(hipGetLastError(), "kernel launch");
+    return 0;
+}
+
+extern "C" int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots) {
+    if (!ctx) return fail(HS_ED25519_E_ARG, "set_profiling: null context");
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    ctx->ev.clear(); ctx->ev_slots = 0; ctx->ev_calls = 0;
+    for (size_t i = 0; i < 3 * slots; i++) {
+        hipEvent_t e;
+        HS_HIP(hipEventCreate(&e), "hipEventCreate");
+        ctx->ev.push_back(e);
+    }
+    ctx->ev_slots = slots;
+    return 0;
+}
+extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
+                                           size_t *launches) {
+    if (!ctx || !prepare_ms_sum || !verify_ms_sum || !launches) return fail(HS_ED25519_E_ARG, "kernel_times: null");
+    const size_t cnt = ctx->ev_calls < ctx->ev_slots ? ctx->ev_calls : ctx->ev_slots;
+    double a = 0, b = 0;
+    for (size_t i = 0; i < cnt; i++) {
+        float t0 = 0, t1 = 0;
+        HS_HIP(hipEventElapsedTime(&t0, ctx->ev[3 * i], ctx->ev[3 * i + 1]), "hipEventElapsedTime");
+        HS_HIP(hipEventElapsedTime(&t1, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]), "hipEventElapsedTime");
+        a += t0; b += t1;
+    }
+    *prepare_ms_sum = a; *verify_ms_sum = b; *launches = cnt;
+    return 0;
+}
+
+// ---- host-pointer API ----------------------------------------------------------------------
+static int pool_get(hs_ed25519_ctx **out) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    for (;;) {
+        if (!g_free.empty()) { *out = g_free.back(); g_free.pop_back(); return 0; }
+        if (g_live < kMaxPool) { g_live++; break; }
+        g_cv.wait(lk);
+    }
+    lk.unlock();
+    hs_ed25519_ctx *c = nullptr;
+    int rc = hs_ed25519_ctx_create(&c, 64);
+    if (rc) { lk.lock(); g_live--; g_cv.notify_one(); return rc; }
+    *out = c;
+    return 0;
+}
+static void pool_put(hs_ed25519_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_free.push_back(c);
+    g_cv.notify_one();
+}
+
+static int verify_host(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
+                       size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (mode > 1) return fail(HS_ED25519_E_ARG, "verify: bad mode");
+    if (n == 0) return g_init ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!digests || !pks || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
+    hs_ed25519_ctx *c = nullptr;
+    int rc = pool_get(&c);
+    if (rc) return rc;
+    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    size_t want = n > g_max_batch ? n : g_max_batch;
+    rc = ctx_reserve(c, want, true);
+    if (rc) return rc;
+    // staging layout: [digests: dg_bytes][pks: 32n][sigs: 64n], each section 16-byte aligned
+    const size_t dg_bytes = digest_stride ? 32 * n : 32;
+    const size_t off_pk = round_up(dg_bytes, 16), off_sig = off_pk + 32 * n, in_bytes = off_sig + 64 * n;
+    memcpy(c->h_in, digests, dg_bytes);
+    memcpy(c->h_in + off_pk, pks, 32 * n);
+    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    const size_t bm = bitmap_bytes(n);
+    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
+    rc = hs_ed25519_verify_device(c, c->d_in, digest_stride, c->d_in + off_pk, c->d_in + off_sig, n, mode, c->d_out,
+                                  (uint32_t *)(c->d_out + bm), c->stream);
+    if (rc) return rc;
+    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    uint32_t nrej;
+    memcpy(&nrej, c->h_out + bm, 4);
+    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
+    return nrej == 0 ? 1 : 0;
+}
+
+extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
+                                        size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host(digest, 0, pks, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
+                                       size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host(digests, 32, pks, sigs, n, mode, bitmap);
+}

@@ -1,0 +1,179 @@
+// sha512_sc.h - k = SHA-512(R || A || M) mod L for 32-byte R, A, M, and the
+// scalar-side checks of the verification path.
+//
+// Replaces, on crypto/src/lib.rs:200-219 of the reference, what ed25519-dalek
+// 1.0.1 does with sha2::Sha512 + Scalar::from_hash (hram), check_scalar
+// (s < L) and the scalar recoding that feeds the scalar multiplication.
+// The reference's Digest is always 32 bytes (crypto/src/lib.rs:21-22), so the
+// hash input is exactly 96 bytes = one padded SHA-512 block.
+#pragma once
+#include "fe26.h"
+#include "sha512_consts.h"
+
+#if defined(__HIPCC__)
+#define HS_TABLE static __device__ __constant__ const
+#else
+#define HS_TABLE static const
+#endif
+
+namespace hs {
+
+HS_TABLE u64 SHA512_K[80] = HS_SHA512_K_INIT;
+
+HS_HD u64 ror64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
+HS_HD u32 bswap32(u32 x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
+
+// in: 24 little-endian words (R, A, M).  out: the 64-byte digest as a
+// little-endian 512-bit integer in 16 words.
+HS_HD void sha512_96(u32 out[16], const u32 in[24]) {
+    const u64 H0[8] = HS_SHA512_H0_INIT;
+    u64 w[16];
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = ((u64)bswap32(in[2 * i]) << 32) | bswap32(in[2 * i + 1]);
+    w[12] = 0x8000000000000000ull; w[13] = 0; w[14] = 0; w[15] = 96 * 8;
+    u64 a = H0[0], b = H0[1], c = H0[2], d = H0[3], e = H0[4], f = H0[5], g = H0[6], h = H0[7];
+#pragma nounroll
+    for (int r = 0; r < 80; r += 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (r) {
+                const u64 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+                const u64 s0 = ror64(w15, 1) ^ ror64(w15, 8) ^ (w15 >> 7);
+                const u64 s1 = ror64(w2, 19) ^ ror64(w2, 61) ^ (w2 >> 6);
+                w[i] += s0 + w[(i + 9) & 15] + s1;
+            }
+            const u64 S1 = ror64(e, 14) ^ ror64(e, 18) ^ ror64(e, 41);
+            const u64 ch = (e & f) ^ (~e & g);
+            const u64 t1 = h + S1 + ch + SHA512_K[r + i] + w[i];
+            const u64 S0 = ror64(a, 28) ^ ror64(a, 34) ^ ror64(a, 39);
+            const u64 mj = (a & b) ^ (a & c) ^ (b & c);
+            const u64 t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+    }
+    const u64 hh[8] = { a + H0[0], b + H0[1], c + H0[2], d + H0[3], e + H0[4], f + H0[5], g + H0[6], h + H0[7] };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        out[2 * i] = bswap32((u32)(hh[i] >> 32));
+        out[2 * i + 1] = bswap32((u32)hh[i]);
+    }
+}
+
+// ---------------------------------------------------------------- scalars mod L, 32-bit limbs
+// L = 2^252 + c,  c = 0x14def9dea2f79cd65812631a5cf5d3ed  (125 bits)
+#define HS_L_WORDS { 0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u }
+#define HS_C_WORDS { 0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu }
+
+// s < L ?  (dalek check_scalar; subsumes ed25519::Signature::from_bytes' top-3-bit test)
+HS_HD bool sc_is_canonical(const u32 s[8]) {
+    const u32 Lw[8] = HS_L_WORDS;
+    // borrow of s - L: s < L iff the subtraction borrows
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)s[i] - Lw[i] - borrow;
+        borrow = (t >> 63) & 1;
+    }
+    return borrow != 0;
+}
+
+// prod[0..n+3] = c * x[0..n-1]
+template <int N>
+HS_HD void sc_mul_c(u32 *prod, const u32 *x) {
+    const u32 Cw[4] = HS_C_WORDS;
+#pragma unroll
+    for (int i = 0; i < N + 4; i++) prod[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const u64 t = (u64)x[i] * Cw[j] + prod[i + j] + carry;
+            prod[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+        prod[N + j] = (u32)carry;
+    }
+}
+// hi = x >> 252 for an NW-word x (NH = NW - 7 words out), lo = x mod 2^252 (8 words)
+template <int NW>
+HS_HD void sc_split252(u32 lo[8], u32 *hi, const u32 *x) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) lo[i] = i < NW ? x[i] : 0;
+    lo[7] &= 0x0fffffffu;
+#pragma unroll
+    for (int i = 7; i < NW; i++) hi[i - 7] = (x[i] >> 28) | (i + 1 < NW ? x[i + 1] << 4 : 0);
+}
+// r = x mod L for a 512-bit x.  2^252 = -c (mod L), folded three times:
+//   x = lo1 + 2^252 hi1 ; c hi1 = lo2 + 2^252 hi2 ; c hi2 = lo3 + 2^252 hi3 ; p3 = c hi3
+//   x = lo1 - lo2 + lo3 - p3  (mod L), every term < 2^252.
+HS_HD void sc_reduce512(u32 r[8], const u32 x[16]) {
+    u32 lo1[8], hi1[9], p1[13], lo2[8], hi2[6], p2[10], lo3[8], hi3[3], p3[7];
+    sc_split252<16>(lo1, hi1, x);
+    sc_mul_c<9>(p1, hi1);            // < 2^385
+    sc_split252<13>(lo2, hi2, p1);   // hi2 < 2^133 (5 words used, 6th = 0)
+    sc_mul_c<6>(p2, hi2);            // < 2^258
+    sc_split252<10>(lo3, hi3, p2);   // hi3 < 2^6
+    sc_mul_c<3>(p3, hi3);            // < 2^131
+    const u32 Lw[8] = HS_L_WORDS;
+    // t = lo1 + lo3 + 2L - lo2 - p3  in [0, 4L)
+    u32 t[9];
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int64_t v = carry + (int64_t)lo1[i] + lo3[i] + 2 * (int64_t)Lw[i] - lo2[i] - (i < 7 ? (int64_t)p3[i] : 0);
+        t[i] = (u32)v;
+        carry = v >> 32;
+    }
+    t[8] = (u32)carry;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        // u = t - L; keep if no borrow
+        u32 u[9];
+        u64 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const u64 d = (u64)t[i] - (i < 8 ? Lw[i] : 0) - borrow;
+            u[i] = (u32)d;
+            borrow = (d >> 63) & 1;
+        }
+        const bool ge = borrow == 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = ge ? u[i] : t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = t[i];
+}
+
+// r = a * b mod L (a, b < 2^256)
+HS_HD void sc_mul(u32 r[8], const u32 a[8], const u32 b[8]) {
+    u32 p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) p[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 t = (u64)a[i] * b[j] + p[i + j] + carry;
+            p[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+        p[8 + j] = (u32)carry;
+    }
+    sc_reduce512(r, p);
+}
+
+// Signed radix-16 recoding for x < 2^253: r = x + 0x88..88; digit_i = nibble_i(r) - 8
+// in [-8, 7] and sum digit_i 16^i = x.
+HS_HD void sc_recode16(u32 r[8], const u32 x[8]) {
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)x[i] + 0x88888888u + carry;
+        r[i] = (u32)t;
+        carry = t >> 32;
+    }
+}
+
+}  // namespace hs

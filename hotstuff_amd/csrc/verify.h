@@ -1,0 +1,170 @@
+// verify.h - the two per-lane stages of one Ed25519 verification (host+device).
+//
+//   stage 1  prepare_point : one lane per (signature, point) pair; decompress A or R,
+//                            small-order flag; the R lane also hashes
+//                            k = SHA-512(R||A||M) mod L, range-checks s and recodes both scalars.
+//   stage 2  verify_lane   : one lane per signature; [k](-A) + [s]B by a joint
+//                            fixed-window (signed radix-16) double-scalar multiplication
+//                            - lane-uniform control flow, table entries chosen per lane -
+//                            then the projective comparison with R.
+//
+// Semantics restated from ed25519-dalek 1.0.1 as reached from the reference:
+//   mode HS_MODE_STRICT  = PublicKey::verify_strict   (crypto/src/lib.rs:200-204)
+//   mode HS_MODE_BATCH   = the per-signature cofactorless equation that
+//                          dalek::verify_batch sums  (crypto/src/lib.rs:206-219);
+//                          a batch verdict is the AND over its signatures
+//                          (classes i and ii exact, class iii -> reject).
+#pragma once
+#include "ge25519.h"
+#include "sha512_sc.h"
+
+namespace hs {
+
+enum : u32 { HS_MODE_BATCH = 0, HS_MODE_STRICT = 1 };
+enum : u32 { HS_F_ONCURVE = 1, HS_F_SMALL = 2, HS_F_SCANON = 4 };
+
+// Workspace between the stages, structure-of-arrays with row stride `np` (n padded to
+// 64) so that a wavefront's 64 lanes touch 64 consecutive dwords of every row:
+//   pt   [2][20][np] u32   x,y limbs of A (slot 0) and R (slot 1)
+//   sc   [16][np]    u32   recoded k (rows 0-7) and recoded s (rows 8-15)
+//   flag [2][np]     u32   HS_F_* bits per point
+struct workspace {
+    u32 *pt, *sc, *flag;
+    u32 np;
+};
+HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + 16 + 2); }
+
+// ---- stage 1 ------------------------------------------------------------------------------
+// task in [0, n): A of signature `task`; task in [n, 2n): R of signature task - n.
+// pk / sig / msg point at this signature's 32 / 64 / 32 bytes as little-endian words.
+HS_HD void prepare_point(const workspace &ws, u32 i, bool is_r, const u32 *pk, const u32 *sig,
+                         const u32 *msg, u32 mode) {
+    u32 enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) enc[j] = is_r ? sig[j] : pk[j];
+    ge_p3 p;
+    u32 fl = ge_decompress(p, enc) ? HS_F_ONCURVE : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+    const u32 slot = is_r ? 1u : 0u;
+    u32 *row = ws.pt + (size_t)slot * 20 * ws.np + i;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { row[(size_t)j * ws.np] = p.X.v[j]; row[(size_t)(10 + j) * ws.np] = p.Y.v[j]; }
+    if (is_r) {
+        u32 in[24], h[16], k[8], s[8], rk[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
+        sha512_96(h, in);
+        sc_reduce512(k, h);
+        fl |= sc_is_canonical(s) ? HS_F_SCANON : 0;
+        sc_recode16(rk, k);
+        sc_recode16(rs, s);      // meaningless when s >= L; the lane is rejected by HS_F_SCANON
+#pragma unroll
+        for (int j = 0; j < 8; j++) { ws.sc[(size_t)j * ws.np + i] = rk[j]; ws.sc[(size_t)(8 + j) * ws.np + i] = rs[j]; }
+    }
+    ws.flag[(size_t)slot * ws.np + i] = fl;
+}
+
+// ---- stage 2 ------------------------------------------------------------------------------
+// take the top nibble of a 256-bit recoded scalar as a signed digit and shift left by 4
+HS_HD int sc_pop_digit(u32 w[8]) {
+    const int d = (int)(w[7] >> 28) - 8;
+#pragma unroll
+    for (int j = 7; j > 0; j--) w[j] = (w[j] << 4) | (w[j - 1] >> 28);
+    w[0] <<= 4;
+    return d;
+}
+
+// btab: 9 affine Niels entries j*B, j = 0..8 (entry 0 = identity).
+HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *btab) {
+    const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
+    bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+
+    ge_p3 p;                       // -A
+    fe rx, ry;
+    {
+        const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
+        fe ax;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            ax.v[j] = ra[(size_t)j * ws.np]; p.Y.v[j] = ra[(size_t)(10 + j) * ws.np];
+            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
+        }
+        fe_neg(p.X, ax);
+        fe_1(p.Z);
+        fe_mul(p.T, p.X, p.Y);
+    }
+    u32 kw[8], sw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
+
+    // per-lane table j * (-A), j = 0..8, in private memory (indexed per lane below)
+    ge_cached atab[9];
+    ge_cached_identity(atab[0]);
+    ge_to_cached(atab[1], p);
+    {
+        const ge_cached a1 = atab[1];
+#pragma nounroll
+        for (int j = 2; j <= 8; j++) {
+            ge_p1p1 t;
+            ge_add(t, p, a1, false);
+            ge_p1p1_to_p3(p, t, true);
+            ge_to_cached(atab[j], p);
+        }
+    }
+
+    ge_p3 acc;
+    ge_identity(acc);
+#pragma nounroll
+    for (int w = 0; w < 64; w++) {
+        ge_p1p1 t;
+#pragma nounroll
+        for (int d = 0; d < 4; d++) {
+            ge_dbl(t, acc);
+            ge_p1p1_to_p3(acc, t, d == 3);
+        }
+        const int dk = sc_pop_digit(kw), ds = sc_pop_digit(sw);
+        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        ge_add(t, acc, atab[ik], dk < 0);
+        ge_p1p1_to_p3(acc, t, true);
+        ge_madd(t, acc, btab[is], ds < 0);
+        ge_p1p1_to_p3(acc, t, false);
+    }
+    // acc == R as points:  X == x_R Z  and  Y == y_R Z
+    fe a, b;
+    fe_mul(a, rx, acc.Z);
+    fe_mul(b, ry, acc.Z);
+    fe_carry(acc.X); fe_carry(acc.Y);
+    return ok && fe_eq(a, acc.X) && fe_eq(b, acc.Y);
+}
+
+// ---- base-point table (computed once on the host at init) ----------------------------------
+HS_HD void ge_p3_to_niels(ge_niels &n, const ge_p3 &p) {
+    fe zi, x, y, xy;
+    fe_invert(zi, p.Z);
+    fe_mul(x, p.X, zi); fe_mul(y, p.Y, zi);
+    fe_add(n.ypx, y, x); fe_carry(n.ypx);
+    fe_sub(n.ymx, y, x); fe_carry(n.ymx);
+    fe_mul(xy, x, y); fe_mul(n.xy2d, xy, fe_d2());
+}
+HS_HD void ge_basepoint(ge_p3 &b) {
+    const u32 bx[10] = FE26_BX, by[10] = FE26_BY, bt[10] = FE26_BT;
+    b.X = fe_const(bx); b.Y = fe_const(by); fe_1(b.Z); b.T = fe_const(bt);
+}
+// tab[j] = j*B for j = 0..count-1
+inline void make_base_table(ge_niels *tab, int count) {
+    ge_p3 b, p;
+    ge_basepoint(b);
+    ge_cached bc;
+    ge_to_cached(bc, b);
+    fe_1(tab[0].ypx); fe_1(tab[0].ymx); fe_0(tab[0].xy2d);
+    p = b;
+    for (int j = 1; j < count; j++) {
+        ge_p3_to_niels(tab[j], p);
+        ge_p1p1 t;
+        ge_add(t, p, bc, false);
+        ge_p1p1_to_p3(p, t, true);
+    }
+}
+
+}  // namespace hs

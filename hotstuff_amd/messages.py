@@ -1,0 +1,131 @@
+"""Call-site mirror of consensus/src/messages.rs for the verification path.
+
+Only what surrounds the signature checks is restated, so that parity tests read like
+the reference's own (consensus/src/tests/messages_tests.rs):
+
+* ``Committee.stake`` / ``quorum_threshold``   consensus/src/config.rs:63-72
+* ``QC.digest`` / ``QC.verify``                messages.rs:201-208, 180-198
+* ``TC.verify``                                messages.rs:290-315
+
+The structural checks (duplicate authority, unknown authority, quorum) run on the host
+exactly in the reference's order and raise before any signature is looked at; the
+signature checks go to the GPU engine: ``QC.verify`` -> one shared-digest BATCH call,
+``TC.verify`` -> one per-vote-digest STRICT call replacing the reference's serial loop
+of ``Signature::verify`` (messages.rs:307-313).
+"""
+import hashlib
+import struct
+
+from .crypto import CryptoError, Digest, Signature
+
+
+class ConsensusError(Exception):
+    """consensus::error::ConsensusError (the variants this path can raise)."""
+
+
+class AuthorityReuse(ConsensusError):
+    pass
+
+
+class UnknownAuthority(ConsensusError):
+    pass
+
+
+class QCRequiresQuorum(ConsensusError):
+    pass
+
+
+class TCRequiresQuorum(ConsensusError):
+    pass
+
+
+class InvalidSignature(ConsensusError):
+    """ConsensusError::InvalidSignature(#[from] CryptoError) consensus/src/error.rs:38-39."""
+
+
+class Committee:
+    """consensus::config::Committee reduced to what verify needs: name -> stake."""
+
+    def __init__(self, authorities, epoch=0):
+        self.authorities = dict(authorities)   # PublicKey -> stake
+        self.epoch = epoch
+
+    def size(self):
+        return len(self.authorities)
+
+    def stake(self, name):
+        return self.authorities.get(name, 0)
+
+    def quorum_threshold(self):
+        # config.rs:67-72: 2 * total / 3 + 1
+        return 2 * sum(self.authorities.values()) // 3 + 1
+
+
+def _check_quorum(names, committee, err):
+    weight = 0
+    used = set()
+    for name in names:
+        if name in used:
+            raise AuthorityReuse(name)
+        voting_rights = committee.stake(name)
+        if voting_rights <= 0:
+            raise UnknownAuthority(name)
+        used.add(name)
+        weight += voting_rights
+    if weight < committee.quorum_threshold():
+        raise err()
+
+
+class QC:
+    """messages.rs:164-169: hash, round, votes: Vec<(PublicKey, Signature)>."""
+
+    def __init__(self, hash=None, round=0, votes=None):
+        self.hash = hash if hash is not None else Digest()
+        self.round = round
+        self.votes = list(votes or [])
+
+    @classmethod
+    def genesis(cls):
+        return cls()
+
+    def digest(self):
+        # messages.rs:201-208: SHA-512(hash || round_le_u64)[..32]
+        h = hashlib.sha512()
+        h.update(self.hash.b)
+        h.update(struct.pack("<Q", self.round))
+        return Digest(h.digest()[:32])
+
+    def verify(self, committee):
+        _check_quorum((name for name, _ in self.votes), committee, QCRequiresQuorum)
+        try:
+            Signature.verify_batch(self.digest(), self.votes)
+        except CryptoError as e:
+            raise InvalidSignature() from e
+
+
+class TC:
+    """messages.rs:283-287: round, votes: Vec<(PublicKey, Signature, Round)>."""
+
+    def __init__(self, round=0, votes=None):
+        self.round = round
+        self.votes = list(votes or [])
+
+    def vote_digest(self, high_qc_round):
+        # messages.rs:307-311: SHA-512(round_le || high_qc_round_le)[..32]
+        h = hashlib.sha512()
+        h.update(struct.pack("<Q", self.round))
+        h.update(struct.pack("<Q", high_qc_round))
+        return Digest(h.digest()[:32])
+
+    def verify(self, committee):
+        _check_quorum((name for name, _, _ in self.votes), committee, TCRequiresQuorum)
+        digests = [self.vote_digest(r) for _, _, r in self.votes]
+        try:
+            oks = Signature.verify_many(digests, [(a, s) for a, s, _ in self.votes])
+        except CryptoError as e:
+            raise InvalidSignature() from e
+        if not all(oks):
+            raise InvalidSignature()
+
+    def high_qc_rounds(self):
+        return [r for _, _, r in self.votes]

@@ -1,0 +1,82 @@
+"""Sharding one large committee's signatures over the GPUs of a node.
+
+SURVEY.md 8(e): the units (signatures) are independent, so the batch is cut into
+contiguous index ranges, one per rank (one process per GPU).  No data-path collective
+is needed for the work itself; the single exchange step the north star names is an
+all-gather of the per-shard accept bitmaps so every rank - whichever one the host polls -
+holds the full bitmap and the global verdict.  With ``torch.distributed`` backend
+"nccl" that all-gather IS RCCL over xGMI; at ~1 KB per GPU it is latency-bound.
+
+Shard size is rounded up to a multiple of 64 signatures so that every shard's bitmap is
+whole 64-bit wavefront ballots and the gathered slices concatenate bit-exactly.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous range [lo, hi) of signature indices owned by `rank`, and the
+    per-rank padded shard size S (multiple of 64; every rank uses the same S)."""
+    per = (n + world - 1) // world
+    S = (per + 63) // 64 * 64 if n else 64
+    lo = min(n, rank * S)
+    hi = min(n, lo + S)
+    return lo, hi, S
+
+
+def gather_bitmaps(local_bitmap, group=None):
+    """All-gather equal-sized uint8 bitmap slices -> concatenated uint8 tensor
+    (world * len(local_bitmap) bytes) on every rank."""
+    world = dist.get_world_size(group)
+    out = torch.empty(world * local_bitmap.numel(), dtype=torch.uint8, device=local_bitmap.device)
+    dist.all_gather_into_tensor(out, local_bitmap.contiguous(), group=group)
+    return out
+
+
+def verify_sharded(verify_shard, n, group=None, device=None):
+    """Verify signatures [0, n) cooperatively.
+
+    verify_shard(lo, hi, S) -> uint8 tensor of S // 8 bytes on `device`: the accept
+    bitmap of signatures [lo, hi) (bit j = signature lo + j; bits past hi - lo zero).
+    Returns (all_ok: bool, bitmap: uint8 tensor of ceil(n / 8) bytes), identical on
+    every rank.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi, S = shard_bounds(n, world, rank)
+    local = verify_shard(lo, hi, S)
+    if local.numel() != S // 8:
+        raise ValueError("verify_shard must return S/8 = %d bytes, got %d" % (S // 8, local.numel()))
+    full = gather_bitmaps(local, group)
+    nbytes = (n + 7) // 8
+    bitmap = full[:nbytes]
+    # all accepted <=> the first n bits are all ones
+    if n == 0:
+        return True, bitmap
+    whole = n // 8
+    ok = bool((bitmap[:whole] == 0xFF).all().item()) if whole else True
+    if n % 8:
+        ok = ok and int(bitmap[whole].item()) == (1 << (n % 8)) - 1
+    return ok, bitmap
+
+
+class GpuShardVerifier:
+    """verify_shard callable for device-resident inputs: slices the packed tensors and
+    runs this rank's range through the C-ABI device entry point on the current stream."""
+
+    def __init__(self, digests, digest_stride, pks, sigs, mode, max_batch=None):
+        from . import _lib
+        self._lib = _lib
+        self.digests, self.digest_stride, self.pks, self.sigs, self.mode = digests, digest_stride, pks, sigs, mode
+        self.ctx = _lib.DeviceContext(max_batch or 1024)
+
+    def __call__(self, lo, hi, S):
+        dev = self.pks.device
+        bitmap = torch.zeros(S // 8, dtype=torch.uint8, device=dev)
+        n = hi - lo
+        if n > 0:
+            dg = self.digests if self.digest_stride == 0 else self.digests[32 * lo:]
+            self.ctx.verify(dg.data_ptr(), self.digest_stride, self.pks[32 * lo:].data_ptr(),
+                            self.sigs[64 * lo:].data_ptr(), n, self.mode, bitmap.data_ptr(), 0,
+                            torch.cuda.current_stream().cuda_stream)
+        return bitmap

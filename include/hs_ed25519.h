@@ -1,0 +1,112 @@
+/* hs_ed25519.h - C ABI of the MI355X batch Ed25519 verification engine.
+ *
+ * The reference (asonnino/hotstuff) has no FFI today; its boundary for this
+ * path is two Rust associated functions in crypto/src/lib.rs:
+ *
+ *   Signature::verify(&self, &Digest, &PublicKey)            lib.rs:200-204
+ *   Signature::verify_batch(&Digest, I: IntoIterator<...>)   lib.rs:206-219
+ *
+ * reached from consensus/src/messages.rs:64,144,258 (single), :197 (QC::verify,
+ * one shared digest) and :307-313 (TC::verify, one digest per vote).  These
+ * entry points are what a Rust `extern "C"` block in crypto/src/lib.rs binds
+ * (INTEGRATION.md shows the shim).  Plain pointers and sizes only.
+ *
+ * Data formats (reference types, crypto/src/lib.rs:21-22, 65-66, 178-182):
+ *   digest  32 bytes                         (Digest)
+ *   pk      32 bytes, compressed Edwards y   (PublicKey)
+ *   sig     64 bytes, R (part1) || s (part2) (Signature::flatten, lib.rs:193-198)
+ * Arrays are packed: element i of `pks` is at pks + 32*i, of `sigs` at
+ * sigs + 64*i, of `digests` at digests + 32*i.
+ *
+ * Verdict semantics (mode):
+ *   HS_ED25519_BATCH  (0)  the equation ed25519-dalek 1.0.1 `verify_batch`
+ *                          checks, decided per signature: s < L, A and R on the
+ *                          curve, [k](-A) + [s]B == R as points, cofactorless,
+ *                          no small-order rejection.  The call accepts iff every
+ *                          signature does.  (dalek's randomised sum gives the same
+ *                          answer except on crafted mixed-order inputs where dalek
+ *                          itself is non-deterministic; those are rejected here.)
+ *   HS_ED25519_STRICT (1)  `PublicKey::verify_strict`: BATCH plus reject when
+ *                          [8]R == O or [8]A == O.
+ *
+ * Return value of every verify call:
+ *    1  every signature accepted (n == 0 -> 1, as lib.rs:206-219 returns Ok)
+ *    0  at least one signature rejected
+ *   <0  engine error (HS_ED25519_E_*); the caller must treat it as Err - the
+ *       engine never reports success on failure and has no CPU fallback inside.
+ * bitmap (optional, may be NULL): bit (i & 7) of byte (i >> 3) is 1 iff
+ * signature i was accepted; ceil(n/8) bytes are written.
+ *
+ * Thread safety: every function may be called concurrently from any thread
+ * (the reference's tests call verify from several threads of one process,
+ * SURVEY.md 8b); calls are served from an internal pool of stream contexts.
+ */
+#ifndef HS_ED25519_H
+#define HS_ED25519_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_ED25519_BATCH 0u
+#define HS_ED25519_STRICT 1u
+
+#define HS_ED25519_E_NOT_INIT (-1) /* hs_ed25519_init not called or failed        */
+#define HS_ED25519_E_DEVICE (-2)   /* HIP runtime error (see hs_ed25519_last_error) */
+#define HS_ED25519_E_ARG (-3)      /* null / misaligned pointer, bad mode           */
+#define HS_ED25519_E_NOMEM (-4)    /* allocation failure                            */
+
+/* Select the GPU (HIP ordinal), upload the base-point table and pre-size the
+ * context pool for batches of `max_batch` signatures (contexts grow on demand).
+ * Idempotent and thread-safe.  Returns 0 or HS_ED25519_E_*. */
+int hs_ed25519_init(int device, size_t max_batch);
+void hs_ed25519_shutdown(void);
+/* Human-readable text of the last engine error seen by the calling thread. */
+const char *hs_ed25519_last_error(void);
+
+/* Signature::verify_batch / QC::verify shape: one digest shared by n pairs.
+ * Replaces crypto/src/lib.rs:206-219 (called at consensus/src/messages.rs:197). */
+int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
+                             size_t n, uint32_t mode, uint8_t *bitmap);
+
+/* TC::verify shape: one digest per pair.  Replaces the loop of
+ * Signature::verify calls at consensus/src/messages.rs:307-313 (mode STRICT),
+ * and with n = 1 a single crypto/src/lib.rs:200-204 call. */
+int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
+                            size_t n, uint32_t mode, uint8_t *bitmap);
+
+/* ---- device-resident variant (streamed rounds, benchmarks, multi-GPU shards) ----
+ * All data pointers are DEVICE pointers on the initialised GPU, 16-byte aligned.
+ *   d_digests     n*32 bytes, or 32 bytes when digest_stride == 0 (shared digest)
+ *   digest_stride 0 or 32
+ *   d_bitmap      8*ceil(n/64) bytes, written in full (bits >= n are 0)
+ *   d_nreject     one uint32, incremented by the number of rejected signatures
+ *                 (zero it before the call); may be NULL
+ *   stream        hipStream_t to enqueue on (NULL = the context's own stream)
+ * Enqueues and returns immediately: 0 on success or HS_ED25519_E_*.  The scratch
+ * workspace belongs to `ctx`; a context serves one call at a time per stream order. */
+typedef struct hs_ed25519_ctx hs_ed25519_ctx;
+int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch);
+void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);
+int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
+                             const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
+                             uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
+
+/* Profiling: keep a ring of `slots` HIP-event triples recorded on the launch stream around
+ * the two kernels of each hs_ed25519_verify_device call on `ctx` (0 = off).  After the
+ * stream has been synchronised, hs_ed25519_ctx_kernel_times returns the summed durations
+ * (ms) of the prepare and verify kernels over the recorded calls and their count. */
+int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots);
+int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
+                                size_t *launches);
+
+/* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
+const char *hs_ed25519_dominant_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,65 @@
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _make(path):
+    subprocess.run(["make", "-C", path], check=True, capture_output=True)
+
+
+S = ctypes.c_size_t
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C oracle (test infrastructure)."""
+    so = os.path.join(ROOT, "oracle", "libhs_oracle.so")
+    if not os.path.exists(so):
+        _make(os.path.join(ROOT, "oracle"))
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """The product's device headers compiled for the CPU (tests/emu)."""
+    so = os.path.join(ROOT, "tests", "emu", "libhs_emu.so")
+    try:
+        _make(os.path.join(ROOT, "tests", "emu"))
+    except Exception:
+        if not os.path.exists(so):
+            raise
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def openssl_vectors():
+    return json.load(open(os.path.join(GOLDEN, "openssl_vectors.json")))
+
+
+@pytest.fixture(scope="session")
+def edge_vectors():
+    return json.load(open(os.path.join(GOLDEN, "edge_vectors.json")))["vectors"]
+
+
+def oracle_verify_many(orc, digests, stride, pks, sigs, n, mode):
+    out = ctypes.create_string_buffer(max(1, n))
+    orc.hs_oracle_verify_many(digests, S(32), S(stride), pks, sigs, S(n), mode, out, 1)
+    return out.raw[:n]
+
+
+def bits(bitmap, n):
+    return bytes((bitmap[i >> 3] >> (i & 7)) & 1 for i in range(n))

@@ -1,0 +1,69 @@
+// tests/emu/emu.cpp - TEST INFRASTRUCTURE.  Compiles the product's host+device headers
+// (hotstuff_amd/csrc/*.h) with g++ and runs the two lane stages serially on the CPU, so the
+// exact device arithmetic can be checked against oracle/ without a GPU.  Never shipped and
+// never used by the product path (which has no CPU fallback).
+#include <cstring>
+#include <vector>
+#include "../../hotstuff_amd/csrc/verify.h"
+using namespace hs;
+
+static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
+
+extern "C" {
+void emu_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *r) {
+    u32 wa[8], wb[8], wr[8]; load_words(wa, a, 8); load_words(wb, b, 8);
+    fe x, y, z; fe_from_words(x, wa); fe_from_words(y, wb); fe_mul(z, x, y); fe_to_words(wr, z); memcpy(r, wr, 32);
+}
+// loose-operand multiplication: (a1 + a2) * (b1 + 2p - b2)  exercises the 2x / 3x bounds
+void emu_fe_mul_loose(const uint8_t *a1, const uint8_t *a2, const uint8_t *b1, const uint8_t *b2, uint8_t *r) {
+    u32 w[8], wr[8]; fe x1, x2, y1, y2, f, g, z;
+    load_words(w, a1, 8); fe_from_words(x1, w); load_words(w, a2, 8); fe_from_words(x2, w);
+    load_words(w, b1, 8); fe_from_words(y1, w); load_words(w, b2, 8); fe_from_words(y2, w);
+    fe_add(f, x1, x2); fe_sub(g, y1, y2); fe_mul(z, f, g); fe_to_words(wr, z); memcpy(r, wr, 32);
+}
+void emu_fe_sq_loose(const uint8_t *a1, const uint8_t *a2, uint8_t *r) {   // (a1 + 2p - a2)^2
+    u32 w[8], wr[8]; fe x1, x2, f, z;
+    load_words(w, a1, 8); fe_from_words(x1, w); load_words(w, a2, 8); fe_from_words(x2, w);
+    fe_sub(f, x1, x2); fe_sq(z, f); fe_to_words(wr, z); memcpy(r, wr, 32);
+}
+void emu_fe_sq(const uint8_t *a, uint8_t *r) {
+    u32 wa[8], wr[8]; load_words(wa, a, 8); fe x, z; fe_from_words(x, wa); fe_sq(z, x); fe_to_words(wr, z); memcpy(r, wr, 32);
+}
+void emu_fe_invert(const uint8_t *a, uint8_t *r) {
+    u32 wa[8], wr[8]; load_words(wa, a, 8); fe x, z; fe_from_words(x, wa); fe_invert(z, x); fe_to_words(wr, z); memcpy(r, wr, 32);
+}
+void emu_fe_roundtrip(const uint8_t *a, uint8_t *r) {
+    u32 wa[8], wr[8]; load_words(wa, a, 8); fe x; fe_from_words(x, wa); fe_to_words(wr, x); memcpy(r, wr, 32);
+}
+void emu_sha512_96(const uint8_t *in, uint8_t *out) { u32 wi[24], wo[16]; load_words(wi, in, 24); sha512_96(wo, wi); memcpy(out, wo, 64); }
+void emu_sc_reduce512(const uint8_t *in, uint8_t *out) { u32 wi[16], wo[8]; load_words(wi, in, 16); sc_reduce512(wo, wi); memcpy(out, wo, 32); }
+void emu_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { u32 wa[8], wb[8], wo[8]; load_words(wa, a, 8); load_words(wb, b, 8); sc_mul(wo, wa, wb); memcpy(out, wo, 32); }
+int emu_sc_is_canonical(const uint8_t *s) { u32 w[8]; load_words(w, s, 8); return sc_is_canonical(w); }
+// digits of the signed radix-16 recoding, most significant first
+void emu_sc_digits(const uint8_t *s, int8_t *digits) {
+    u32 w[8], r[8]; load_words(w, s, 8); sc_recode16(r, w);
+    for (int i = 0; i < 64; i++) digits[i] = (int8_t)sc_pop_digit(r);
+}
+int emu_decompress(const uint8_t *s, uint8_t *x, uint8_t *y, int *small) {
+    u32 w[8], wx[8], wy[8]; load_words(w, s, 8); ge_p3 p; bool ok = ge_decompress(p, w);
+    fe_to_words(wx, p.X); fe_to_words(wy, p.Y); memcpy(x, wx, 32); memcpy(y, wy, 32);
+    *small = ok ? ge_is_small_order(p) : 0;
+    return ok;
+}
+// out[i] = per-signature verdict.  msg_stride = 0 (shared digest) or 32.
+void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                uint32_t mode, uint8_t *out) {
+    if (!n) return;
+    const u32 np = (u32)((n + 63) / 64 * 64);
+    std::vector<u32> buf(workspace_words(np));
+    workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    ge_niels btab[9]; make_base_table(btab, 9);
+    for (size_t t = 0; t < 2 * n; t++) {
+        const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
+        u32 pk[8], sig[16], msg[8];
+        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        prepare_point(ws, (u32)i, is_r, pk, sig, msg, mode);
+    }
+    for (size_t i = 0; i < n; i++) out[i] = verify_lane(ws, (u32)i, mode, btab) ? 1 : 0;
+}
+}

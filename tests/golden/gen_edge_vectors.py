@@ -7,10 +7,15 @@ Each vector: name, class, msg, pk, sig (hex) and three verdicts:
   strict        Signature::verify        (crypto/src/lib.rs:200-204)
   cofactorless  the per-signature equation verify_batch sums (lib.rs:206-219)
   cofactored    [8](sB - kA - R) == O
-Batch law: a batch containing the vector is accepted by
-dalek iff cofactorless (class ii), rejected iff not cofactored (class i), and
-is "dalek-nondeterministic" when cofactored and not cofactorless (class iii);
-this engine rejects class iii.
+  torsion_free  A and R both decode into the prime-order subgroup
+Batch law (refines SURVEY.md 8a A4-note): dalek::verify_batch sums
+[z_i]R_i + [z_i k_i mod L]A_i with random 128-bit z_i, so
+  * not cofactored                  -> rejected (w.p. 1 - 2^-125)           class i
+  * cofactorless and torsion_free   -> accepted always                      class ii
+  * anything else that is cofactored (a torsion component in A or R, even when the
+    per-signature cofactorless equation holds, because z_i k_i is reduced mod L) ->
+    dalek's answer depends on the z_i: "dalek-nondeterministic"            class iii
+On class iii this engine returns the per-signature cofactorless verdict.
 
     python tests/golden/gen_edge_vectors.py
 """
@@ -35,12 +40,19 @@ def le32(v):
 VEC = []
 
 
+def _torsion_free(enc):
+    """True iff enc decodes to a point of the prime-order subgroup ([L]P == O)."""
+    p = E.decompress(enc)
+    return p is not None and E.pt_is_identity(E.pt_mul(E.L, p))
+
+
 def add(name, cls, msg, pk, sig):
     VEC.append({
         "name": name, "class": cls, "msg": msg.hex(), "pk": pk.hex(), "sig": sig.hex(),
         "strict": E.verify_strict(msg, pk, sig),
         "cofactorless": E.verify_cofactorless(msg, pk, sig),
         "cofactored": E.verify_cofactored(msg, pk, sig),
+        "torsion_free": _torsion_free(pk) and _torsion_free(sig[:32]),
     })
 
 

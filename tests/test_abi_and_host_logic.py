@@ -1,0 +1,95 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/hs_ed25519.h declares;
+the host-side mirror of the reference interface behaves like the reference's own tests
+(consensus/src/tests/messages_tests.rs) for everything that happens BEFORE the signature
+check; and without a GPU every verification fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from hotstuff_amd import _lib
+from hotstuff_amd.crypto import CryptoError, Digest, PublicKey, Signature
+from hotstuff_amd.messages import (QC, TC, AuthorityReuse, Committee, QCRequiresQuorum, TCRequiresQuorum,
+                                   UnknownAuthority)
+
+H = bytes.fromhex
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hs_ed25519.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(hs_ed25519_\w+)\s*\(", hdr)))
+    assert len(names) >= 9, names
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libhs_ed25519.so does not export " + n
+    assert _lib.lib() is not None      # the package binds them all
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """The product path must not import, link or execute anything under oracle/ or tests/."""
+    pkg = os.path.join(ROOT, "hotstuff_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("//", "#", "*", '"""')))
+                assert "hs_oracle" not in code and "libhs_oracle" not in code and "libhs_emu" not in code, f
+                assert not re.search(r"^\s*(import|from)\s+(ed25519_ref|synth)\b", src, flags=re.M), f
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_never_success():
+    sig = Signature()
+    with pytest.raises(CryptoError):
+        sig.verify(Digest(), PublicKey())
+    with pytest.raises(CryptoError):
+        Signature.verify_batch(Digest(), [(PublicKey(), Signature())])
+    # the empty batch never reaches the engine: Ok, as lib.rs:206-219 returns for an empty iterator
+    assert Signature.verify_batch(Digest(), []) is None
+
+
+def _fixture(openssl_vectors):
+    fx = openssl_vectors["reference_fixture"]
+    keys = [PublicKey(H(k["pk"])) for k in fx["keys"]]
+    committee = Committee({k: 1 for k in keys}, epoch=100)
+    votes = [(PublicKey(H(v["pk"])), Signature.from_bytes(H(v["sig"]))) for v in fx["qc_votes"]]
+    return fx, keys, committee, votes
+
+
+def test_types_mirror_reference(openssl_vectors):
+    fx, keys, committee, votes = _fixture(openssl_vectors)
+    k = keys[0]
+    assert PublicKey.decode_base64(k.encode_base64()) == k          # crypto_tests.rs:31-38
+    assert k.encode_base64() == "IP26ybELdYe7p7W8FjvOaeeW1x5O1EwQ/LRIhon3oUQ="
+    s = votes[0][1]
+    assert s.flatten() == s.part1 + s.part2 and len(s.flatten()) == 64
+    assert Signature.default().flatten() == bytes(64)
+    assert committee.quorum_threshold() == 3 and committee.size() == 4   # config.rs:67-72, N = 4
+    qc = QC(Digest(), 1, votes)
+    assert qc.digest().b == H(fx["qc_digest"])                      # messages.rs:201-208
+
+
+def test_qc_structural_errors_precede_crypto(openssl_vectors):
+    """messages_tests.rs:13-55: these raise before any signature is verified (so they
+    pass on a machine without a GPU)."""
+    fx, keys, committee, votes = _fixture(openssl_vectors)
+    qc = QC(Digest(), 1, votes[:2] + [votes[0]])
+    with pytest.raises(AuthorityReuse):
+        qc.verify(committee)
+    unknown = PublicKey(bytes(range(32)))
+    with pytest.raises(UnknownAuthority):
+        QC(Digest(), 1, votes[:2] + [(unknown, votes[2][1])]).verify(committee)
+    with pytest.raises(QCRequiresQuorum):
+        QC(Digest(), 1, votes[:2]).verify(committee)
+    tc_votes = [(a, s, 0) for a, s in votes]
+    with pytest.raises(AuthorityReuse):
+        TC(2, tc_votes[:2] + [tc_votes[0]]).verify(committee)
+    with pytest.raises(TCRequiresQuorum):
+        TC(2, tc_votes[:2]).verify(committee)
+    tc = TC(7, tc_votes)
+    import hashlib, struct
+    assert tc.vote_digest(3).b == hashlib.sha512(struct.pack("<QQ", 7, 3)).digest()[:32]   # messages.rs:307-311

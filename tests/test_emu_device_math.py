@@ -1,0 +1,113 @@
+"""The product's device headers (hotstuff_amd/csrc/*.h) compiled for the CPU and checked
+against the big-int ground truth, hashlib and the C oracle - the same arithmetic the
+gfx950 kernels run, validated without a GPU."""
+import ctypes
+import hashlib
+import os
+import random
+
+import ed25519_ref as E
+from conftest import S, oracle_verify_many
+
+P, L = E.P, E.L
+
+
+def rb(v):
+    return int(v).to_bytes(32, "little")
+
+
+def B(n):
+    return ctypes.create_string_buffer(n)
+
+
+SPECIAL = [0, 1, 2, P - 1, P - 2, P, P + 1, 2 ** 255 - 1, 2 ** 255 - 19, 2 ** 254, 19, (1 << 255) - 20,
+           2 ** 26 - 1, 2 ** 51 - 1, (2 ** 255 - 1) ^ 0x5555]
+
+
+def test_field_ops(emu):
+    rnd = random.Random(11)
+    o = B(32)
+    for i in range(400):
+        a = rnd.choice(SPECIAL) if i < 60 else rnd.getrandbits(255)
+        b = rnd.choice(SPECIAL) if i < 30 else rnd.getrandbits(255)
+        c = rnd.getrandbits(255)
+        d = rnd.choice(SPECIAL) if i % 3 == 0 else rnd.getrandbits(255)
+        emu.emu_fe_mul(rb(a), rb(b), o); assert int.from_bytes(o.raw, "little") == a * b % P
+        emu.emu_fe_sq(rb(a), o); assert int.from_bytes(o.raw, "little") == a * a % P
+        emu.emu_fe_roundtrip(rb(a), o); assert int.from_bytes(o.raw, "little") == a % 2 ** 255 % P
+        # loose operands exercise the documented 2x / 3x limb bounds
+        emu.emu_fe_mul_loose(rb(a), rb(c), rb(b), rb(d), o)
+        assert int.from_bytes(o.raw, "little") == ((a % 2**255) + c) * ((b % 2**255) - (d % 2**255)) % P
+        emu.emu_fe_sq_loose(rb(a), rb(d), o)
+        assert int.from_bytes(o.raw, "little") == ((a % 2**255) - (d % 2**255)) ** 2 % P
+        if i < 60:
+            emu.emu_fe_invert(rb(a), o); assert int.from_bytes(o.raw, "little") == pow(a % 2**255, P - 2, P)
+
+
+def test_sha512_and_scalars(emu):
+    rnd = random.Random(12)
+    o64, o = B(64), B(32)
+    for i in range(100):
+        m = os.urandom(96)
+        emu.emu_sha512_96(m, o64)
+        assert o64.raw == hashlib.sha512(m).digest()
+    edge = [b"\xff" * 64, b"\0" * 64, (L * L - 1).to_bytes(64, "little"), L.to_bytes(64, "little"),
+            (L - 1).to_bytes(64, "little"), (2 ** 252).to_bytes(64, "little"), (L << 259).to_bytes(64, "little"),
+            (2 ** 511).to_bytes(64, "little"), (5 * L + 3).to_bytes(64, "little"), (2 * L - 1).to_bytes(64, "little")]
+    for h in edge + [os.urandom(64) for _ in range(200)]:
+        emu.emu_sc_reduce512(h, o)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(h, "little") % L
+    for _ in range(100):
+        a, b = rnd.getrandbits(256), rnd.getrandbits(256)
+        emu.emu_sc_mul(rb(a), rb(b), o)
+        assert int.from_bytes(o.raw, "little") == a * b % L
+    for s in [0, 1, L - 1, L, L + 1, 2 ** 252, 2 ** 253, 2 ** 256 - 1, L - 2 ** 32, L + 2 ** 64]:
+        assert emu.emu_sc_is_canonical(rb(s)) == int(s < L)
+    dg = (ctypes.c_int8 * 64)()
+    for i in range(60):
+        s = [0, 1, L - 1, 2 ** 253 - 1, 2 ** 252, 0x8888 << 200][i] if i < 6 else rnd.getrandbits(253)
+        emu.emu_sc_digits(rb(s), dg)
+        v = 0
+        for d in dg:
+            assert -8 <= d <= 7
+            v = v * 16 + d
+        assert v == s
+
+
+def test_decompress_matches_dalek_rules(emu, edge_vectors):
+    x, y, sm = B(32), B(32), ctypes.c_int()
+    encs = [os.urandom(32) for _ in range(80)]
+    encs += [bytes.fromhex(v["pk"]) for v in edge_vectors] + [bytes.fromhex(v["sig"])[:32] for v in edge_vectors]
+    for e in encs:
+        ok = emu.emu_decompress(e, x, y, ctypes.byref(sm))
+        p = E.decompress(e)
+        assert bool(ok) == (p is not None)
+        if ok:
+            assert int.from_bytes(x.raw, "little") == p[0] and int.from_bytes(y.raw, "little") == p[1]
+            assert bool(sm.value) == E.pt_is_small_order(p)
+
+
+def test_verify_stages_on_edge_vectors(emu, edge_vectors):
+    n = len(edge_vectors)
+    msgs = b"".join(bytes.fromhex(v["msg"]) for v in edge_vectors)
+    pks = b"".join(bytes.fromhex(v["pk"]) for v in edge_vectors)
+    sigs = b"".join(bytes.fromhex(v["sig"]) for v in edge_vectors)
+    out = B(n)
+    emu.emu_verify(msgs, S(32), pks, sigs, S(n), 1, out)
+    assert [bool(b) for b in out.raw] == [v["strict"] for v in edge_vectors]
+    emu.emu_verify(msgs, S(32), pks, sigs, S(n), 0, out)
+    assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in edge_vectors]
+
+
+def test_verify_stages_vs_c_oracle_random(emu, oracle):
+    import synth
+    n = 96
+    for shared in (False, True):
+        dg, pk, sg = synth.make_batch(n, shared=shared)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=64)
+        stride = 0 if shared else 32
+        for mode in (0, 1):
+            out = B(n)
+            emu.emu_verify(dg, S(stride), pk, sg, S(n), mode, out)
+            assert out.raw == oracle_verify_many(oracle, dg, stride, pk, sg, n, mode)
+            assert [i for i in range(n) if not out.raw[i]] == bad

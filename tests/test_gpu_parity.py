@@ -1,0 +1,240 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (ctypes ->
+libhs_ed25519.so), against the golden fixtures, the edge-vector set and the CPU oracle on
+the same seeded inputs; size-independent properties at BASELINE.json's full sizes.
+Bit-exact: this is integer work, the accept bitmap must be identical.
+Never reads /root/reference (it does not exist on the GPU box)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+from hotstuff_amd.crypto import CryptoError, Digest, PublicKey, Signature
+from hotstuff_amd.messages import QC, TC, Committee, InvalidSignature
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.init(0, 8192)
+    yield
+
+
+def gpu_bits(dg, pk, sg, n, mode, shared):
+    ok, bm = _lib.verify_packed(dg, pk, sg, n, mode, shared=shared, want_bitmap=True)
+    b = bits(bm, n)
+    assert ok == all(b)
+    return b
+
+
+def test_openssl_vectors(openssl_vectors):
+    # (the RFC 8032 vectors have 0-2 byte messages; the boundary takes 32-byte digests only,
+    #  crypto/src/lib.rs:21 - they pin the oracle in test_oracle_golden.py instead)
+    vec = openssl_vectors["openssl_sign"]
+    n = len(vec)
+    dg = b"".join(H(v["msg"]) for v in vec)
+    pk = b"".join(H(v["pk"]) for v in vec)
+    sg = b"".join(H(v["sig"]) for v in vec)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        assert gpu_bits(dg, pk, sg, n, mode, False) == b"\x01" * n
+    # every recorded single-bit tampering is rejected (OpenSSL's own verdict is in the fixture)
+    t_dg, t_pk, t_sg, expect = bytearray(), bytearray(), bytearray(), []
+    for v in vec:
+        for t in v["tamper"]:
+            f = {"sig": bytearray(H(v["sig"])), "pk": bytearray(H(v["pk"])), "msg": bytearray(H(v["msg"]))}
+            f[t["field"]][t["byte"]] ^= 1 << t["bit"]
+            t_dg += f["msg"]; t_pk += f["pk"]; t_sg += f["sig"]
+            expect.append(1 if t["openssl_accepts"] else 0)
+    m = len(expect)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        assert gpu_bits(bytes(t_dg), bytes(t_pk), bytes(t_sg), m, mode, False) == bytes(expect)
+
+
+def test_reference_own_test_cases(openssl_vectors):
+    """crypto_tests.rs:50-115 and messages_tests.rs:8-10 through the interface mirror."""
+    fx = openssl_vectors["reference_fixture"]
+    order = fx["pop_order"]
+    pk = [PublicKey(H(fx["keys"][i]["pk"])) for i in order]
+    sig = [Signature.from_bytes(H(s)) for s in fx["hello_sigs"]]
+    hello, bad = Digest(H(fx["hello_digest"])), Digest(H(fx["bad_digest"]))
+    assert sig[0].verify(hello, pk[0]) is None                       # verify_valid_signature
+    with pytest.raises(CryptoError):
+        sig[0].verify(bad, pk[0])                                    # verify_invalid_signature
+    assert Signature.verify_batch(hello, list(zip(pk[:3], sig[:3]))) is None   # verify_valid_batch
+    with pytest.raises(CryptoError):                                 # verify_invalid_batch
+        Signature.verify_batch(hello, list(zip(pk[:3], sig[:2] + [Signature.default()])))
+    assert Signature.verify_batch(hello, []) is None                 # empty iterator -> Ok
+    committee = Committee({PublicKey(H(k["pk"])): 1 for k in fx["keys"]}, 100)
+    votes = [(PublicKey(H(v["pk"])), Signature.from_bytes(H(v["sig"]))) for v in fx["qc_votes"]]
+    assert QC(Digest(), 1, votes).verify(committee) is None          # verify_valid_qc
+    broken = [votes[0], votes[1], (votes[2][0], votes[1][1])]
+    with pytest.raises(InvalidSignature):
+        QC(Digest(), 1, broken).verify(committee)
+
+
+def test_tc_verify_shape(oracle):
+    """TC::verify (messages.rs:290-315): per-vote digests, strict semantics, one GPU call."""
+    n = 4
+    names = [PublicKey(synth.sign(synth.key_seed(i), b"")[0]) for i in range(n)]
+    committee = Committee({k: 1 for k in names})
+    tc = TC(9, [])
+    votes = []
+    for i in range(3):
+        d = tc.vote_digest(i + 1)
+        _, sg = synth.sign(synth.key_seed(i), d.b)
+        votes.append((names[i], Signature.from_bytes(sg), i + 1))
+    assert TC(9, votes).verify(committee) is None
+    votes[1] = (votes[1][0], votes[1][1], 5)      # signed round differs from the claimed one
+    with pytest.raises(InvalidSignature):
+        TC(9, votes).verify(committee)
+
+
+def test_edge_vectors_both_modes(edge_vectors):
+    n = len(edge_vectors)
+    dg = b"".join(H(v["msg"]) for v in edge_vectors)
+    pk = b"".join(H(v["pk"]) for v in edge_vectors)
+    sg = b"".join(H(v["sig"]) for v in edge_vectors)
+    got = gpu_bits(dg, pk, sg, n, _lib.STRICT, False)
+    for v, g in zip(edge_vectors, got):
+        assert bool(g) == v["strict"], ("strict", v["name"])
+    got = gpu_bits(dg, pk, sg, n, _lib.BATCH, False)
+    for v, g in zip(edge_vectors, got):
+        assert bool(g) == v["cofactorless"], ("batch", v["name"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 94, 95, 128, 1000])
+@pytest.mark.parametrize("shared", [True, False])
+def test_sizes_vs_oracle_with_corruption(oracle, n, shared):
+    dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)
+    stride = 0 if shared else 32
+    for mode in (_lib.BATCH, _lib.STRICT):
+        got = gpu_bits(dg, pk, sg, n, mode, shared)
+        assert got == oracle_verify_many(oracle, dg, stride, pk, sg, n, mode)
+        assert [i for i in range(n) if not got[i]] == bad
+
+
+def test_config2_1024_tuples_bit_exact(oracle):
+    """BASELINE config 2: 1,024 distinct (digest, pk, sig) tuples, ~3 % corrupted (SURVEY 8d mix)."""
+    n = 1024
+    dg, pk, sg = synth.make_batch(n, shared=False, cache_dir=CACHE)
+    assert gpu_bits(dg, pk, sg, n, _lib.STRICT, False) == b"\x01" * n
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, False)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        got = gpu_bits(dg, pk, sg, n, mode, False)
+        assert got == oracle_verify_many(oracle, dg, 32, pk, sg, n, mode)
+        assert [i for i in range(n) if not got[i]] == bad and len(bad) > 10
+
+
+def test_config3_qc_10000_validators_properties():
+    """BASELINE config 3: N = 10,000 -> n = 6,667 signatures over one digest.  Full-size,
+    oracle-free properties: all-valid accepts; a single flipped bit clears exactly that
+    signature's bit; the verdict is idempotent and invariant under permutation."""
+    n = 6667
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)
+    assert ok and bits(bm, n) == b"\x01" * n
+    ok2, bm2 = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)
+    assert ok2 and bm2 == bm                                         # idempotent
+    for victim in (0, 4242, n - 1):
+        s2 = bytearray(sg); s2[64 * victim + 17] ^= 0x04
+        ok, bm = _lib.verify_packed(dg, pk, bytes(s2), n, _lib.BATCH, shared=True, want_bitmap=True)
+        b = bits(bm, n)
+        assert not ok and [i for i in range(n) if not b[i]] == [victim]
+    # permutation: reverse the votes, corrupt one, the cleared bit moves with it
+    rp = b"".join(pk[32 * i:32 * i + 32] for i in reversed(range(n)))
+    rs = bytearray(b"".join(sg[64 * i:64 * i + 64] for i in reversed(range(n))))
+    rs[64 * 10 + 40] ^= 1
+    ok, bm = _lib.verify_packed(dg, rp, bytes(rs), n, _lib.BATCH, shared=True, want_bitmap=True)
+    b = bits(bm, n)
+    assert not ok and [i for i in range(n) if not b[i]] == [10]
+    # wrong shared digest: every signature rejected
+    ok, bm = _lib.verify_packed(bytes(32), pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)
+    assert not ok and bits(bm, n) == b"\x00" * n
+
+
+def test_device_resident_api_matches_host_api(oracle):
+    """hs_ed25519_verify_device on torch-owned HBM buffers and torch's current stream."""
+    n = 1000
+    dg, pk, sg = synth.make_batch(n, shared=False, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, False, rate_byte=30)
+    dev = torch.device("cuda:0")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
+    d_bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
+    d_nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = _lib.DeviceContext(n)
+    ctx.verify(d_dg.data_ptr(), 32, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.STRICT, d_bm.data_ptr(),
+               d_nr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = bits(bytes(d_bm.cpu().tolist()), n)
+    assert got == oracle_verify_many(oracle, dg, 32, pk, sg, n, 1)
+    assert int(d_nr.item()) == len(bad)
+    assert bytes(d_bm.cpu().tolist())[(n + 7) // 8:] == bytes(len(d_bm) - (n + 7) // 8)   # tail bits zero
+    ctx.close()
+
+
+def test_argument_errors_are_errors_not_accepts():
+    ctx = _lib.DeviceContext(64)
+    with pytest.raises(_lib.EngineError):
+        ctx.verify(8, 32, 16, 16, 4, 0, 16)            # misaligned device pointers
+    with pytest.raises(_lib.EngineError):
+        ctx.verify(0, 32, 0, 0, 4, 0, 0)               # null pointers
+    with pytest.raises(_lib.EngineError):
+        _lib.check(_lib.lib().hs_ed25519_verify_multi(None, None, None, 3, 0, None), "verify")
+    ctx.close()
+
+
+def test_concurrent_host_calls_are_thread_safe(oracle):
+    """the reference's tests call verify from several threads of one process."""
+    import threading
+    n = 200
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    _, _, sg_bad, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=40)
+    results = {}
+
+    def work(k):
+        s = sg_bad if k % 2 else sg
+        results[k] = [_lib.verify_packed(dg, pk, s, n, _lib.BATCH, shared=True, want_bitmap=True) for _ in range(3)]
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k, rs in results.items():
+        for ok, bm in rs:
+            b = bits(bm, n)
+            assert [i for i in range(n) if not b[i]] == (bad if k % 2 else [])
+            assert ok == (k % 2 == 0)
+
+
+def test_single_gpu_sharded_path_over_rccl():
+    """hotstuff_amd.sharding with the real GPU verifier and the nccl (= RCCL) backend at
+    world_size 1 (gpurun boxes have one GPU; N > 1 is the driver's scaling run)."""
+    import torch.distributed as dist
+    from hotstuff_amd.sharding import GpuShardVerifier, verify_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        n = 1500
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        s2 = bytearray(sg); s2[64 * 77] ^= 1
+        dev = torch.device("cuda:0")
+        t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        v = GpuShardVerifier(t(dg), 0, t(pk), t(bytes(s2)), _lib.BATCH, n)
+        ok, bm = verify_sharded(v, n)
+        b = bits(bytes(bm.cpu().tolist()), n)
+        assert not ok and [i for i in range(n) if not b[i]] == [77]
+    finally:
+        if created:
+            dist.destroy_process_group()

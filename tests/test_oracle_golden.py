@@ -1,0 +1,115 @@
+"""Pin the oracle (both restatements) against every golden vector we hold:
+RFC 8032, OpenSSL-generated fixtures, the reference's own test inputs restated, and
+the edge-vector set.  CPU only."""
+import ctypes
+
+import ed25519_ref as E
+from conftest import S, oracle_verify_many
+
+H = bytes.fromhex
+
+
+def c_verify(orc, msg, pk, sig, strict):
+    f = orc.hs_oracle_verify_strict if strict else orc.hs_oracle_verify_cofactorless
+    return f(msg, S(len(msg)), pk, sig) == 1
+
+
+def test_rfc8032(oracle, openssl_vectors):
+    for v in openssl_vectors["rfc8032"]:
+        seed, pk, msg, sig = H(v["seed"]), H(v["pk"]), H(v["msg"]), H(v["sig"])
+        assert E.public_key(seed) == pk and E.sign(seed, msg) == sig
+        o_pk, o_sig = ctypes.create_string_buffer(32), ctypes.create_string_buffer(64)
+        oracle.hs_oracle_public_key(seed, o_pk)
+        oracle.hs_oracle_sign(seed, msg, S(len(msg)), o_sig)
+        assert o_pk.raw == pk and o_sig.raw == sig
+        for strict in (0, 1):
+            assert c_verify(oracle, msg, pk, sig, strict)
+        assert E.verify_strict(msg, pk, sig) and E.verify_cofactorless(msg, pk, sig)
+        assert not c_verify(oracle, msg + b"x", pk, sig, 1)
+
+
+def test_openssl_signed_and_tampered(oracle, openssl_vectors):
+    for v in openssl_vectors["openssl_sign"]:
+        seed, pk, msg, sig = H(v["seed"]), H(v["pk"]), H(v["msg"]), H(v["sig"])
+        # our signer reproduces OpenSSL's deterministic signature byte for byte
+        assert E.public_key(seed) == pk and E.sign(seed, msg) == sig
+        assert c_verify(oracle, msg, pk, sig, 1) and c_verify(oracle, msg, pk, sig, 0)
+        for t in v["tamper"]:
+            f = {"sig": bytearray(sig), "pk": bytearray(pk), "msg": bytearray(msg)}
+            f[t["field"]][t["byte"]] ^= 1 << t["bit"]
+            m2, p2, s2 = bytes(f["msg"]), bytes(f["pk"]), bytes(f["sig"])
+            # single-bit tamperings: OpenSSL, dalek-strict and dalek-batch semantics all reject
+            assert t["openssl_accepts"] is False
+            assert not c_verify(oracle, m2, p2, s2, 1) and not c_verify(oracle, m2, p2, s2, 0)
+            assert not E.verify_strict(m2, p2, s2)
+
+
+def test_reference_fixture_expectations(oracle, openssl_vectors):
+    """The reference's crypto_tests.rs / messages_tests.rs cases, on the restated fixture."""
+    fx = openssl_vectors["reference_fixture"]
+    keys = fx["keys"]
+    order = fx["pop_order"]
+    hello, bad = H(fx["hello_digest"]), H(fx["bad_digest"])
+    sigs = [H(s) for s in fx["hello_sigs"]]
+    pk = [H(keys[i]["pk"]) for i in order]
+    for i in order:    # seeds -> public keys as the fixture table says
+        assert E.public_key(H(keys[i]["seed"])).hex() == keys[i]["pk"]
+    # verify_valid_signature / verify_invalid_signature (crypto_tests.rs:50-77)
+    assert c_verify(oracle, hello, pk[0], sigs[0], 1)
+    assert not c_verify(oracle, bad, pk[0], sigs[0], 1)
+    # verify_valid_batch (crypto_tests.rs:80-94): 3 valid pairs, shared digest
+    P, Sg = b"".join(pk[:3]), b"".join(sigs[:3])
+    assert oracle.hs_oracle_verify_batch(hello, S(32), S(0), P, Sg, S(3), ctypes.c_uint64(1)) == 1
+    assert E.verify_batch_shared(hello, list(zip(pk[:3], sigs[:3])))
+    # verify_invalid_batch (crypto_tests.rs:97-115): 2 valid + Signature::default()
+    P, Sg = b"".join(pk[:3]), b"".join(sigs[:2]) + bytes(64)
+    assert oracle.hs_oracle_verify_batch(hello, S(32), S(0), P, Sg, S(3), ctypes.c_uint64(1)) == 0
+    assert not E.verify_batch_shared(hello, list(zip(pk[:3], sigs[:2] + [bytes(64)])))
+    # verify_valid_qc (messages_tests.rs:8-10)
+    qd = H(fx["qc_digest"])
+    P = b"".join(H(v["pk"]) for v in fx["qc_votes"])
+    Sg = b"".join(H(v["sig"]) for v in fx["qc_votes"])
+    assert oracle.hs_oracle_verify_batch(qd, S(32), S(0), P, Sg, S(3), ctypes.c_uint64(2)) == 1
+    # empty batch -> Ok (lib.rs:206-219 with an empty iterator)
+    assert oracle.hs_oracle_verify_batch(qd, S(32), S(0), b"", b"", S(0), ctypes.c_uint64(3)) == 1
+
+
+def test_edge_vectors_c_oracle_matches_bigint(oracle, edge_vectors):
+    n = len(edge_vectors)
+    msgs = b"".join(H(v["msg"]) for v in edge_vectors)
+    pks = b"".join(H(v["pk"]) for v in edge_vectors)
+    sigs = b"".join(H(v["sig"]) for v in edge_vectors)
+    strict = oracle_verify_many(oracle, msgs, 32, pks, sigs, n, 1)
+    cl = oracle_verify_many(oracle, msgs, 32, pks, sigs, n, 0)
+    for i, v in enumerate(edge_vectors):
+        assert bool(strict[i]) == v["strict"], v["name"]
+        assert bool(cl[i]) == v["cofactorless"], v["name"]
+        assert not (v["strict"] and not v["cofactorless"])      # strict implies cofactorless
+        assert not (v["cofactorless"] and not v["cofactored"])  # cofactorless implies cofactored
+
+
+def test_batch_law_on_edge_vectors(oracle, edge_vectors, openssl_vectors):
+    """dalek::verify_batch (RLC restatement) on [honest..., edge vector]: class ii (cofactorless
+    and torsion-free) accepted, class i (not cofactored) rejected, for every choice of the
+    random z_i; class iii is dalek-nondeterministic (tests/golden/gen_edge_vectors.py)."""
+    honest = openssl_vectors["openssl_sign"][:3]
+    for v in edge_vectors:
+        msgs = b"".join(H(h["msg"]) for h in honest) + H(v["msg"])
+        pks = b"".join(H(h["pk"]) for h in honest) + H(v["pk"])
+        sigs = b"".join(H(h["sig"]) for h in honest) + H(v["sig"])
+        got = [oracle.hs_oracle_verify_batch(msgs, S(32), S(32), pks, sigs, S(4), ctypes.c_uint64(e)) for e in range(4)]
+        if v["cofactorless"] and v["torsion_free"]:
+            assert all(g == 1 for g in got), v["name"]
+        elif not v["cofactored"]:
+            assert all(g == 0 for g in got), v["name"]
+
+
+def test_batch_sizes_straus_pippenger_switch(oracle):
+    """n = 0..95 region crosses dalek's Straus/Pippenger switch at 2n+1 = 190."""
+    import synth
+    dg, pk, sg = synth.make_batch(96, shared=True)
+    for n in (0, 1, 2, 63, 64, 65, 94, 95, 96):
+        assert oracle.hs_oracle_verify_batch(dg, S(32), S(0), pk, sg, S(n), ctypes.c_uint64(n)) == 1
+        if n:
+            bad = bytearray(sg[:64 * n]); bad[64 * (n - 1) + 40] ^= 2
+            assert oracle.hs_oracle_verify_batch(dg, S(32), S(0), pk, bytes(bad), S(n), ctypes.c_uint64(n)) == 0
