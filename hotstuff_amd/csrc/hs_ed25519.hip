@@ -189,12 +189,18 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     ws.np = np; ws.pt = ctx->d_ws; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
     const u32 nn = (u32)n;
     hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
+    const u32 *p_dg = (const u32 *)d_digests, *p_pk = (const u32 *)d_pks, *p_sg = (const u32 *)d_sigs;
+    u32 dsw = (u32)(digest_stride / 4), nn_ = nn, mode_ = mode;
+    unsigned long long *p_bm = (unsigned long long *)d_bitmap;
+    u32 *p_nr = d_nreject;
+    void *a1[] = { &ws, &p_dg, &dsw, &p_pk, &p_sg, &nn_, &mode_ };
+    void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
+    // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
-    hipLaunchKernelGGL(k_prepare, dim3((2 * nn + 63) / 64), dim3(64), 0, st, ws, (const u32 *)d_digests,
-                       (u32)(digest_stride / 4), (const u32 *)d_pks, (const u32 *)d_sigs, nn, mode);
-    hipLaunchKernelGGL(k_verify, dim3(np / 64), dim3(64), 0, st, ws, nn, mode, (unsigned long long *)d_bitmap, d_nreject);
+    HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
+    if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");
+    HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
     if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
-    HS_HIP(hipGetLastError(), "kernel launch");
     return 0;
 }
 

@@ -197,12 +197,12 @@ def test_concurrent_host_calls_are_thread_safe(oracle):
     import threading
     n = 200
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
-    _, _, sg_bad, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=40)
+    _, pk_bad, sg_bad, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=40)
     results = {}
 
     def work(k):
-        s = sg_bad if k % 2 else sg
-        results[k] = [_lib.verify_packed(dg, pk, s, n, _lib.BATCH, shared=True, want_bitmap=True) for _ in range(3)]
+        p, s = (pk_bad, sg_bad) if k % 2 else (pk, sg)
+        results[k] = [_lib.verify_packed(dg, p, s, n, _lib.BATCH, shared=True, want_bitmap=True) for _ in range(3)]
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
     [t.start() for t in th]
