@@ -90,6 +90,50 @@ def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=12.0):
     }
 
 
+def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
+    """BASELINE.json's second metric: p50 wall time of one QC::verify-equivalent call at N
+    validators (n = floor(2N/3) + 1 signatures over one digest, batch semantics).  Measured
+    (a) through the host-pointer C-ABI (pinned staging + PCIe both ways included) and
+    (b) device-resident (inputs in HBM, verdict word read back)."""
+    n = 2 * validators // 3 + 1
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    lib = _lib.lib()
+    b_dg, b_pk, b_sg = (ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg))
+    host = []
+    for i in range(calls + 20):
+        t0 = time.perf_counter()
+        rc = lib.hs_ed25519_verify_shared(ctypes.addressof(b_dg), ctypes.addressof(b_pk), ctypes.addressof(b_sg),
+                                          n, _lib.BATCH, None)
+        dt = time.perf_counter() - t0
+        assert rc == 1, "QC batch rejected"
+        if i >= 20:
+            host.append(dt)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
+    bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
+    nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = _lib.DeviceContext(n)
+    devt = []
+    for i in range(calls + 20):
+        nr.zero_()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ctx.verify(d_dg.data_ptr(), 0, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bm.data_ptr(), nr.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+        bad = int(nr.item())            # D2H of the verdict word = end of the call
+        dt = time.perf_counter() - t0
+        assert bad == 0
+        if i >= 20:
+            devt.append(dt)
+    ctx.close()
+    med = lambda v: sorted(v)[len(v) // 2]
+    p99 = lambda v: sorted(v)[int(len(v) * 0.99)]
+    return {"n_validators": validators, "signatures": n, "calls": calls,
+            "p50_ms_host_api": round(med(host) * 1e3, 4), "p99_ms_host_api": round(p99(host) * 1e3, 4),
+            "p50_ms_device_resident": round(med(devt) * 1e3, 4),
+            "verifies_per_s_at_p50_host_api": round(n / med(host), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +143,10 @@ def main():
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
+    ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "8")),
+                    help="CU-masked streams: split the chip into this many slices (0 = plain streams)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -113,8 +161,10 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    exchange = world > 1 or os.environ.get("HS_BENCH_FORCE_EXCHANGE") == "1"
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     _lib.init(local, args.batch)
 
@@ -127,25 +177,39 @@ def main():
     d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
 
     ns = max(1, min(args.streams, args.steps))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-    ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
+    ctxs = None
+    if args.partitions:
+        try:
+            ctxs = [_lib.DeviceContext(n, partition=(j % args.partitions, args.partitions)) for j in range(ns)]
+            streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        except _lib.EngineError as e:       # CU masking unavailable: plain streams
+            print("bench: CU-masked streams unavailable (%s); using plain streams" % e, file=sys.stderr)
+            ctxs, args.partitions = None, 0
+    if ctxs is None:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
     bm_bytes = 8 * ((n + 63) // 64)
     bitmaps = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)]
     nrej = torch.zeros(ns, dtype=torch.int32, device=dev)
-    gathered = [torch.empty(world * bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)] if world > 1 else None
+    gathered = [torch.empty(world * bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)] if exchange else None
+
+    # raw addresses once, outside the timed loop (the step itself is one C-ABI call)
+    p_dg, p_pk, p_sg = d_dg.data_ptr(), d_pk.data_ptr(), d_sg.data_ptr()
+    p_bm = [b.data_ptr() for b in bitmaps]
+    p_nr = [nrej[j:].data_ptr() for j in range(ns)]
+    p_st = [s.cuda_stream for s in streams]
 
     def step(i):
         j = i % ns
         st = streams[j]
-        ctxs[j].verify(d_dg.data_ptr(), stride, d_pk.data_ptr(), d_sg.data_ptr(), n, mode,
-                       bitmaps[j].data_ptr(), nrej[j:].data_ptr(), st.cuda_stream)
-        if world > 1:
+        ctxs[j].verify(p_dg, stride, p_pk, p_sg, n, mode, p_bm[j], p_nr[j], p_st[j])
+        if exchange:
             with torch.cuda.stream(st):
                 dist.all_gather_into_tensor(gathered[j], bitmaps[j])
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -153,18 +217,25 @@ def main():
         step(i)
     fence()
     for c in ctxs:
-        c.set_profiling((args.steps + ns - 1) // ns)
+        c.set_profiling(0 if args.no_events else (args.steps + ns - 1) // ns)
     nrej.zero_()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    enqueue_s = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank holds every shard's bitmap: all signatures of all ranks accepted
+        g = gathered[0].view(torch.int64)
+        assert g.numel() == world * (bm_bytes // 8)
+        for r in range(world):
+            ws_ = g[r * (bm_bytes // 8): r * (bm_bytes // 8) + n // 64].tolist()
+            assert all((int(w) & ((1 << 64) - 1)) == (1 << 64) - 1 for w in ws_), "gathered bitmap of rank %d" % r
 
     # correctness of what was timed: every synthetic signature is valid
     assert int(nrej.sum().item()) == 0, "engine rejected valid signatures during the timed region"
@@ -199,8 +270,8 @@ def main():
                 "workload": ("QC::verify shape: %d signatures over one digest, batch semantics" % n) if shared else
                             ("BASELINE configs[1]: %d distinct (digest, pk, sig) tuples per step per GPU, "
                              "strict semantics" % n),
-                "signatures_per_step_per_gpu": n, "streams": ns,
-                "exchange": "RCCL all-gather of per-shard accept bitmaps" if world > 1 else "none (1 GPU)",
+                "signatures_per_step_per_gpu": n, "streams": ns, "cu_partitions": args.partitions,
+                "exchange": "RCCL all-gather of per-shard accept bitmaps" if exchange else "none (1 GPU)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel().decode(),
@@ -211,12 +282,15 @@ def main():
                 "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
             },
             "kernels_ms": {"k_prepare": round(avg_prepare_ms, 4), "k_verify": round(avg_verify_ms, 4)},
+            "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
+        if world == 1 and not args.no_qc:
+            out["qc_verify_latency"] = qc_latency(_lib, torch, synth, dev)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

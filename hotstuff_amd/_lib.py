@@ -49,6 +49,10 @@ def lib():
                 l.hs_ed25519_verify_multi.restype = ctypes.c_int
                 l.hs_ed25519_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), sz]
                 l.hs_ed25519_ctx_create.restype = ctypes.c_int
+                l.hs_ed25519_ctx_create_partition.argtypes = [ctypes.POINTER(ctypes.c_void_p), sz, ctypes.c_uint, ctypes.c_uint]
+                l.hs_ed25519_ctx_create_partition.restype = ctypes.c_int
+                l.hs_ed25519_ctx_stream.argtypes = [vp]
+                l.hs_ed25519_ctx_stream.restype = ctypes.c_void_p
                 l.hs_ed25519_ctx_destroy.argtypes = [vp]
                 l.hs_ed25519_ctx_destroy.restype = None
                 l.hs_ed25519_verify_device.argtypes = [vp, vp, sz, vp, vp, sz, u32, vp, vp, vp]
@@ -117,10 +121,20 @@ class DeviceContext:
     """hs_ed25519_ctx: workspace + stream for device-resident batches.  Pointers are raw
     HIP device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
 
-    def __init__(self, max_batch=1024):
+    def __init__(self, max_batch=1024, partition=None):
+        """partition = (part, nparts): the context's own stream only runs on that slice of the
+        chip's CUs (pass stream=0 to verify() to use it)."""
         ensure_init()
         self._h = ctypes.c_void_p()
-        check(lib().hs_ed25519_ctx_create(ctypes.byref(self._h), int(max_batch)), "hs_ed25519_ctx_create")
+        if partition is None:
+            check(lib().hs_ed25519_ctx_create(ctypes.byref(self._h), int(max_batch)), "hs_ed25519_ctx_create")
+        else:
+            check(lib().hs_ed25519_ctx_create_partition(ctypes.byref(self._h), int(max_batch), int(partition[0]),
+                                                        int(partition[1])), "hs_ed25519_ctx_create_partition")
+
+    @property
+    def stream(self):
+        return lib().hs_ed25519_ctx_stream(self._h)
 
     def verify(self, d_digests, digest_stride, d_pks, d_sigs, n, mode, d_bitmap, d_nreject=0, stream=0):
         check(lib().hs_ed25519_verify_device(self._h, d_digests, digest_stride, d_pks, d_sigs, int(n), mode,

@@ -12,10 +12,12 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <condition_variable>
 #include <vector>
 #include "verify.h"
+#include "verify_quad.h"
 #include "../../include/hs_ed25519.h"
 
 using namespace hs;
@@ -61,6 +63,41 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
     }
 }
 
+// Four lanes per signature (verify_quad.h): a wavefront covers 16 signatures, so a
+// 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
+__device__ fe g_btab4[9][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
+
+__global__ void __launch_bounds__(64)
+k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
+    __shared__ fe s_btab4[9][4];
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(g_btab4);
+        u32 *dst = reinterpret_cast<u32 *>(s_btab4);
+        for (u32 j = threadIdx.x; j < sizeof(s_btab4) / 4; j += 64) dst[j] = src[j];
+    }
+    __syncthreads();
+    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool active = i < n;
+    bool flags_ok;
+    const qflags f = verify_quad(ws, active ? i : n - 1, mode, s_btab4, flags_ok);
+    unsigned long long m = __ballot(f.f && flags_ok && active);
+    // signature q accepted iff all four lanes of its quad agree; gather bit 4q -> bit q
+    m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    if (threadIdx.x == 0) {
+        bitmap16[blockIdx.x] = (unsigned short)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 16;
+            const u32 sigs = first < n ? min(16u, n - first) : 0u;
+            const u32 bad = sigs - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
@@ -95,6 +132,8 @@ static size_t g_max_batch = 0;
 static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
+static int g_kernel = 0;            // 0 = choose by batch size, 1 = one lane per signature, 2 = quad
+static const size_t kQuadMaxBatch = 32768;   // above this the chip is full either way
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }
@@ -137,6 +176,31 @@ extern "C" int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch) {
     *out = c;
     return 0;
 }
+// A context whose own stream may only run on a contiguous slice of the chip's CUs
+// (hipExtStreamCreateWithCUMask).  Concurrent small batches then occupy disjoint CUs instead
+// of being stacked on the same ones by the workgroup dispatcher.
+extern "C" int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_batch, unsigned part, unsigned nparts) {
+    if (!out || nparts == 0 || part >= nparts) return fail(HS_ED25519_E_ARG, "ctx_create_partition: bad arguments");
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    hipDeviceProp_t prop;
+    HS_HIP(hipGetDeviceProperties(&prop, g_device), "hipGetDeviceProperties");
+    const unsigned cus = (unsigned)prop.multiProcessorCount;
+    if (nparts > cus) return fail(HS_ED25519_E_ARG, "ctx_create_partition: more partitions than CUs");
+    std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+    const unsigned lo = (unsigned)((uint64_t)cus * part / nparts), hi = (unsigned)((uint64_t)cus * (part + 1) / nparts);
+    for (unsigned c = lo; c < hi; c++) mask[c / 32] |= 1u << (c % 32);
+    hs_ed25519_ctx *c = new (std::nothrow) hs_ed25519_ctx();
+    if (!c) return fail(HS_ED25519_E_NOMEM, "ctx_create_partition: out of memory");
+    hipError_t e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, "hipExtStreamCreateWithCUMask", e); }
+    int rc = ctx_reserve(c, max_batch ? max_batch : 64, false);
+    if (rc) { (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
+    *out = c;
+    return 0;
+}
+extern "C" void *hs_ed25519_ctx_stream(hs_ed25519_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
@@ -155,6 +219,10 @@ extern "C" int hs_ed25519_init(int device, size_t max_batch) {
     ge_niels tab[9];
     make_base_table(tab, 9);
     HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
+    fe tab4[9][4];
+    make_base_table_quad(tab4, 9);
+    HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
+    if (const char *k = getenv("HS_ED25519_KERNEL")) g_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : 0);
     HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
     return 0;
@@ -165,7 +233,7 @@ extern "C" void hs_ed25519_shutdown(void) {
     g_free.clear(); g_live = 0; g_init = false;
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
-extern "C" const char *hs_ed25519_dominant_kernel(void) { return "k_verify"; }
+extern "C" const char *hs_ed25519_dominant_kernel(void) { return g_kernel == 1 ? "k_verify" : "k_verify_quad"; }
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
@@ -199,7 +267,9 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
     HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
     if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");
-    HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
+    const bool quad = g_kernel == 2 || (g_kernel == 0 && n <= kQuadMaxBatch);
+    if (quad) HS_HIP(hipLaunchKernel((const void *)k_verify_quad, dim3(np / 16), dim3(64), a2, 0, st), "launch k_verify_quad");
+    else HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
     if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
     return 0;
 }

@@ -1,0 +1,200 @@
+// verify_quad.h - stage 2 with FOUR lanes per signature (a "quad").
+//
+// The extended coordinates (X, Y, Z, T) of the running point live one per lane in lanes
+// 4q..4q+3 of a wavefront.  The HWCD formulas split into two rounds of four independent
+// field multiplications, so
+//      doubling  = 1 vector squaring + 1 vector multiplication
+//      addition  = 2 vector multiplications
+// and the operand shuffles between the rounds are DPP quad_perm moves, which on CDNA4 stay
+// inside the VALU (no LDS, no ds_swizzle).  Compared with one lane per signature this gives
+// 4x the wavefronts per launch (a 1,024-signature batch becomes 64 wavefronts instead of
+// 16), ~3x lower latency per verification and a quarter of the per-lane register state.
+//
+// The code is written once over a tiny vector abstraction (qv + q* primitives): on the GPU a
+// qv is ONE lane's field element and the primitives are DPP moves / lane selects; under a
+// plain C++ compiler a qv is all four lanes and the primitives are loops, which is how
+// tests/emu validates exactly this algorithm on the CPU.
+//
+// Same semantics as verify_lane (verify.h); replaces dalek's
+// vartime_double_scalar_mul_basepoint + point comparison (crypto/src/lib.rs:203, :218).
+#pragma once
+#include "verify.h"
+
+namespace hs {
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ device: qv = one lane
+#define HS_Q __device__ __forceinline__
+typedef fe qv;
+HS_Q u32 q_lane() { return threadIdx.x & 3u; }
+template <int P0, int P1, int P2, int P3>
+HS_Q qv q_perm(const qv &a) {       // lane i <- lane P_i of the same quad
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        r.v[i] = (u32)__builtin_amdgcn_mov_dpp((int)a.v[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+    return r;
+}
+template <int MASK>
+HS_Q qv q_sel(const qv &a, const qv &b) {   // lane i takes b iff bit i of MASK
+    const bool pick = (MASK >> q_lane()) & 1;
+    qv r; fe_select(r, a, b, pick); return r;
+}
+HS_Q qv q_mul(const qv &f, const qv &g) { qv r; fe_mul(r, f, g); return r; }
+HS_Q qv q_sq(const qv &f) { qv r; fe_sq(r, f); return r; }
+HS_Q qv q_add(const qv &a, const qv &b) { qv r; fe_add(r, a, b); return r; }
+HS_Q qv q_sub(const qv &a, const qv &b) { qv r; fe_sub(r, a, b); return r; }
+HS_Q qv q_carry(const qv &a) { qv r = a; fe_carry(r); return r; }
+HS_Q qv q_pick(const qv &a, const qv &b, bool pick_b) { qv r; fe_select(r, a, b, pick_b); return r; }
+HS_Q qv q_lanes(const fe &c0, const fe &c1, const fe &c2, const fe &c3) {   // per-lane constant
+    const u32 l = q_lane();
+    qv r; fe_select(r, c0, c1, l == 1); fe_select(r, r, c2, l == 2); fe_select(r, r, c3, l == 3); return r;
+}
+// entry `idx` of a table laid out [idx][lane] (LDS or global)
+HS_Q qv q_load(const fe (*tab)[4], int idx) { return tab[idx][q_lane()]; }
+// per-lane equality of canonical values -> one flag per lane
+struct qflags { bool f; };
+HS_Q qflags q_eq(const qv &a, const qv &b_reduced) { qflags r; r.f = fe_eq(a, b_reduced); return r; }
+#else
+// ------------------------------------------------------------------ host: qv = four lanes
+#define HS_Q inline
+struct qv { fe l[4]; };
+template <int P0, int P1, int P2, int P3>
+HS_Q qv q_perm(const qv &a) { qv r; r.l[0] = a.l[P0]; r.l[1] = a.l[P1]; r.l[2] = a.l[P2]; r.l[3] = a.l[P3]; return r; }
+template <int MASK>
+HS_Q qv q_sel(const qv &a, const qv &b) { qv r; for (int i = 0; i < 4; i++) r.l[i] = ((MASK >> i) & 1) ? b.l[i] : a.l[i]; return r; }
+HS_Q qv q_mul(const qv &f, const qv &g) { qv r; for (int i = 0; i < 4; i++) fe_mul(r.l[i], f.l[i], g.l[i]); return r; }
+HS_Q qv q_sq(const qv &f) { qv r; for (int i = 0; i < 4; i++) fe_sq(r.l[i], f.l[i]); return r; }
+HS_Q qv q_add(const qv &a, const qv &b) { qv r; for (int i = 0; i < 4; i++) fe_add(r.l[i], a.l[i], b.l[i]); return r; }
+HS_Q qv q_sub(const qv &a, const qv &b) { qv r; for (int i = 0; i < 4; i++) fe_sub(r.l[i], a.l[i], b.l[i]); return r; }
+HS_Q qv q_carry(const qv &a) { qv r = a; for (int i = 0; i < 4; i++) fe_carry(r.l[i]); return r; }
+HS_Q qv q_pick(const qv &a, const qv &b, bool pick_b) { return pick_b ? b : a; }
+HS_Q qv q_lanes(const fe &c0, const fe &c1, const fe &c2, const fe &c3) { qv r; r.l[0] = c0; r.l[1] = c1; r.l[2] = c2; r.l[3] = c3; return r; }
+HS_Q qv q_load(const fe (*tab)[4], int idx) { qv r; for (int i = 0; i < 4; i++) r.l[i] = tab[idx][i]; return r; }
+struct qflags { bool f[4]; };
+HS_Q qflags q_eq(const qv &a, const qv &b_reduced) { qflags r; for (int i = 0; i < 4; i++) r.f[i] = fe_eq(a.l[i], b_reduced.l[i]); return r; }
+#endif
+
+HS_HD fe fe_small(u32 c) { fe r; fe_0(r); r.v[0] = c; return r; }
+
+// (X, Y, Z, T) -> (Y-X, Y+X, T, Z): the left operands of an addition's first round
+HS_Q qv q_add_lhs(const qv &p) {
+    const qv u = q_perm<1, 1, 3, 2>(p);               // (Y, Y, T, Z)
+    const qv x = q_perm<0, 0, 0, 0>(p);               // X everywhere
+    const qv zero = q_lanes(fe_small(0), fe_small(0), fe_small(0), fe_small(0));
+    const qv d = q_sub(u, x);                         // lane 0: Y - X            (3x)
+    const qv s = q_add(u, q_sel<0b1100>(x, zero));    // lane 1: Y + X; lanes 2,3: u + 0
+    return q_sel<0b0001>(s, d);
+}
+// cached form (Y-X, Y+X, 2dT, 2Z) of an extended point: one vector multiplication by constants
+HS_Q qv q_to_cached(const qv &p) {
+    const qv k = q_lanes(fe_small(1), fe_small(1), fe_d2(), fe_small(2));
+    return q_mul(q_add_lhs(p), k);
+}
+// negate a cached entry: swap lanes 0/1, negate lane 2
+HS_Q qv q_cached_neg(const qv &e) {
+    const qv sw = q_perm<1, 0, 2, 3>(e);
+    const qv zero = q_lanes(fe_small(0), fe_small(0), fe_small(0), fe_small(0));
+    return q_sel<0b0100>(sw, q_sub(zero, sw));        // lane 2: 2p - 2dT  (2x)
+}
+// p + e  (e cached, already sign-adjusted) -> extended
+HS_Q qv q_add_cached(const qv &p, const qv &e) {
+    const qv m = q_mul(q_add_lhs(p), e);              // (A, B, C, D), reduced
+    const qv a = q_perm<0, 0, 0, 0>(m), b = q_perm<1, 1, 1, 1>(m), c = q_perm<2, 2, 2, 2>(m), d = q_perm<3, 3, 3, 3>(m);
+    const qv E = q_sub(b, a), H = q_add(b, a), F = q_sub(d, c), G = q_add(d, c);   // 3x, 2x, 3x, 2x
+    const qv l = q_sel<0b0100>(q_sel<0b0010>(E, G), F);     // (E, G, F, E)
+    const qv r = q_sel<0b0100>(q_sel<0b0001>(H, F), G);     // (F, H, G, H)
+    return q_mul(l, r);                                     // (EF, GH, FG, EH)
+}
+// 2p -> extended (input T unused)
+HS_Q qv q_dbl(const qv &p) {
+    const qv x = q_perm<0, 0, 0, 0>(p), y = q_perm<1, 1, 1, 1>(p);
+    const qv a = q_sel<0b1000>(p, q_add(x, y));       // (X, Y, Z, X+Y)
+    const qv s = q_sq(a);                             // (XX, YY, ZZ, AA), reduced
+    const qv xx = q_perm<0, 0, 0, 0>(s), yy = q_perm<1, 1, 1, 1>(s), zz = q_perm<2, 2, 2, 2>(s), aa = q_perm<3, 3, 3, 3>(s);
+    const qv S = q_carry(q_add(yy, xx));              // Y3' = YY + XX     (1x)
+    const qv D = q_carry(q_sub(yy, xx));              // Z3' = YY - XX     (1x)
+    const qv E = q_sub(aa, S);                        // X3' = AA - S      (3x)
+    const qv F = q_sub(q_add(zz, zz), D);             // T3' = 2ZZ - D     (4x)
+    const qv l = q_sel<0b0100>(q_sel<0b0010>(E, S), D);     // (E, S, D, E)   <= 3x
+    const qv r = q_sel<0b1000>(q_sel<0b0010>(F, D), S);     // (F, D, F, S)   <= 4x
+    return q_mul(r, l);                                     // (EF, SD, DF, ES)
+}
+
+// atab entries are per lane: on the GPU each lane keeps its own component in private memory.
+// btab: [9][4] cached multiples j*B, j = 0..8, lane order (Y-X, Y+X, 2dT, 2Z).
+// Returns, per lane, whether this lane's coordinate check passed (lanes 2,3: true) AND the
+// signature-level flags; the caller ANDs lanes 0 and 1 of the quad.
+HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok) {
+    const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
+    bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+    flags_ok = ok;
+
+    fe ax, ay, rx, ry;
+    {
+        const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            ax.v[j] = ra[(size_t)j * ws.np]; ay.v[j] = ra[(size_t)(10 + j) * ws.np];
+            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
+        }
+    }
+    u32 kw[8], sw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
+
+    // -A = (-x, y, 1, -xy): one vector multiplication (-x, y, 1, -x) * (1, 1, 1, y)
+    fe nax; fe_neg(nax, ax);
+    qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
+
+    qv atab[9];                                       // j * (-A), cached, j = 0..8
+    atab[0] = q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2));
+    atab[1] = q_to_cached(p);
+    {
+        const qv a1 = atab[1];
+#pragma nounroll
+        for (int j = 2; j <= 8; j++) {
+            p = q_add_cached(p, a1);
+            atab[j] = q_to_cached(p);
+        }
+    }
+
+    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
+#pragma nounroll
+    for (int w = 0; w < 64; w++) {
+#pragma nounroll
+        for (int d = 0; d < 4; d++) acc = q_dbl(acc);
+        const int dk = sc_pop_digit(kw), ds = sc_pop_digit(sw);
+        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        const qv ea = atab[ik];
+        acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
+        const qv eb = q_load(btab, is);
+        acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+    }
+    // acc == R as points: X == x_R Z (lane 0), Y == y_R Z (lane 1); lanes 2, 3 compare Z with Z
+    const qv z = q_perm<2, 2, 2, 2>(acc);
+    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
+    const qv lhs = q_sel<0b1100>(acc, z);
+    return q_eq(rhs, q_carry(lhs));
+}
+
+// cached multiples of the base point for the quad kernel: tab[j][lane], j = 0..count-1
+inline void make_base_table_quad(fe (*tab)[4], int count) {
+    ge_p3 b, p;
+    ge_basepoint(b);
+    ge_cached bc;
+    ge_to_cached(bc, b);
+    tab[0][0] = fe_small(1); tab[0][1] = fe_small(1); tab[0][2] = fe_small(0); tab[0][3] = fe_small(2);
+    p = b;
+    for (int j = 1; j < count; j++) {
+        ge_niels n;
+        ge_p3_to_niels(n, p);
+        tab[j][0] = n.ymx; tab[j][1] = n.ypx; tab[j][2] = n.xy2d; tab[j][3] = fe_small(2);
+        ge_p1p1 t;
+        ge_add(t, p, bc, false);
+        ge_p1p1_to_p3(p, t, true);
+    }
+}
+
+}  // namespace hs

@@ -24,8 +24,10 @@
  *                          curve, [k](-A) + [s]B == R as points, cofactorless,
  *                          no small-order rejection.  The call accepts iff every
  *                          signature does.  (dalek's randomised sum gives the same
- *                          answer except on crafted mixed-order inputs where dalek
- *                          itself is non-deterministic; those are rejected here.)
+ *                          answer on every input where dalek is deterministic; on
+ *                          crafted inputs with a torsion component in A or R its
+ *                          answer depends on its random z_i - there the engine
+ *                          returns this per-signature verdict.  DESIGN.md section 3.)
  *   HS_ED25519_STRICT (1)  `PublicKey::verify_strict`: BATCH plus reject when
  *                          [8]R == O or [8]A == O.
  *
@@ -91,6 +93,12 @@ int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const ui
 typedef struct hs_ed25519_ctx hs_ed25519_ctx;
 int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch);
 void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);
+/* Like hs_ed25519_ctx_create, but the context's own stream is restricted to partition `part`
+ * of `nparts` equal contiguous slices of the GPU's compute units (CU-masked stream), so that
+ * small batches in flight on different contexts occupy disjoint CUs.  Pass stream = NULL to
+ * hs_ed25519_verify_device to use it; hs_ed25519_ctx_stream returns the hipStream_t. */
+int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_batch, unsigned part, unsigned nparts);
+void *hs_ed25519_ctx_stream(hs_ed25519_ctx *ctx);
 int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
                              const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
                              uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #include "../../hotstuff_amd/csrc/verify.h"
+#include "../../hotstuff_amd/csrc/verify_quad.h"
 using namespace hs;
 
 static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
@@ -65,5 +66,24 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
         prepare_point(ws, (u32)i, is_r, pk, sig, msg, mode);
     }
     for (size_t i = 0; i < n; i++) out[i] = verify_lane(ws, (u32)i, mode, btab) ? 1 : 0;
+}
+// the quad (4 lanes per signature) stage 2, same stage 1
+void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                     uint32_t mode, uint8_t *out) {
+    if (!n) return;
+    const u32 np = (u32)((n + 63) / 64 * 64);
+    std::vector<u32> buf(workspace_words(np));
+    workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    fe btab[9][4]; make_base_table_quad(btab, 9);
+    for (size_t t = 0; t < 2 * n; t++) {
+        const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
+        u32 pk[8], sig[16], msg[8];
+        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        prepare_point(ws, (u32)i, is_r, pk, sig, msg, mode);
+    }
+    for (size_t i = 0; i < n; i++) {
+        bool fl; qflags f = verify_quad(ws, (u32)i, mode, btab, fl);
+        out[i] = (fl && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
+    }
 }
 }
