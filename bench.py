@@ -113,18 +113,22 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
     nr = torch.zeros(1, dtype=torch.int32, device=dev)
     ctx = _lib.DeviceContext(n)
+    st = torch.cuda.ExternalStream(ctx.stream, device=dev)     # the context's own stream
     devt = []
-    for i in range(calls + 20):
-        nr.zero_()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ctx.verify(d_dg.data_ptr(), 0, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bm.data_ptr(), nr.data_ptr(),
-                   torch.cuda.current_stream().cuda_stream)
-        bad = int(nr.item())            # D2H of the verdict word = end of the call
-        dt = time.perf_counter() - t0
-        assert bad == 0
-        if i >= 20:
-            devt.append(dt)
+    with torch.cuda.stream(st):
+        for i in range(calls + 20):
+            nr.zero_()
+            st.synchronize()
+            t0 = time.perf_counter()
+            ctx.verify(d_dg.data_ptr(), 0, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bm.data_ptr(),
+                       nr.data_ptr(), ctx.stream)
+            bad = int(nr.item())        # D2H of the verdict word on the same stream = end of the call
+            dt = time.perf_counter() - t0
+            assert bad == 0
+            if i >= 20:
+                devt.append(dt)
+    full = bm.view(torch.int64)[: n // 64].tolist()
+    assert all((int(w) & ((1 << 64) - 1)) == (1 << 64) - 1 for w in full), "QC bitmap"
     ctx.close()
     med = lambda v: sorted(v)[len(v) // 2]
     p99 = lambda v: sorted(v)[int(len(v) * 0.99)]
@@ -253,6 +257,14 @@ def main():
     avg_verify_ms = ver_ms / max(1, launches)
     avg_prepare_ms = prep_ms / max(1, launches)
 
+    traffic = None
+    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        kname = _lib.lib().hs_ed25519_dominant_kernel().decode()
+        if pmc.get("signatures_per_launch") == n and kname in pmc["kernels"]:
+            traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         total = world * n * args.steps
         value = total / elapsed
@@ -276,7 +288,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel().decode(),
                 "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
+                "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                                  if traffic else None,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
                 "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
