@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
-    ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "8")),
+    ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "16")),
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams)")
     args = ap.parse_args()
 

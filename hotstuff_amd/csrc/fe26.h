@@ -142,29 +142,38 @@ HS_HD void fe_sq(fe &r, const fe &f) {
     fe_reduce_cols(r, h);
 }
 
-HS_HD void fe_sqn(fe &r, const fe &a, int n) {
+// r = a^(2^N).  Short runs are straight-line; long runs are a real loop (a 1- or 2-trip
+// `nounroll` loop sends hipcc's register allocation from ~130 to ~300 VGPRs - measured).
+template <int N>
+HS_HD void fe_sqn(fe &r, const fe &a) {
     fe_sq(r, a);
-    for (int i = 1; i < n; i++) fe_sq(r, r);
+    if (N <= 5) {
+#pragma unroll
+        for (int i = 1; i < N; i++) fe_sq(r, r);
+    } else {
+#pragma nounroll
+        for (int i = 1; i < N; i++) fe_sq(r, r);
+    }
 }
 
 // z^(2^250 - 1) and z^11: shared head of the inversion and sqrt-ratio ladders
 HS_HD void fe_pow250(fe &r, fe &z11, const fe &z) {
     fe z2, z9, t, z5, z10, z20, z50, z100;
-    fe_sq(z2, z); fe_sqn(t, z2, 2); fe_mul(z9, t, z); fe_mul(z11, z9, z2);
+    fe_sq(z2, z); fe_sqn<2>(t, z2); fe_mul(z9, t, z); fe_mul(z11, z9, z2);
     fe_sq(t, z11); fe_mul(z5, t, z9);
-    fe_sqn(t, z5, 5); fe_mul(z10, t, z5);
-    fe_sqn(t, z10, 10); fe_mul(z20, t, z10);
-    fe_sqn(t, z20, 20); fe_mul(t, t, z20);
-    fe_sqn(t, t, 10); fe_mul(z50, t, z10);
-    fe_sqn(t, z50, 50); fe_mul(z100, t, z50);
-    fe_sqn(t, z100, 100); fe_mul(t, t, z100);
-    fe_sqn(t, t, 50); fe_mul(r, t, z50);
+    fe_sqn<5>(t, z5); fe_mul(z10, t, z5);
+    fe_sqn<10>(t, z10); fe_mul(z20, t, z10);
+    fe_sqn<20>(t, z20); fe_mul(t, t, z20);
+    fe_sqn<10>(t, t); fe_mul(z50, t, z10);
+    fe_sqn<50>(t, z50); fe_mul(z100, t, z50);
+    fe_sqn<100>(t, z100); fe_mul(t, t, z100);
+    fe_sqn<50>(t, t); fe_mul(r, t, z50);
 }
 HS_HD void fe_invert(fe &r, const fe &z) {
-    fe t, z11; fe_pow250(t, z11, z); fe_sqn(t, t, 5); fe_mul(r, t, z11);
+    fe t, z11; fe_pow250(t, z11, z); fe_sqn<5>(t, t); fe_mul(r, t, z11);
 }
 HS_HD void fe_pow22523(fe &r, const fe &z) {
-    fe t, z11; fe_pow250(t, z11, z); fe_sqn(t, t, 2); fe_mul(r, t, z);
+    fe t, z11; fe_pow250(t, z11, z); fe_sqn<2>(t, t); fe_mul(r, t, z);
 }
 
 // little-endian 32 bytes (as 8 words) -> reduced limbs; bit 255 dropped, no canonical check

@@ -25,9 +25,10 @@ using namespace hs;
 // ------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------
-__device__ ge_niels g_btab[9];      // j*B, j = 0..8 (uploaded by hs_ed25519_init)
+__device__ ge_niels g_btab[HS_BTAB_ENTRIES];      // j*B, j = 0..128 (uploaded by hs_ed25519_init)
 
-__global__ void __launch_bounds__(64)
+// (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
+__global__ void __launch_bounds__(64, 3)
 k_prepare(workspace ws, const u32 *__restrict__ digests, u32 digest_stride_words,
           const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
@@ -40,18 +41,10 @@ k_prepare(workspace ws, const u32 *__restrict__ digests, u32 digest_stride_words
 
 __global__ void __launch_bounds__(64)
 k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject) {
-    // LDS-staged base-point window table (9 entries x 30 limbs)
-    __shared__ ge_niels s_btab[9];
-    {
-        const u32 *src = reinterpret_cast<const u32 *>(g_btab);
-        u32 *dst = reinterpret_cast<u32 *>(s_btab);
-        for (u32 j = threadIdx.x; j < sizeof(s_btab) / 4; j += 64) dst[j] = src[j];
-    }
-    __syncthreads();
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     const bool active = i < n;
     // inactive tail lanes run lane min(i, n-1)'s data so the wavefront stays convergent
-    const bool ok = verify_lane(ws, active ? i : n - 1, mode, s_btab) && active;
+    const bool ok = verify_lane(ws, active ? i : n - 1, mode, g_btab) && active;
     const unsigned long long mask = __ballot(ok);
     if (threadIdx.x == 0) {
         bitmap[blockIdx.x] = mask;
@@ -65,21 +58,14 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
 
 // Four lanes per signature (verify_quad.h): a wavefront covers 16 signatures, so a
 // 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
-__device__ fe g_btab4[9][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
+__device__ fe g_btab4[HS_BTAB_ENTRIES][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
 
 __global__ void __launch_bounds__(64)
 k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
-    __shared__ fe s_btab4[9][4];
-    {
-        const u32 *src = reinterpret_cast<const u32 *>(g_btab4);
-        u32 *dst = reinterpret_cast<u32 *>(s_btab4);
-        for (u32 j = threadIdx.x; j < sizeof(s_btab4) / 4; j += 64) dst[j] = src[j];
-    }
-    __syncthreads();
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     bool flags_ok;
-    const qflags f = verify_quad(ws, active ? i : n - 1, mode, s_btab4, flags_ok);
+    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_btab4, flags_ok);
     unsigned long long m = __ballot(f.f && flags_ok && active);
     // signature q accepted iff all four lanes of its quad agree; gather bit 4q -> bit q
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
@@ -93,6 +79,33 @@ k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap
             const u32 first = blockIdx.x * 16;
             const u32 sigs = first < n ? min(16u, n - first) : 0u;
             const u32 bad = sigs - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
+// Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
+__global__ void __launch_bounds__(64, 3)
+k_verify_fused(const u32 *__restrict__ digests, u32 digest_stride_words, const u32 *__restrict__ pks,
+               const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
+               u32 *__restrict__ nreject) {
+    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, digests + (size_t)digest_stride_words * j,
+                                      mode, g_btab4);
+    unsigned long long m = __ballot(ok && active);
+    m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    if (threadIdx.x == 0) {
+        bitmap16[blockIdx.x] = (unsigned short)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 16;
+            const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
+            const u32 bad = sigs_here - (u32)__popcll(m);
             if (bad) atomicAdd(nreject, bad);
         }
     }
@@ -132,8 +145,8 @@ static size_t g_max_batch = 0;
 static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
-static int g_kernel = 0;            // 0 = choose by batch size, 1 = one lane per signature, 2 = quad
-static const size_t kQuadMaxBatch = 32768;   // above this the chip is full either way
+static int g_kernel = 0;            // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
+static const size_t kQuadMaxBatch = 16384;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }
@@ -216,13 +229,14 @@ extern "C" int hs_ed25519_init(int device, size_t max_batch) {
     HS_HIP(hipGetDeviceCount(&count), "hipGetDeviceCount");
     if (device < 0 || device >= count) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
     HS_HIP(hipSetDevice(device), "hipSetDevice");
-    ge_niels tab[9];
-    make_base_table(tab, 9);
+    static ge_niels tab[HS_BTAB_ENTRIES];
+    make_base_table(tab, HS_BTAB_ENTRIES);
     HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
-    fe tab4[9][4];
-    make_base_table_quad(tab4, 9);
+    static fe tab4[HS_BTAB_ENTRIES][4];
+    make_base_table_quad(tab4, HS_BTAB_ENTRIES);
     HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
-    if (const char *k = getenv("HS_ED25519_KERNEL")) g_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : 0);
+    if (const char *k = getenv("HS_ED25519_KERNEL"))
+        g_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : 0));
     HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
     return 0;
@@ -233,7 +247,9 @@ extern "C" void hs_ed25519_shutdown(void) {
     g_free.clear(); g_live = 0; g_init = false;
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
-extern "C" const char *hs_ed25519_dominant_kernel(void) { return g_kernel == 1 ? "k_verify" : "k_verify_quad"; }
+extern "C" const char *hs_ed25519_dominant_kernel(void) {
+    return g_kernel == 1 ? "k_verify" : (g_kernel == 2 ? "k_verify_quad" : "k_verify_fused");
+}
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
@@ -263,13 +279,19 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     u32 *p_nr = d_nreject;
     void *a1[] = { &ws, &p_dg, &dsw, &p_pk, &p_sg, &nn_, &mode_ };
     void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
+    void *a3[] = { &p_dg, &dsw, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
+    const int kern = g_kernel ? g_kernel : (n <= kQuadMaxBatch ? 3 : 1);
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
-    HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
+    if (kern != 3)
+        HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
     if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");
-    const bool quad = g_kernel == 2 || (g_kernel == 0 && n <= kQuadMaxBatch);
-    if (quad) HS_HIP(hipLaunchKernel((const void *)k_verify_quad, dim3(np / 16), dim3(64), a2, 0, st), "launch k_verify_quad");
-    else HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
+    if (kern == 3)
+        HS_HIP(hipLaunchKernel((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, 0, st), "launch k_verify_fused");
+    else if (kern == 2)
+        HS_HIP(hipLaunchKernel((const void *)k_verify_quad, dim3(np / 16), dim3(64), a2, 0, st), "launch k_verify_quad");
+    else
+        HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
     if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
     return 0;
 }

@@ -176,4 +176,16 @@ HS_HD void sc_recode16(u32 r[8], const u32 x[8]) {
     }
 }
 
+// Signed radix-256 recoding for x < 2^253: r = x + 0x80..80; digit_i = byte_i(r) - 128
+// in [-128, 127] and sum digit_i 256^i = x.
+HS_HD void sc_recode256(u32 r[8], const u32 x[8]) {
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)x[i] + 0x80808080u + carry;
+        r[i] = (u32)t;
+        carry = t >> 32;
+    }
+}
+
 }  // namespace hs

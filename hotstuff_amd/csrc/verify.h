@@ -26,7 +26,7 @@ enum : u32 { HS_F_ONCURVE = 1, HS_F_SMALL = 2, HS_F_SCANON = 4 };
 // Workspace between the stages, structure-of-arrays with row stride `np` (n padded to
 // 64) so that a wavefront's 64 lanes touch 64 consecutive dwords of every row:
 //   pt   [2][20][np] u32   x,y limbs of A (slot 0) and R (slot 1)
-//   sc   [16][np]    u32   recoded k (rows 0-7) and recoded s (rows 8-15)
+//   sc   [16][np]    u32   k recoded signed radix-16 (rows 0-7), s recoded signed radix-256 (rows 8-15)
 //   flag [2][np]     u32   HS_F_* bits per point
 struct workspace {
     u32 *pt, *sc, *flag;
@@ -57,7 +57,7 @@ HS_HD void prepare_point(const workspace &ws, u32 i, bool is_r, const u32 *pk, c
         sc_reduce512(k, h);
         fl |= sc_is_canonical(s) ? HS_F_SCANON : 0;
         sc_recode16(rk, k);
-        sc_recode16(rs, s);      // meaningless when s >= L; the lane is rejected by HS_F_SCANON
+        sc_recode256(rs, s);     // meaningless when s >= L; the lane is rejected by HS_F_SCANON
 #pragma unroll
         for (int j = 0; j < 8; j++) { ws.sc[(size_t)j * ws.np + i] = rk[j]; ws.sc[(size_t)(8 + j) * ws.np + i] = rs[j]; }
     }
@@ -74,7 +74,17 @@ HS_HD int sc_pop_digit(u32 w[8]) {
     return d;
 }
 
-// btab: 9 affine Niels entries j*B, j = 0..8 (entry 0 = identity).
+// take the top byte of a 256-bit radix-256 recoded scalar as a signed digit and shift left by 8
+HS_HD int sc_pop_digit8(u32 w[8]) {
+    const int d = (int)(w[7] >> 24) - 128;
+#pragma unroll
+    for (int j = 7; j > 0; j--) w[j] = (w[j] << 8) | (w[j - 1] >> 24);
+    w[0] <<= 8;
+    return d;
+}
+#define HS_BTAB_ENTRIES 129   // j*B, j = 0..128: 8-bit signed windows for the base point
+
+// btab: HS_BTAB_ENTRIES affine Niels entries j*B (entry 0 = identity), L2-resident.
 HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *btab) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
     bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
@@ -123,11 +133,15 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *bta
             ge_dbl(t, acc);
             ge_p1p1_to_p3(acc, t, d == 3);
         }
-        const int dk = sc_pop_digit(kw), ds = sc_pop_digit(sw);
-        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        const int dk = sc_pop_digit(kw);
+        const int ik = dk < 0 ? -dk : dk;
         ge_add(t, acc, atab[ik], dk < 0);
-        ge_p1p1_to_p3(acc, t, true);
-        ge_madd(t, acc, btab[is], ds < 0);
+        if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
+            ge_p1p1_to_p3(acc, t, true);
+            const int ds = sc_pop_digit8(sw);
+            const int is = ds < 0 ? -ds : ds;
+            ge_madd(t, acc, btab[is], ds < 0);
+        }
         ge_p1p1_to_p3(acc, t, false);
     }
     // acc == R as points:  X == x_R Z  and  Y == y_R Z

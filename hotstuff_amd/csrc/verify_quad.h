@@ -121,29 +121,14 @@ HS_Q qv q_dbl(const qv &p) {
     return q_mul(r, l);                                     // (EF, SD, DF, ES)
 }
 
-// atab entries are per lane: on the GPU each lane keeps its own component in private memory.
-// btab: [9][4] cached multiples j*B, j = 0..8, lane order (Y-X, Y+X, 2dT, 2Z).
-// Returns, per lane, whether this lane's coordinate check passed (lanes 2,3: true) AND the
-// signature-level flags; the caller ANDs lanes 0 and 1 of the quad.
-HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok) {
-    const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
-    bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
-    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
-    flags_ok = ok;
-
-    fe ax, ay, rx, ry;
-    {
-        const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
-#pragma unroll
-        for (int j = 0; j < 10; j++) {
-            ax.v[j] = ra[(size_t)j * ws.np]; ay.v[j] = ra[(size_t)(10 + j) * ws.np];
-            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
-        }
-    }
-    u32 kw[8], sw[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
-
+// The quad stage-2 core.  ax, ay, rx, ry (affine A and R) and the recoded scalars are uniform
+// across the four lanes of a quad.  atab entries are per lane: on the GPU each lane keeps its
+// own component in private memory.
+// btab: [HS_BTAB_ENTRIES][4] cached multiples j*B, lane order (Y-X, Y+X, 2dT, 2Z), L2-resident.
+// Returns, per lane, whether this lane's coordinate check passed (lanes 2, 3: always true);
+// the caller ANDs the four lanes of the quad with the signature-level flags.
+HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, u32 kw[8], u32 sw[8],
+                             const fe (*btab)[4]) {
     // -A = (-x, y, 1, -xy): one vector multiplication (-x, y, 1, -x) * (1, 1, 1, y)
     fe nax; fe_neg(nax, ax);
     qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
@@ -165,12 +150,16 @@ HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4
     for (int w = 0; w < 64; w++) {
 #pragma nounroll
         for (int d = 0; d < 4; d++) acc = q_dbl(acc);
-        const int dk = sc_pop_digit(kw), ds = sc_pop_digit(sw);
-        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        const int dk = sc_pop_digit(kw);
+        const int ik = dk < 0 ? -dk : dk;
         const qv ea = atab[ik];
         acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
-        const qv eb = q_load(btab, is);
-        acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+        if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
+            const int ds = sc_pop_digit8(sw);
+            const int is = ds < 0 ? -ds : ds;
+            const qv eb = q_load(btab, is);
+            acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+        }
     }
     // acc == R as points: X == x_R Z (lane 0), Y == y_R Z (lane 1); lanes 2, 3 compare Z with Z
     const qv z = q_perm<2, 2, 2, 2>(acc);
@@ -178,6 +167,65 @@ HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4
     const qv lhs = q_sel<0b1100>(acc, z);
     return q_eq(rhs, q_carry(lhs));
 }
+
+// stage 2 reading the workspace written by k_prepare
+HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok) {
+    const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
+    bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+    flags_ok = ok;
+    fe ax, ay, rx, ry;
+    {
+        const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            ax.v[j] = ra[(size_t)j * ws.np]; ay.v[j] = ra[(size_t)(10 + j) * ws.np];
+            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
+        }
+    }
+    u32 kw[8], sw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
+    return verify_quad_core(ax, ay, rx, ry, kw, sw, btab);
+}
+
+// The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
+// computes it redundantly so no lane diverges.  Returns s < L.
+HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, const u32 *msg) {
+    u32 in[24], h[16], k[8], s[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
+    sha512_96(h, in);
+    sc_reduce512(k, h);
+    sc_recode16(kw, k);
+    sc_recode256(sw, s);
+    return sc_is_canonical(s);
+}
+
+#if defined(__HIPCC__)
+// Fused stage 1 + stage 2 for one quad: lane 1 decompresses R, the other lanes decompress A
+// (one shared instruction stream), everybody hashes, DPP broadcasts hand A to the whole
+// quad, then the core.  One launch per batch and no workspace traffic.
+HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const fe (*btab)[4]) {
+    const u32 lane = q_lane();
+    u32 enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) enc[j] = lane == 1 ? sig[j] : pk[j];
+    ge_p3 pt;
+    u32 fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order(pt) ? HS_F_SMALL : 0;
+    const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+    const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
+    u32 kw[8], sw[8];
+    bool ok = prepare_scalars(kw, sw, pk, sig, msg);
+    ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+    const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
+    const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, btab);
+    return f.f && ok;
+}
+#endif
 
 // cached multiples of the base point for the quad kernel: tab[j][lane], j = 0..count-1
 inline void make_base_table_quad(fe (*tab)[4], int count) {

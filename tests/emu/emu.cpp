@@ -40,6 +40,10 @@ void emu_sha512_96(const uint8_t *in, uint8_t *out) { u32 wi[24], wo[16]; load_w
 void emu_sc_reduce512(const uint8_t *in, uint8_t *out) { u32 wi[16], wo[8]; load_words(wi, in, 16); sc_reduce512(wo, wi); memcpy(out, wo, 32); }
 void emu_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { u32 wa[8], wb[8], wo[8]; load_words(wa, a, 8); load_words(wb, b, 8); sc_mul(wo, wa, wb); memcpy(out, wo, 32); }
 int emu_sc_is_canonical(const uint8_t *s) { u32 w[8]; load_words(w, s, 8); return sc_is_canonical(w); }
+void emu_sc_digits8(const uint8_t *s, int16_t *digits) {
+    u32 w[8], r[8]; load_words(w, s, 8); sc_recode256(r, w);
+    for (int i = 0; i < 32; i++) digits[i] = (int16_t)sc_pop_digit8(r);
+}
 // digits of the signed radix-16 recoding, most significant first
 void emu_sc_digits(const uint8_t *s, int8_t *digits) {
     u32 w[8], r[8]; load_words(w, s, 8); sc_recode16(r, w);
@@ -58,7 +62,7 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
     workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
-    ge_niels btab[9]; make_base_table(btab, 9);
+    static ge_niels btab[HS_BTAB_ENTRIES]; make_base_table(btab, HS_BTAB_ENTRIES);
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
         u32 pk[8], sig[16], msg[8];
@@ -74,7 +78,7 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
     workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
-    fe btab[9][4]; make_base_table_quad(btab, 9);
+    static fe btab[HS_BTAB_ENTRIES][4]; make_base_table_quad(btab, HS_BTAB_ENTRIES);
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
         u32 pk[8], sig[16], msg[8];

@@ -6,6 +6,8 @@ import hashlib
 import os
 import random
 
+import pytest
+
 import ed25519_ref as E
 from conftest import S, oracle_verify_many
 
@@ -74,6 +76,19 @@ def test_sha512_and_scalars(emu):
         assert v == s
 
 
+def test_radix256_recoding(emu):
+    rnd = random.Random(13)
+    dg = (ctypes.c_int16 * 32)()
+    for i in range(60):
+        s = [0, 1, L - 1, 2 ** 253 - 1, 2 ** 252, 0x80 << 200, 0x7f << 120][i] if i < 7 else rnd.getrandbits(253)
+        emu.emu_sc_digits8(rb(s), dg)
+        v = 0
+        for d in dg:
+            assert -128 <= d <= 127
+            v = v * 256 + d
+        assert v == s
+
+
 def test_decompress_matches_dalek_rules(emu, edge_vectors):
     x, y, sm = B(32), B(32), ctypes.c_int()
     encs = [os.urandom(32) for _ in range(80)]
@@ -87,20 +102,25 @@ def test_decompress_matches_dalek_rules(emu, edge_vectors):
             assert bool(sm.value) == E.pt_is_small_order(p)
 
 
-def test_verify_stages_on_edge_vectors(emu, edge_vectors):
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad"])
+def test_verify_stages_on_edge_vectors(emu, edge_vectors, fn):
+    """fn = the one-lane-per-signature stage 2 or the quad (4 lanes per signature) stage 2."""
+    verify = getattr(emu, fn)
     n = len(edge_vectors)
     msgs = b"".join(bytes.fromhex(v["msg"]) for v in edge_vectors)
     pks = b"".join(bytes.fromhex(v["pk"]) for v in edge_vectors)
     sigs = b"".join(bytes.fromhex(v["sig"]) for v in edge_vectors)
     out = B(n)
-    emu.emu_verify(msgs, S(32), pks, sigs, S(n), 1, out)
+    verify(msgs, S(32), pks, sigs, S(n), 1, out)
     assert [bool(b) for b in out.raw] == [v["strict"] for v in edge_vectors]
-    emu.emu_verify(msgs, S(32), pks, sigs, S(n), 0, out)
+    verify(msgs, S(32), pks, sigs, S(n), 0, out)
     assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in edge_vectors]
 
 
-def test_verify_stages_vs_c_oracle_random(emu, oracle):
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad"])
+def test_verify_stages_vs_c_oracle_random(emu, oracle, fn):
     import synth
+    verify = getattr(emu, fn)
     n = 96
     for shared in (False, True):
         dg, pk, sg = synth.make_batch(n, shared=shared)
@@ -108,6 +128,6 @@ def test_verify_stages_vs_c_oracle_random(emu, oracle):
         stride = 0 if shared else 32
         for mode in (0, 1):
             out = B(n)
-            emu.emu_verify(dg, S(stride), pk, sg, S(n), mode, out)
+            verify(dg, S(stride), pk, sg, S(n), mode, out)
             assert out.raw == oracle_verify_many(oracle, dg, stride, pk, sg, n, mode)
             assert [i for i in range(n) if not out.raw[i]] == bad
