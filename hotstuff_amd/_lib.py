@@ -62,6 +62,20 @@ def lib():
                 l.hs_ed25519_ctx_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
                 l.hs_ed25519_ctx_kernel_times.restype = ctypes.c_int
+                l.hs_ed25519_keyset_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz]
+                l.hs_ed25519_keyset_create.restype = ctypes.c_int
+                l.hs_ed25519_keyset_destroy.argtypes = [vp]
+                l.hs_ed25519_keyset_destroy.restype = None
+                l.hs_ed25519_keyset_size.argtypes = [vp]
+                l.hs_ed25519_keyset_size.restype = sz
+                l.hs_ed25519_keyset_bytes.argtypes = [sz]
+                l.hs_ed25519_keyset_bytes.restype = sz
+                l.hs_ed25519_verify_shared_cached.argtypes = [vp, vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_shared_cached.restype = ctypes.c_int
+                l.hs_ed25519_verify_multi_cached.argtypes = [vp, vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_multi_cached.restype = ctypes.c_int
+                l.hs_ed25519_verify_device_cached.argtypes = [vp, vp, vp, sz, vp, vp, sz, u32, vp, vp, vp]
+                l.hs_ed25519_verify_device_cached.restype = ctypes.c_int
                 _lib = l
     return _lib
 
@@ -117,6 +131,69 @@ def verify_packed(digests, pks, sigs, n, mode, shared, want_bitmap=False):
     return rc == 1, (bytes(bm) if bm is not None else None)
 
 
+class KeySet:
+    """hs_ed25519_keyset: the committee key cache.  Built once per epoch from the committee's
+    public keys (consensus/src/config.rs:39-43); per-key window tables live in HBM and every
+    later verification of those keys skips the doublings and both decompressions.
+    `index` maps key bytes -> position, the lookup the Rust shim does next to the stake map."""
+
+    UNKNOWN = 0xFFFFFFFF
+
+    def __init__(self, pks):
+        ensure_init()
+        pks = [bytes(p) for p in pks]
+        if not pks or any(len(p) != 32 for p in pks):
+            raise ValueError("KeySet needs a non-empty list of 32-byte keys")
+        self.index = {}
+        for i, p in enumerate(pks):
+            self.index.setdefault(p, i)
+        self.n = len(pks)
+        self._h = ctypes.c_void_p()
+        buf, keep = _buf(b"".join(pks))
+        check(lib().hs_ed25519_keyset_create(ctypes.byref(self._h), buf, self.n), "hs_ed25519_keyset_create")
+        del keep
+
+    @property
+    def handle(self):
+        return self._h
+
+    def hbm_bytes(self):
+        return lib().hs_ed25519_keyset_bytes(self.n)
+
+    def indices(self, pks):
+        """uint32 little-endian packed indices for a sequence of key byte strings."""
+        import struct
+        idx = [self.index.get(bytes(p), self.UNKNOWN) for p in pks]
+        return struct.pack("<%dI" % len(idx), *idx), idx
+
+    def verify_packed(self, digests, key_idx_packed, sigs, n, mode, shared, want_bitmap=False):
+        n = int(n)
+        if len(key_idx_packed) != 4 * n or len(sigs) != 64 * n or len(digests) != (32 if shared else 32 * n):
+            raise ValueError("packed buffer sizes do not match n=%d" % n)
+        if n == 0:
+            return True, (b"" if want_bitmap else None)
+        bm = (ctypes.c_ubyte * ((n + 7) // 8))() if want_bitmap else None
+        pd, k1 = _buf(digests)
+        pi, k2 = _buf(key_idx_packed)
+        ps, k3 = _buf(sigs)
+        fn = lib().hs_ed25519_verify_shared_cached if shared else lib().hs_ed25519_verify_multi_cached
+        rc = check(fn(self._h, pd, pi, ps, n, mode, ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
+                   "hs_ed25519_verify_cached")
+        del k1, k2, k3
+        return rc == 1, (bytes(bm) if bm is not None else None)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hs_ed25519_keyset_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceContext:
     """hs_ed25519_ctx: workspace + stream for device-resident batches.  Pointers are raw
     HIP device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
@@ -140,6 +217,11 @@ class DeviceContext:
         check(lib().hs_ed25519_verify_device(self._h, d_digests, digest_stride, d_pks, d_sigs, int(n), mode,
                                              d_bitmap, d_nreject or None, stream or None),
               "hs_ed25519_verify_device")
+
+    def verify_cached(self, keyset, d_digests, digest_stride, d_key_idx, d_sigs, n, mode, d_bitmap, d_nreject=0, stream=0):
+        check(lib().hs_ed25519_verify_device_cached(self._h, keyset.handle, d_digests, digest_stride, d_key_idx, d_sigs,
+                                                    int(n), mode, d_bitmap, d_nreject or None, stream or None),
+              "hs_ed25519_verify_device_cached")
 
     def set_profiling(self, slots):
         check(lib().hs_ed25519_ctx_set_profiling(self._h, int(slots)), "hs_ed25519_ctx_set_profiling")

@@ -100,28 +100,35 @@ class Signature:
             raise CryptoError()
 
     @staticmethod
-    def verify_batch(digest, votes):
+    def verify_batch(digest, votes, keyset=None):
         """lib.rs:206-219: one shared digest, iterable of (PublicKey, Signature);
-        empty -> Ok.  All-or-nothing."""
+        empty -> Ok.  All-or-nothing.  With `keyset` (the committee key cache) and every
+        key registered in it, the cached kernels are used; the verdict is the same."""
         pks = bytearray()
         sigs = bytearray()
+        keys = []
         n = 0
         for key, sig in votes:
             pks += key.b
+            keys.append(key.b)
             sigs += sig.part1
             sigs += sig.part2
             n += 1
         if n == 0:
             return
         try:
-            ok, _ = _lib.verify_packed(digest.b, bytes(pks), bytes(sigs), n, _lib.BATCH, shared=True)
+            if keyset is not None and all(k in keyset.index for k in keys):
+                packed, _ = keyset.indices(keys)
+                ok, _ = keyset.verify_packed(digest.b, packed, bytes(sigs), n, _lib.BATCH, shared=True)
+            else:
+                ok, _ = _lib.verify_packed(digest.b, bytes(pks), bytes(sigs), n, _lib.BATCH, shared=True)
         except _lib.EngineError as e:
             raise CryptoError(str(e)) from e
         if not ok:
             raise CryptoError()
 
     @staticmethod
-    def verify_many(digests, votes):
+    def verify_many(digests, votes, keyset=None):
         """One digest per (PublicKey, Signature) pair, strict semantics - the batched
         form of the loop at consensus/src/messages.rs:307-313.  Returns the per-pair
         accept list (the reference stops at the first failure; "all accepted" is the
@@ -134,7 +141,11 @@ class Signature:
         sigs = b"".join(s.flatten() for _, s in votes)
         dg = b"".join(d.b for d in digests)
         try:
-            _, bm = _lib.verify_packed(dg, pks, sigs, n, _lib.STRICT, shared=False, want_bitmap=True)
+            if keyset is not None and all(k.b in keyset.index for k, _ in votes):
+                packed, _ = keyset.indices([k.b for k, _ in votes])
+                _, bm = keyset.verify_packed(dg, packed, sigs, n, _lib.STRICT, shared=False, want_bitmap=True)
+            else:
+                _, bm = _lib.verify_packed(dg, pks, sigs, n, _lib.STRICT, shared=False, want_bitmap=True)
         except _lib.EngineError as e:
             raise CryptoError(str(e)) from e
         return [bool(bm[i >> 3] >> (i & 7) & 1) for i in range(n)]

@@ -18,6 +18,7 @@
 #include <vector>
 #include "verify.h"
 #include "verify_quad.h"
+#include "verify_cached.h"
 #include "../../include/hs_ed25519.h"
 
 using namespace hs;
@@ -96,6 +97,75 @@ k_verify_fused(const u32 *__restrict__ digests, u32 digest_stride_words, const u
                                       mode, g_btab4);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    if (threadIdx.x == 0) {
+        bitmap16[blockIdx.x] = (unsigned short)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 16;
+            const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
+            const u32 bad = sigs_here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
+// ---- committee key cache (verify_cached.h) -------------------------------------------------
+// registration pass 1: one lane per key - decompress, flags, keep the key bytes
+__global__ void __launch_bounds__(64, 3)
+k_keyset_decompress(const u32 *__restrict__ pks, u32 nkeys, u32 *__restrict__ axy, u32 *__restrict__ pk_out,
+                    u32 *__restrict__ flag) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= nkeys) return;
+    u32 enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { enc[j] = pks[(size_t)8 * k + j]; pk_out[(size_t)8 * k + j] = enc[j]; }
+    ge_p3 p;
+    u32 fl = ge_decompress(p, enc) ? HS_F_ONCURVE : 0;
+    fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+    flag[k] = fl;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { axy[(size_t)20 * k + j] = p.X.v[j]; axy[(size_t)20 * k + 10 + j] = p.Y.v[j]; }
+}
+// registration pass 2: one quad per (window, key); the 16 quads of a wavefront share a window
+// so that their 8w doublings stay convergent
+__global__ void __launch_bounds__(64)
+k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u32 nkeys_pad, u32 negate) {
+    const u32 g = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const u32 w = g / nkeys_pad, k = g % nkeys_pad;
+    const bool active = k < nkeys;
+    const u32 kk = active ? k : nkeys - 1;
+    fe ax, ay;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { ax.v[j] = axy[(size_t)20 * kk + j]; ay.v[j] = axy[(size_t)20 * kk + 10 + j]; }
+    // inactive tail quads rebuild the last key's window into the same place (identical values)
+    keyset_build_window(tab + (size_t)kk * HS_KS_KEY_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
+                        ax, ay, negate != 0, (int)w);
+}
+// verification against a key set: one quad per signature, 64 table additions + 1 inversion
+__global__ void __launch_bounds__(64, 3)
+k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, const u32 *__restrict__ digests,
+                u32 digest_stride_words, const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
+    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const u32 ki_raw = key_idx[j];
+    const bool known = ki_raw < nkeys;
+    const u32 ki = known ? ki_raw : 0;
+    const u32 *sig = sigs + (size_t)16 * j;
+    u32 kw[8], sw[8], renc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) renc[t] = sig[t];
+    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, digests + (size_t)digest_stride_words * j, true);
+    const u32 fl = ks.flag[ki];
+    ok = ok && known && (fl & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
+    const bool curve = verify_cached_core(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
+    unsigned long long m = __ballot(ok && curve && active);
+    m &= 0x1111111111111111ull;         // the verdict is quad-uniform: take lane 0 of each quad
     m = (m | (m >> 3)) & 0x0303030303030303ull;
     m = (m | (m >> 6)) & 0x000f000f000f000full;
     m = (m | (m >> 12)) & 0x000000ff000000ffull;
@@ -323,6 +393,113 @@ extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_
     return 0;
 }
 
+// ---- key sets --------------------------------------------------------------------------------
+struct hs_ed25519_keyset {
+    size_t nkeys = 0;
+    u32 *d_tab = nullptr, *d_pk = nullptr, *d_flag = nullptr;
+};
+static u32 *g_base_tab = nullptr;       // the base point's own window table (same layout)
+
+static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate, hipStream_t st) {
+    const u32 nk = (u32)nkeys, pad = (u32)round_up(nkeys, 16), neg = negate ? 1u : 0u;
+    void *args[] = { &d_tab, &d_axy, (void *)&nk, (void *)&pad, (void *)&neg };
+    HS_HIP(hipLaunchKernel((const void *)k_keyset_build, dim3(pad / 16 * HS_KS_WINDOWS), dim3(64), args, 0, st),
+           "launch k_keyset_build");
+    return 0;
+}
+static int ensure_base_table() {        // caller holds no lock; idempotent under g_mu
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_base_tab) return 0;
+    ge_p3 b; ge_basepoint(b);
+    u32 h_axy[20];
+    for (int j = 0; j < 10; j++) { h_axy[j] = b.X.v[j]; h_axy[10 + j] = b.Y.v[j]; }
+    u32 *d_axy = nullptr, *d_tab = nullptr;
+    HS_HIP(hipMalloc((void **)&d_axy, sizeof h_axy), "hipMalloc");
+    HS_HIP(hipMalloc((void **)&d_tab, (size_t)HS_KS_KEY_WORDS * 4), "hipMalloc base table");
+    HS_HIP(hipMemcpy(d_axy, h_axy, sizeof h_axy, hipMemcpyHostToDevice), "H2D");
+    int rc = build_tables(d_tab, d_axy, 1, false, nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize(), "base table build");
+    (void)hipFree(d_axy);
+    g_base_tab = d_tab;
+    return 0;
+}
+
+extern "C" size_t hs_ed25519_keyset_bytes(size_t nkeys) { return nkeys * ((size_t)HS_KS_KEY_WORDS * 4 + 32 + 4); }
+
+extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t nkeys) {
+    if (!out || !pks || nkeys == 0 || nkeys > 0x0fffffffu) return fail(HS_ED25519_E_ARG, "keyset_create: bad arguments");
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    int rc = ensure_base_table();
+    if (rc) return rc;
+    hs_ed25519_keyset *ks = new (std::nothrow) hs_ed25519_keyset();
+    if (!ks) return fail(HS_ED25519_E_NOMEM, "keyset_create: out of memory");
+    u32 *d_in = nullptr, *d_axy = nullptr;
+    hipError_t e = hipSuccess;
+    do {
+        if ((e = hipMalloc((void **)&ks->d_tab, nkeys * (size_t)HS_KS_KEY_WORDS * 4)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&ks->d_pk, nkeys * 32)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&ks->d_flag, nkeys * 4)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&d_in, nkeys * 32)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&d_axy, nkeys * 80)) != hipSuccess) break;
+        if ((e = hipMemcpy(d_in, pks, nkeys * 32, hipMemcpyHostToDevice)) != hipSuccess) break;
+        const u32 nk = (u32)nkeys;
+        void *a[] = { &d_in, (void *)&nk, &d_axy, &ks->d_pk, &ks->d_flag };
+        if ((e = hipLaunchKernel((const void *)k_keyset_decompress, dim3((nk + 63) / 64), dim3(64), a, 0, nullptr)) != hipSuccess) break;
+        if (build_tables(ks->d_tab, d_axy, nkeys, true, nullptr)) { e = hipErrorUnknown; break; }
+        e = hipDeviceSynchronize();
+    } while (0);
+    if (d_in) (void)hipFree(d_in);
+    if (d_axy) (void)hipFree(d_axy);
+    if (e != hipSuccess) {
+        if (ks->d_tab) (void)hipFree(ks->d_tab);
+        if (ks->d_pk) (void)hipFree(ks->d_pk);
+        if (ks->d_flag) (void)hipFree(ks->d_flag);
+        delete ks;
+        return fail(e == hipErrorOutOfMemory ? HS_ED25519_E_NOMEM : HS_ED25519_E_DEVICE, "keyset_create", e);
+    }
+    ks->nkeys = nkeys;
+    *out = ks;
+    return 0;
+}
+extern "C" void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks) {
+    if (!ks) return;
+    (void)hipDeviceSynchronize();
+    if (ks->d_tab) (void)hipFree(ks->d_tab);
+    if (ks->d_pk) (void)hipFree(ks->d_pk);
+    if (ks->d_flag) (void)hipFree(ks->d_flag);
+    delete ks;
+}
+extern "C" size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks) { return ks ? ks->nkeys : 0; }
+
+extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
+                                               size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs,
+                                               size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_cached: null context / key set");
+    if (n == 0) return 0;
+    if (!d_digests || !d_key_idx || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_cached: null pointer");
+    if (misaligned(d_digests, 16) || misaligned(d_key_idx, 4) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) ||
+        misaligned(d_nreject, 4))
+        return fail(HS_ED25519_E_ARG, "verify_device_cached: misaligned pointer");
+    if ((digest_stride != 0 && digest_stride != 32) || mode > 1 || n > 0x3fffffffu)
+        return fail(HS_ED25519_E_ARG, "verify_device_cached: bad digest_stride / mode / n");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const u32 np = (u32)round_up(n, 64);
+    keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
+    u32 nkeys = (u32)ks->nkeys, dsw = (u32)(digest_stride / 4), nn = (u32)n, mode_ = mode;
+    const u32 *p_bt = g_base_tab, *p_dg = (const u32 *)d_digests, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
+    unsigned short *p_bm = (unsigned short *)d_bitmap;
+    u32 *p_nr = d_nreject;
+    void *a[] = { &kv, &nkeys, &p_bt, &p_dg, &dsw, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
+    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
+    if (ev) { HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord"); }
+    HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
+    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
+    return 0;
+}
+
 // ---- host-pointer API ----------------------------------------------------------------------
 static int pool_get(hs_ed25519_ctx **out) {
     std::unique_lock<std::mutex> lk(g_mu);
@@ -385,4 +562,47 @@ extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t 
 extern "C" int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
                                        size_t n, uint32_t mode, uint8_t *bitmap) {
     return verify_host(digests, 32, pks, sigs, n, mode, bitmap);
+}
+
+// host-pointer form of the cached path: key_idx[i] indexes the key set
+static int verify_host_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                              const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (mode > 1) return fail(HS_ED25519_E_ARG, "verify: bad mode");
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
+    if (n == 0) return 1;
+    if (!digests || !key_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
+    hs_ed25519_ctx *c = nullptr;
+    int rc = pool_get(&c);
+    if (rc) return rc;
+    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    size_t want = n > g_max_batch ? n : g_max_batch;
+    rc = ctx_reserve(c, want, true);
+    if (rc) return rc;
+    // staging (capacity 128 B per signature): [digests][key_idx: 4n][sigs: 64n]
+    const size_t dg_bytes = digest_stride ? 32 * n : 32;
+    const size_t off_ki = round_up(dg_bytes, 16), off_sig = round_up(off_ki + 4 * n, 16), in_bytes = off_sig + 64 * n;
+    memcpy(c->h_in, digests, dg_bytes);
+    memcpy(c->h_in + off_ki, key_idx, 4 * n);
+    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    const size_t bm = bitmap_bytes(n);
+    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
+    rc = hs_ed25519_verify_device_cached(c, ks, c->d_in, digest_stride, (const uint32_t *)(c->d_in + off_ki), c->d_in + off_sig,
+                                         n, mode, c->d_out, (uint32_t *)(c->d_out + bm), c->stream);
+    if (rc) return rc;
+    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    uint32_t nrej;
+    memcpy(&nrej, c->h_out + bm, 4);
+    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
+    return nrej == 0 ? 1 : 0;
+}
+extern "C" int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
+                                               const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host_cached(ks, digest, 0, key_idx, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
+                                              const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host_cached(ks, digests, 32, key_idx, sigs, n, mode, bitmap);
 }

@@ -1,0 +1,152 @@
+// verify_cached.h - verification against a registered key set (committee key cache).
+//
+// In the reference every verified key belongs to the committee, which is static per epoch
+// (consensus/src/config.rs:39-43; Block/Vote/QC/Timeout/TC::verify all check
+// committee.stake(author) > 0 before the signature, consensus/src/messages.rs:57-61,
+// 138-142, 182-194, 252-256, 292-304).  So the variable-base half of
+//      [k](-A) + [s]B == R
+// can be tabled per key once per epoch.  With signed 8-bit windows
+//      [k](-A) = sum_w T_A[w][k_w],   T_A[w][j] = j * 2^(8w) * (-A),   w < 32, j <= 128
+// a verification is 32 + 32 table additions: no doublings, no decompression of A; and R is
+// checked without decompressing it either - compute R' = sum, invert Z once, compare y' with
+// the encoded y and the parity of x' with the sign bit (equivalent to dalek's "decompress R,
+// compare points": if y' = y_R the encoding is on the curve and decodes to (+-x', y'); the
+// sign bit picks x' unless x' = 0, where dalek accepts either sign).
+//
+// Cost: 64 additions + 1 inversion, against 252 doublings + 96 additions + 2 square roots
+// for the cold path.  Price: 129 * 32 cached points = 660,480 bytes of HBM per key
+// (6.6 GB for 10,000 validators, 66 GB for 100,000 - MI355X has 288 GB).
+//
+// Table entries use the quad kernel's cached layout, (Y-X, Y+X, 2dT, 2Z) one coordinate per
+// lane, so the same q_add_cached serves; entry 0 of every window is the identity.
+// Same accept set as verify_lane / verify_quad (tests run all 70 edge vectors through it).
+#pragma once
+#include "verify_quad.h"
+
+namespace hs {
+
+#define HS_KS_WINDOWS 32
+#define HS_KS_ENTRIES 129
+#define HS_KS_ENTRY_WORDS 40                                   // 4 lanes x 10 limbs
+#define HS_KS_KEY_WORDS (HS_KS_WINDOWS * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS)
+
+// per-key header written by the registration pass
+struct keyset_view {
+    const u32 *tab;      // [key][window][entry][lane][limb]
+    const u32 *pk;       // [key][8]   the 32 key bytes (hash input)
+    const u32 *flag;     // [key]      HS_F_ONCURVE | HS_F_SMALL
+};
+
+#if defined(__HIPCC__)
+HS_Q qv q_invert(const qv &z) { qv r; fe_invert(r, z); return r; }
+HS_Q bool q_quad_and01(const qflags &f) {     // lanes 0 and 1 both set, uniform over the quad
+    const int v = f.f ? 1 : 0;
+    const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
+    const int b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
+    return a && b;
+}
+HS_Q qv q_load_entry(const u32 *entry) {      // this lane's coordinate of a 40-word entry
+    const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * q_lane());
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const uint2 v = p[i]; r.v[2 * i] = v.x; r.v[2 * i + 1] = v.y; }
+    return r;
+}
+HS_Q void q_store_entry(u32 *entry, const qv &e) {
+    uint2 *p = reinterpret_cast<uint2 *>(entry + 10 * q_lane());
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] = make_uint2(e.v[2 * i], e.v[2 * i + 1]);
+}
+// lane 0: x' has the encoded sign (or x' = 0); lane 1: y' equals the encoded y; lanes 2,3: true
+HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
+    u32 w[8];
+    fe_to_words(w, affine);
+    fe ye; fe_from_words(ye, enc);
+    u32 yw[8];
+    fe_to_words(yw, ye);
+    u32 dy = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { dy |= w[i] ^ yw[i]; nz |= w[i]; }
+    const u32 lane = q_lane();
+    qflags r;
+    r.f = lane == 0 ? ((w[0] & 1) == (enc[7] >> 31) || nz == 0) : (lane == 1 ? dy == 0 : true);
+    return r;
+}
+// lane 0: X == 0; lane 1: Y == Z; (identity test of a projective point held in a quad)
+HS_Q qflags q_identity_lanes(const qv &p) {
+    const qv z = q_perm<2, 2, 2, 2>(p);
+    qflags r;
+    const u32 lane = q_lane();
+    r.f = lane == 0 ? fe_iszero(p) : (lane == 1 ? fe_eq(q_carry(p), q_carry(z)) : true);
+    return r;
+}
+#else
+HS_Q qv q_invert(const qv &z) { qv r; for (int i = 0; i < 4; i++) fe_invert(r.l[i], z.l[i]); return r; }
+HS_Q bool q_quad_and01(const qflags &f) { return f.f[0] && f.f[1]; }
+HS_Q qv q_load_entry(const u32 *entry) {
+    qv r; for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i]; return r;
+}
+HS_Q void q_store_entry(u32 *entry, const qv &e) {
+    for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) entry[10 * l + i] = e.l[l].v[i];
+}
+HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
+    u32 wx[8], wy[8], yw[8];
+    fe_to_words(wx, affine.l[0]); fe_to_words(wy, affine.l[1]);
+    fe ye; fe_from_words(ye, enc); fe_to_words(yw, ye);
+    u32 dy = 0, nz = 0;
+    for (int i = 0; i < 8; i++) { dy |= wy[i] ^ yw[i]; nz |= wx[i]; }
+    qflags r; r.f[0] = (wx[0] & 1) == (enc[7] >> 31) || nz == 0; r.f[1] = dy == 0; r.f[2] = r.f[3] = true;
+    return r;
+}
+HS_Q qflags q_identity_lanes(const qv &p) {
+    qflags r; r.f[0] = fe_iszero(p.l[0]);
+    fe y = p.l[1], z = p.l[2]; fe_carry(y); fe_carry(z);
+    r.f[1] = fe_eq(y, z); r.f[2] = r.f[3] = true; return r;
+}
+#endif
+
+// ---- registration: one quad per (key, window) ---------------------------------------------
+// ax, ay: the decompressed key (affine); negate: tables of -A (keys) or +B (base point).
+// Writes entries 0..128 of window `w`: j * 2^(8w) * (+-A) in cached form.
+HS_Q void keyset_build_window(u32 *win /* [129][40] */, const fe &ax, const fe &ay, bool negate, int w) {
+    fe x = ax;
+    if (negate) fe_neg(x, ax);
+    qv p = q_mul(q_lanes(x, ay, fe_small(1), x), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
+#pragma nounroll
+    for (int d = 0; d < 8 * w; d++) p = q_dbl(p);
+    q_store_entry(win, q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2)));
+    const qv e1 = q_to_cached(p);
+    q_store_entry(win + HS_KS_ENTRY_WORDS, e1);
+#pragma nounroll
+    for (int j = 2; j < HS_KS_ENTRIES; j++) {
+        p = q_add_cached(p, e1);
+        q_store_entry(win + (size_t)j * HS_KS_ENTRY_WORDS, q_to_cached(p));
+    }
+}
+
+// ---- verification: one quad per signature -------------------------------------------------
+// atab: this key's table; btab: the base point's table (same layout, +B).
+// kw, sw: radix-256 recodings of k and s.  renc: the 8 words of R's encoding.
+// strict: also reject when [8]R' = O.   Returns the quad-uniform verdict of the curve part.
+HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
+#pragma nounroll
+    for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
+        const int dk = sc_pop_digit8(kw), ds = sc_pop_digit8(sw);
+        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        const qv ea = q_load_entry(atab + ((size_t)w * HS_KS_ENTRIES + ik) * HS_KS_ENTRY_WORDS);
+        const qv eb = q_load_entry(btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
+        acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
+        acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+    }
+    bool ok = true;
+    if (strict) {       // [8]R' == O ?  (R' == R whenever the signature is accepted)
+        qv t = q_dbl(q_dbl(q_dbl(acc)));
+        ok = !q_quad_and01(q_identity_lanes(t));
+    }
+    const qv zinv = q_invert(q_perm<2, 2, 2, 2>(acc));
+    const qv aff = q_mul(acc, zinv);                        // (x', y', 1, t')
+    return ok && q_quad_and01(q_match_encoding(aff, renc));
+}
+
+}  // namespace hs

@@ -191,13 +191,15 @@ HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4
 
 // The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
 // computes it redundantly so no lane diverges.  Returns s < L.
-HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, const u32 *msg) {
+// k is recoded in signed radix 16 (cold path: 4-bit windows on -A) or, with k_radix256, in
+// signed radix 256 (cached path: 8-bit windows on both points).
+HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, const u32 *msg, bool k_radix256 = false) {
     u32 in[24], h[16], k[8], s[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
     sha512_96(h, in);
     sc_reduce512(k, h);
-    sc_recode16(kw, k);
+    if (k_radix256) sc_recode256(kw, k); else sc_recode16(kw, k);
     sc_recode256(sw, s);
     return sc_is_canonical(s);
 }

@@ -46,9 +46,21 @@ class InvalidSignature(ConsensusError):
 class Committee:
     """consensus::config::Committee reduced to what verify needs: name -> stake."""
 
-    def __init__(self, authorities, epoch=0):
+    def __init__(self, authorities, epoch=0, cache_keys=False):
         self.authorities = dict(authorities)   # PublicKey -> stake
         self.epoch = epoch
+        self._keyset = None
+        self._cache_keys = cache_keys
+
+    @property
+    def keyset(self):
+        """The committee key cache (hotstuff_amd._lib.KeySet), built on first use when the
+        committee was created with cache_keys=True: the committee is static for the epoch, so
+        the per-key tables are built once and every QC / TC verification reuses them."""
+        if self._cache_keys and self._keyset is None:
+            from . import _lib
+            self._keyset = _lib.KeySet([k.b for k in self.authorities])
+        return self._keyset
 
     def size(self):
         return len(self.authorities)
@@ -98,7 +110,7 @@ class QC:
     def verify(self, committee):
         _check_quorum((name for name, _ in self.votes), committee, QCRequiresQuorum)
         try:
-            Signature.verify_batch(self.digest(), self.votes)
+            Signature.verify_batch(self.digest(), self.votes, keyset=committee.keyset)
         except CryptoError as e:
             raise InvalidSignature() from e
 
@@ -121,7 +133,7 @@ class TC:
         _check_quorum((name for name, _, _ in self.votes), committee, TCRequiresQuorum)
         digests = [self.vote_digest(r) for _, _, r in self.votes]
         try:
-            oks = Signature.verify_many(digests, [(a, s) for a, s, _ in self.votes])
+            oks = Signature.verify_many(digests, [(a, s) for a, s, _ in self.votes], keyset=committee.keyset)
         except CryptoError as e:
             raise InvalidSignature() from e
         if not all(oks):

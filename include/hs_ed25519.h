@@ -103,6 +103,30 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
                              const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
                              uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
 
+/* ---- committee key cache -------------------------------------------------------------------
+ * Every key the reference verifies belongs to the committee, which is static per epoch
+ * (consensus/src/config.rs:39-43).  hs_ed25519_keyset_create decompresses the n_keys public
+ * keys once and builds per-key window tables in HBM (660,516 bytes per key; see
+ * hs_ed25519_keyset_bytes) so that a verification needs no doublings and no decompression:
+ * 64 table additions + 1 inversion.  The *_cached calls take key_idx[i] = position of
+ * signature i's key in the set instead of the key bytes (the Rust shim resolves it with the
+ * same map QC::verify / TC::verify already use for the stake lookup,
+ * consensus/src/messages.rs:182-194); an index >= n_keys rejects that signature.  Accept set,
+ * return values, bitmap format, modes and alignment rules are identical to the calls above.
+ * A key set is immutable and may be used concurrently from any number of threads/streams. */
+typedef struct hs_ed25519_keyset hs_ed25519_keyset;
+int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys);
+void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks);
+size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks);
+size_t hs_ed25519_keyset_bytes(size_t n_keys);   /* HBM footprint of a key set of that size */
+int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
+                                    const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap);
+int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
+                                   const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap);
+int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
+                                    size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n,
+                                    uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
+
 /* Profiling: keep a ring of `slots` HIP-event triples recorded on the launch stream around
  * the two kernels of each hs_ed25519_verify_device call on `ctx` (0 = off).  After the
  * stream has been synchronised, hs_ed25519_ctx_kernel_times returns the summed durations

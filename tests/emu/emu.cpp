@@ -6,6 +6,7 @@
 #include <vector>
 #include "../../hotstuff_amd/csrc/verify.h"
 #include "../../hotstuff_amd/csrc/verify_quad.h"
+#include "../../hotstuff_amd/csrc/verify_cached.h"
 using namespace hs;
 
 static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
@@ -88,6 +89,42 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
     for (size_t i = 0; i < n; i++) {
         bool fl; qflags f = verify_quad(ws, (u32)i, mode, btab, fl);
         out[i] = (fl && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
+    }
+}
+// ---- committee key cache (verify_cached.h) ----
+size_t emu_keyset_words(size_t nkeys) { return nkeys * (size_t)HS_KS_KEY_WORDS; }
+// tab: nkeys * HS_KS_KEY_WORDS words; flag: nkeys words.  Key `nkeys` is not stored here: the
+// base point's own table is built by emu_keyset_build_base.
+void emu_keyset_build(const uint8_t *pks, size_t nkeys, uint32_t *tab, uint32_t *flag) {
+    for (size_t k = 0; k < nkeys; k++) {
+        u32 w[8]; load_words(w, pks + 32 * k, 8);
+        ge_p3 p; u32 fl = ge_decompress(p, w) ? HS_F_ONCURVE : 0;
+        fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+        flag[k] = fl;
+        for (int win = 0; win < HS_KS_WINDOWS; win++)
+            keyset_build_window(tab + k * (size_t)HS_KS_KEY_WORDS + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
+                                p.X, p.Y, true, win);
+    }
+}
+void emu_keyset_build_base(uint32_t *tab) {
+    ge_p3 b; ge_basepoint(b);
+    for (int win = 0; win < HS_KS_WINDOWS; win++)
+        keyset_build_window(tab + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS, b.X, b.Y, false, win);
+}
+void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys, const uint32_t *btab,
+                       const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
+                       uint32_t mode, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        const u32 ki = key_idx[i];
+        if (ki >= nkeys) { out[i] = 0; continue; }
+        u32 pk[8], sig[16], msg[8], kw[8], sw[8];
+        load_words(pk, pks + 32 * ki, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        bool ok = prepare_scalars(kw, sw, pk, sig, msg, true);
+        const u32 fl = flag[ki];
+        ok = ok && (fl & HS_F_ONCURVE);
+        if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
+        const bool curve = verify_cached_core(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, (mode & HS_MODE_STRICT) != 0);
+        out[i] = (ok && curve) ? 1 : 0;
     }
 }
 }

@@ -1,0 +1,150 @@
+"""GPU parity of the committee key cache (hs_ed25519_keyset_* / *_cached, verify_cached.h)
+against the oracle and the edge vectors, through the C-ABI."""
+import os
+
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+from hotstuff_amd.crypto import Digest, PublicKey, Signature
+from hotstuff_amd.messages import QC, TC, Committee, InvalidSignature
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    assert torch.cuda.is_available()
+    _lib.init(0, 8192)
+    yield
+
+
+def cached_bits(ks, dg, keys, sg, n, mode, shared):
+    packed, _ = ks.indices(keys)
+    ok, bm = ks.verify_packed(dg, packed, sg, n, mode, shared, want_bitmap=True)
+    b = bits(bm, n)
+    assert ok == all(b)
+    return b
+
+
+def test_edge_vectors_with_every_key_registered(edge_vectors):
+    n = len(edge_vectors)
+    keys = [H(v["pk"]) for v in edge_vectors]
+    ks = _lib.KeySet(keys)
+    assert ks.hbm_bytes() == n * (32 * 129 * 160 + 36)
+    dg = b"".join(H(v["msg"]) for v in edge_vectors)
+    sg = b"".join(H(v["sig"]) for v in edge_vectors)
+    # KeySet.index keeps the first position of a repeated key; the tables of equal keys are equal
+    got = cached_bits(ks, dg, keys, sg, n, _lib.STRICT, False)
+    for v, g in zip(edge_vectors, got):
+        assert bool(g) == v["strict"], ("strict", v["name"])
+    got = cached_bits(ks, dg, keys, sg, n, _lib.BATCH, False)
+    for v, g in zip(edge_vectors, got):
+        assert bool(g) == v["cofactorless"], ("batch", v["name"])
+    ks.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 16, 17, 64, 65, 500])
+@pytest.mark.parametrize("shared", [True, False])
+def test_sizes_vs_oracle_with_corruption(oracle, n, shared):
+    dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    stride = 0 if shared else 32
+    for mode in (_lib.BATCH, _lib.STRICT):
+        got = cached_bits(ks, dg, keys, sg, n, mode, shared)
+        assert got == oracle_verify_many(oracle, dg, stride, pk, sg, n, mode)
+        assert [i for i in range(n) if not got[i]] == bad
+    ks.close()
+
+
+def test_cached_equals_cold_on_config2_and_unknown_index(oracle):
+    n = 1024
+    dg, pk, sg = synth.make_batch(n, shared=False, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    dg2, pk2, sg2, bad = synth.corrupt(dg, pk, sg, n, False)
+    # the committee's keys are the registered ones; a vote whose key bytes were corrupted in
+    # flight is simply a different (unknown) key -> index UNKNOWN -> rejected
+    keys2 = [pk2[32 * i:32 * i + 32] for i in range(n)]
+    packed, idx = ks.indices(keys2)
+    assert any(i == _lib.KeySet.UNKNOWN for i in idx)
+    ok, bm = ks.verify_packed(dg2, packed, sg2, n, _lib.STRICT, False, want_bitmap=True)
+    got = bits(bm, n)
+    assert not ok and [i for i in range(n) if not got[i]] == bad
+    cold_ok, cold_bm = _lib.verify_packed(dg2, pk2, sg2, n, _lib.STRICT, shared=False, want_bitmap=True)
+    assert bits(cold_bm, n) == got
+    # keys presented in a different order than registered
+    perm = list(reversed(range(n)))
+    rp = [keys[i] for i in perm]
+    rs = b"".join(sg[64 * i:64 * i + 64] for i in perm)
+    rd = b"".join(dg[32 * i:32 * i + 32] for i in perm)
+    assert cached_bits(ks, rd, rp, rs, n, _lib.STRICT, False) == b"\x01" * n
+    ks.close()
+
+
+def test_qc_and_tc_through_the_committee_cache(openssl_vectors):
+    fx = openssl_vectors["reference_fixture"]
+    committee = Committee({PublicKey(H(k["pk"])): 1 for k in fx["keys"]}, 100, cache_keys=True)
+    votes = [(PublicKey(H(v["pk"])), Signature.from_bytes(H(v["sig"]))) for v in fx["qc_votes"]]
+    assert QC(Digest(), 1, votes).verify(committee) is None            # messages_tests.rs:8-10
+    assert committee.keyset is not None and committee.keyset.n == 4
+    broken = [votes[0], votes[1], (votes[2][0], votes[1][1])]
+    with pytest.raises(InvalidSignature):
+        QC(Digest(), 1, broken).verify(committee)
+    names = list(committee.authorities)
+    seeds = {H(k["pk"]): H(k["seed"]) for k in fx["keys"]}
+    tc = TC(9, [])
+    tvotes = []
+    for i, name in enumerate(names[:3]):
+        d = tc.vote_digest(i + 1)
+        _, sg = synth.sign(seeds[name.b], d.b)
+        tvotes.append((name, Signature.from_bytes(sg), i + 1))
+    assert TC(9, tvotes).verify(committee) is None
+    tvotes[0] = (tvotes[0][0], tvotes[0][1], 7)
+    with pytest.raises(InvalidSignature):
+        TC(9, tvotes).verify(committee)
+
+
+def test_qc_10000_validators_cached_properties():
+    """BASELINE config 3 with the committee cached: N = 10,000 keys (6.6 GB of tables in HBM),
+    a QC of 6,667 votes by a subset; oracle-free properties."""
+    N, n = 10000, 6667
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    filler = [synth.key_seed(10_000_000 + i) for i in range(N - n)]     # never-voting members: any 32 bytes
+    ks = _lib.KeySet(keys + filler)
+    assert ks.n == N
+    assert cached_bits(ks, dg, keys, sg, n, _lib.BATCH, True) == b"\x01" * n
+    for victim in (0, 3333, n - 1):
+        s2 = bytearray(sg); s2[64 * victim + 9] ^= 0x20
+        got = cached_bits(ks, dg, keys, bytes(s2), n, _lib.BATCH, True)
+        assert [i for i in range(n) if not got[i]] == [victim]
+    assert cached_bits(ks, bytes(32), keys, sg, n, _lib.BATCH, True) == b"\x00" * n
+    ks.close()
+
+
+def test_device_resident_cached_api(oracle):
+    n = 777
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    s2 = bytearray(sg); s2[64 * 5 + 40] ^= 1; s2[64 * 700] ^= 2
+    dev = torch.device("cuda:0")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_dg, d_sg = t(dg), t(bytes(s2))
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+    d_bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
+    d_nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = _lib.DeviceContext(n)
+    ctx.verify_cached(ks, d_dg.data_ptr(), 0, d_ki.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, d_bm.data_ptr(),
+                      d_nr.data_ptr(), ctx.stream)
+    torch.cuda.synchronize()
+    got = bits(bytes(d_bm.cpu().tolist()), n)
+    assert [i for i in range(n) if not got[i]] == [5, 700] and int(d_nr.item()) == 2
+    ctx.close(); ks.close()
