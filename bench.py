@@ -39,9 +39,19 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 ALGO_BYTES_MULTI = 128      # 32 B digest + 32 B key + 64 B signature per verification
 ALGO_BYTES_SHARED = 96
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-# field-multiplication-equivalents per strict verification in k_verify (DESIGN.md "op count"):
-# used only for the informative integer roofline
-MAD64_PER_VERIFY = 252 * (4 * 55 + 4 * 100) + 64 * (8 * 100) + 64 * (6 * 100)
+# Informative integer roofline: v_mad_u64_u32 lane-operations per strict
+# verification, counted statically from the kernels' field-operation counts
+#   (field mul = 100 mads, square = 55; quad kernels count all four lanes of the quad),
+# against the chip-wide issue rate measured by tools/ubench_valu.hip (profiles/r1_ubench_valu.txt).
+MAD_PER_VERIFY = {
+    # fused quad: per wavefront of 16 signatures 256 dbl x (55 + 100) + 96 add x 200 + table 7 x 300
+    # + decompress (255 sq + 21 mul) + small-order test, all x 64 lanes / 16 signatures
+    "k_verify_fused": (256 * 155 + 96 * 200 + 7 * 300 + 255 * 55 + 21 * 100 + 3 * 620) * 64 // 16,
+    "k_verify_quad": (256 * 155 + 96 * 200 + 7 * 300) * 64 // 16,
+    # lane: 1024 sq + ~1600 mul in k_verify (k_prepare adds 2 x (267 sq + 30 mul))
+    "k_verify": 1024 * 55 + 1600 * 100,
+}
+MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 
 
 def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=12.0):
@@ -369,9 +379,16 @@ def main():
                 "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
                 "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
             },
+            "int_roofline": None,
             "kernels_ms": {"k_prepare": round(avg_prepare_ms, 4), "k_verify": round(avg_verify_ms, 4)},
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
+        kname = out["roofline"]["kernel"]
+        if kname in MAD_PER_VERIFY:
+            mad_s = value / world * MAD_PER_VERIFY[kname]
+            out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,
+                                   "unit": "v_mad_u64_u32 lane-ops/s (per GPU)", "frac": round(mad_s / MAD_PEAK_PER_S, 4),
+                                   "mad_per_verify": MAD_PER_VERIFY[kname]}
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:

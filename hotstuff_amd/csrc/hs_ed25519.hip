@@ -63,10 +63,12 @@ __device__ fe g_btab4[HS_BTAB_ENTRIES][4];        // cached j*B, [j][lane] = (Y-
 
 __global__ void __launch_bounds__(64)
 k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
+    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+    qtab atab; atab.lds = s_atab;
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     bool flags_ok;
-    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_btab4, flags_ok);
+    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_btab4, flags_ok, atab);
     unsigned long long m = __ballot(f.f && flags_ok && active);
     // signature q accepted iff all four lanes of its quad agree; gather bit 4q -> bit q
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
@@ -90,11 +92,13 @@ __global__ void __launch_bounds__(64, 3)
 k_verify_fused(const u32 *__restrict__ digests, u32 digest_stride_words, const u32 *__restrict__ pks,
                const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
                u32 *__restrict__ nreject) {
+    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+    qtab atab; atab.lds = s_atab;
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
     const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, digests + (size_t)digest_stride_words * j,
-                                      mode, g_btab4);
+                                      mode, g_btab4, atab);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
     m = (m | (m >> 3)) & 0x0303030303030303ull;

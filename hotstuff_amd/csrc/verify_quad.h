@@ -77,6 +77,33 @@ HS_Q qflags q_eq(const qv &a, const qv &b_reduced) { qflags r; for (int i = 0; i
 
 HS_HD fe fe_small(u32 c) { fe r; fe_0(r); r.v[0] = c; return r; }
 
+// The per-signature table j*(-A), j = 0..8.  On the GPU it lives in LDS, one 23 KB slab per
+// wavefront laid out [entry][limb][lane]: whatever entry each quad picks, the 32 lanes of a
+// half-wave hit 32 different banks (bank = lane mod 32), so lookups are conflict-free - and
+// the table never touches HBM (in private memory it was 368 B x 4 lanes of write-back traffic
+// per signature, profiles/r1_pmc_traffic.json).
+#define HS_QTAB_ENTRIES 9
+#if defined(__HIPCC__)
+#define HS_QTAB_WORDS (HS_QTAB_ENTRIES * 10 * 64)
+struct qtab { u32 *lds; };      // this wavefront's slab
+HS_Q void qtab_store(const qtab &t, int j, const qv &e) {
+    u32 *p = t.lds + (size_t)j * 640 + (threadIdx.x & 63u);
+#pragma unroll
+    for (int i = 0; i < 10; i++) p[i * 64] = e.v[i];
+}
+HS_Q qv qtab_load(const qtab &t, int j) {
+    const u32 *p = t.lds + (size_t)j * 640 + (threadIdx.x & 63u);
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = p[i * 64];
+    return r;
+}
+#else
+struct qtab { qv e[HS_QTAB_ENTRIES]; };
+HS_Q void qtab_store(qtab &t, int j, const qv &e) { t.e[j] = e; }
+HS_Q qv qtab_load(const qtab &t, int j) { return t.e[j]; }
+#endif
+
 // (X, Y, Z, T) -> (Y-X, Y+X, T, Z): the left operands of an addition's first round
 HS_Q qv q_add_lhs(const qv &p) {
     const qv u = q_perm<1, 1, 3, 2>(p);               // (Y, Y, T, Z)
@@ -128,20 +155,20 @@ HS_Q qv q_dbl(const qv &p) {
 // Returns, per lane, whether this lane's coordinate check passed (lanes 2, 3: always true);
 // the caller ANDs the four lanes of the quad with the signature-level flags.
 HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, u32 kw[8], u32 sw[8],
-                             const fe (*btab)[4]) {
+                             const fe (*btab)[4], qtab &atab) {
     // -A = (-x, y, 1, -xy): one vector multiplication (-x, y, 1, -x) * (1, 1, 1, y)
     fe nax; fe_neg(nax, ax);
     qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
 
-    qv atab[9];                                       // j * (-A), cached, j = 0..8
-    atab[0] = q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2));
-    atab[1] = q_to_cached(p);
+    // j * (-A), cached, j = 0..8
+    qtab_store(atab, 0, q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2)));
     {
-        const qv a1 = atab[1];
+        const qv a1 = q_to_cached(p);
+        qtab_store(atab, 1, a1);
 #pragma nounroll
         for (int j = 2; j <= 8; j++) {
             p = q_add_cached(p, a1);
-            atab[j] = q_to_cached(p);
+            qtab_store(atab, j, q_to_cached(p));
         }
     }
 
@@ -152,7 +179,7 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
         for (int d = 0; d < 4; d++) acc = q_dbl(acc);
         const int dk = sc_pop_digit(kw);
         const int ik = dk < 0 ? -dk : dk;
-        const qv ea = atab[ik];
+        const qv ea = qtab_load(atab, ik);
         acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
         if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
             const int ds = sc_pop_digit8(sw);
@@ -169,7 +196,7 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
 }
 
 // stage 2 reading the workspace written by k_prepare
-HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok) {
+HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok, qtab &atab) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
     bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
@@ -186,7 +213,7 @@ HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4
     u32 kw[8], sw[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
-    return verify_quad_core(ax, ay, rx, ry, kw, sw, btab);
+    return verify_quad_core(ax, ay, rx, ry, kw, sw, btab, atab);
 }
 
 // The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
@@ -208,7 +235,7 @@ HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, 
 // Fused stage 1 + stage 2 for one quad: lane 1 decompresses R, the other lanes decompress A
 // (one shared instruction stream), everybody hashes, DPP broadcasts hand A to the whole
 // quad, then the core.  One launch per batch and no workspace traffic.
-HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const fe (*btab)[4]) {
+HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const fe (*btab)[4], qtab &atab) {
     const u32 lane = q_lane();
     u32 enc[8];
 #pragma unroll
@@ -224,7 +251,7 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, btab);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, btab, atab);
     return f.f && ok;
 }
 #endif

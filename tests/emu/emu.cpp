@@ -87,7 +87,7 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
         prepare_point(ws, (u32)i, is_r, pk, sig, msg, mode);
     }
     for (size_t i = 0; i < n; i++) {
-        bool fl; qflags f = verify_quad(ws, (u32)i, mode, btab, fl);
+        bool fl; qtab atab; qflags f = verify_quad(ws, (u32)i, mode, btab, fl, atab);
         out[i] = (fl && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
     }
 }
