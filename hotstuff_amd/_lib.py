@@ -62,6 +62,8 @@ def lib():
                 l.hs_ed25519_ctx_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
                 l.hs_ed25519_ctx_kernel_times.restype = ctypes.c_int
+                l.hs_ed25519_set_kernel.argtypes = [ctypes.c_int]
+                l.hs_ed25519_set_kernel.restype = ctypes.c_int
                 l.hs_ed25519_keyset_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz]
                 l.hs_ed25519_keyset_create.restype = ctypes.c_int
                 l.hs_ed25519_keyset_destroy.argtypes = [vp]
@@ -102,6 +104,14 @@ def init(device=None, max_batch=8192):
 def ensure_init():
     if not _inited:
         init()
+
+
+KERNEL_AUTO, KERNEL_LANE, KERNEL_QUAD, KERNEL_FUSED = 0, 1, 2, 3
+
+
+def set_kernel(which):
+    """hs_ed25519_set_kernel: choose the cold-path kernel variant; returns the previous one."""
+    return lib().hs_ed25519_set_kernel(int(which))
 
 
 def _buf(b):

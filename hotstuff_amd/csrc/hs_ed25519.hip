@@ -321,6 +321,13 @@ extern "C" void hs_ed25519_shutdown(void) {
     g_free.clear(); g_live = 0; g_init = false;
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
+// 0 = choose by batch size (default), 1 = k_prepare + k_verify, 2 = k_prepare + k_verify_quad,
+// 3 = k_verify_fused.  For tests and A/B measurements; returns the previous setting.
+extern "C" int hs_ed25519_set_kernel(int which) {
+    const int old = g_kernel;
+    if (which >= 0 && which <= 3) g_kernel = which;
+    return old;
+}
 extern "C" const char *hs_ed25519_dominant_kernel(void) {
     return g_kernel == 1 ? "k_verify" : (g_kernel == 2 ? "k_verify_quad" : "k_verify_fused");
 }

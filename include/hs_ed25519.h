@@ -135,6 +135,13 @@ int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots);
 int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
                                 size_t *launches);
 
+/* Cold-path kernel choice: 0 = by batch size (default: fused 4-lanes-per-signature kernel up to
+ * 16,384 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
+ * 2 = two kernels with the quad stage 2, 3 = fused.  All variants have the same accept set; this
+ * exists for tests and A/B measurements (env HS_ED25519_KERNEL=lane|quad|fused sets it at init).
+ * Returns the previous setting. */
+int hs_ed25519_set_kernel(int which);
+
 /* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
 const char *hs_ed25519_dominant_kernel(void);
 

@@ -238,3 +238,88 @@ def test_single_gpu_sharded_path_over_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED])
+def test_every_kernel_variant_has_the_same_accept_set(oracle, edge_vectors, kernel):
+    """The three cold-path variants (one lane per signature; quad stage 2; fused quad) are
+    selected by batch size in production; force each one over the edge vectors and a corrupted
+    batch so the default test run covers all of them."""
+    old = _lib.set_kernel(kernel)
+    try:
+        n = len(edge_vectors)
+        dg = b"".join(H(v["msg"]) for v in edge_vectors)
+        pk = b"".join(H(v["pk"]) for v in edge_vectors)
+        sg = b"".join(H(v["sig"]) for v in edge_vectors)
+        assert [bool(b) for b in gpu_bits(dg, pk, sg, n, _lib.STRICT, False)] == [v["strict"] for v in edge_vectors]
+        assert [bool(b) for b in gpu_bits(dg, pk, sg, n, _lib.BATCH, False)] == [v["cofactorless"] for v in edge_vectors]
+        n = 333
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+        for mode in (_lib.BATCH, _lib.STRICT):
+            assert gpu_bits(dg, pk, sg, n, mode, True) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+    finally:
+        _lib.set_kernel(old)
+
+
+def test_large_batch_takes_the_two_kernel_path(oracle):
+    """n > 16,384 dispatches k_prepare + k_verify (one lane per signature).  20,000 signatures
+    (6,667 distinct, tiled): oracle on a window, properties on the whole."""
+    base = 6667
+    dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
+    n = 20000
+    pk_t = (pk * 3)[: 32 * n]
+    sg_t = bytearray((sg * 3)[: 64 * n])
+    victims = [1, 6667, 16384, 19999]
+    for v in victims:
+        sg_t[64 * v + 33] ^= 0x08
+    sg_t = bytes(sg_t)
+    ok, bm = _lib.verify_packed(dg, pk_t, sg_t, n, _lib.BATCH, shared=True, want_bitmap=True)
+    b = bits(bm, n)
+    assert not ok and [i for i in range(n) if not b[i]] == victims
+    lo = 16000
+    assert b[lo:lo + 800] == oracle_verify_many(oracle, dg, 0, pk_t[32 * lo:], sg_t[64 * lo:], 800, 0)
+
+
+def test_streamed_rounds_through_the_host_api():
+    """BASELINE config 5 (streamed rounds): QC-sized batches (6,667 signatures, host buffers)
+    issued back to back from several threads; the context pool overlaps pinned H2D, kernels and
+    D2H on separate HIP streams.  Every call's verdict is checked; sustained rate must clear
+    the config's 1 M signatures/s by a wide margin."""
+    import threading
+    import time
+    n = 6667
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    bad_sg = bytearray(sg); bad_sg[64 * 100 + 1] ^= 1; bad_sg = bytes(bad_sg)
+    lib = _lib.lib()
+    bufs = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg, bad_sg)]
+    a = [ctypes.addressof(b) for b in bufs]
+    duration, threads = 1.5, 6
+    counts, errors, lat = [0] * threads, [], [[] for _ in range(threads)]
+
+    def work(k):
+        t_end = time.perf_counter() + duration
+        i = 0
+        while time.perf_counter() < t_end:
+            use_bad = (i % 7 == 3)
+            t0 = time.perf_counter()
+            rc = lib.hs_ed25519_verify_shared(a[0], a[1], a[3] if use_bad else a[2], n, _lib.BATCH, None)
+            lat[k].append(time.perf_counter() - t0)
+            if rc != (0 if use_bad else 1):
+                errors.append((k, i, rc))
+            counts[k] += 1
+            i += 1
+
+    for _ in range(3):
+        assert lib.hs_ed25519_verify_shared(a[0], a[1], a[2], n, _lib.BATCH, None) == 1
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    wall = time.perf_counter() - t0
+    assert not errors, errors[:5]
+    rate = sum(counts) * n / wall
+    allat = sorted(x for l in lat for x in l)
+    print("streamed rounds: %.1f M signatures/s sustained from host memory, %d calls, p50 %.3f ms, p99 %.3f ms"
+          % (rate / 1e6, sum(counts), allat[len(allat) // 2] * 1e3, allat[int(len(allat) * 0.99)] * 1e3))
+    assert rate > 1e6
