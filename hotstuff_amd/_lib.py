@@ -62,6 +62,15 @@ def lib():
                 l.hs_ed25519_ctx_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
                 l.hs_ed25519_ctx_kernel_times.restype = ctypes.c_int
+                u64 = ctypes.c_uint64
+                l.hs_ed25519_verify_tc.argtypes = [u64, vp, vp, vp, sz, vp]
+                l.hs_ed25519_verify_tc.restype = ctypes.c_int
+                l.hs_ed25519_verify_tc_cached.argtypes = [vp, u64, vp, vp, vp, sz, vp]
+                l.hs_ed25519_verify_tc_cached.restype = ctypes.c_int
+                l.hs_ed25519_verify_device_tc.argtypes = [vp, u64, vp, vp, vp, sz, vp, vp, vp]
+                l.hs_ed25519_verify_device_tc.restype = ctypes.c_int
+                l.hs_ed25519_verify_device_tc_cached.argtypes = [vp, vp, u64, vp, vp, vp, sz, vp, vp, vp]
+                l.hs_ed25519_verify_device_tc_cached.restype = ctypes.c_int
                 l.hs_ed25519_set_kernel.argtypes = [ctypes.c_int]
                 l.hs_ed25519_set_kernel.restype = ctypes.c_int
                 l.hs_ed25519_keyset_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz]
@@ -139,6 +148,33 @@ def verify_packed(digests, pks, sigs, n, mode, shared, want_bitmap=False):
                "hs_ed25519_verify")
     del k1, k2, k3
     return rc == 1, (bytes(bm) if bm is not None else None)
+
+
+def verify_tc_packed(round_, hq_rounds, pks, sigs, keyset=None):
+    """hs_ed25519_verify_tc[_cached]: TC::verify with the per-vote digests
+    SHA-512(round || high_qc_round)[..32] built on the device.  Returns (all_ok, bitmap)."""
+    import struct
+    n = len(hq_rounds)
+    if len(sigs) != 64 * n:
+        raise ValueError("packed buffer sizes do not match n=%d" % n)
+    ensure_init()
+    if n == 0:
+        return True, b""
+    bm = (ctypes.c_ubyte * ((n + 7) // 8))()
+    ph, k1 = _buf(struct.pack("<%dQ" % n, *hq_rounds))
+    ps, k2 = _buf(sigs)
+    if keyset is None:
+        if len(pks) != 32 * n:
+            raise ValueError("pks must be n*32 bytes")
+        pp, k3 = _buf(pks)
+        rc = lib().hs_ed25519_verify_tc(int(round_), ph, pp, ps, n, ctypes.cast(bm, ctypes.c_void_p))
+    else:
+        packed, _ = keyset.indices([pks[32 * i:32 * i + 32] for i in range(n)] if isinstance(pks, (bytes, bytearray)) else pks)
+        pp, k3 = _buf(packed)
+        rc = lib().hs_ed25519_verify_tc_cached(keyset.handle, int(round_), ph, pp, ps, n, ctypes.cast(bm, ctypes.c_void_p))
+    check(rc, "hs_ed25519_verify_tc")
+    del k1, k2, k3
+    return rc == 1, bytes(bm)
 
 
 class KeySet:

@@ -30,14 +30,14 @@ __device__ ge_niels g_btab[HS_BTAB_ENTRIES];      // j*B, j = 0..128 (uploaded b
 
 // (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
 __global__ void __launch_bounds__(64, 3)
-k_prepare(workspace ws, const u32 *__restrict__ digests, u32 digest_stride_words,
-          const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode) {
+k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * n) return;
     const bool is_r = t >= n;
     const u32 i = is_r ? t - n : t;
-    prepare_point(ws, i, is_r, pks + (size_t)8 * i, sigs + (size_t)16 * i,
-                  digests + (size_t)digest_stride_words * i, mode);
+    u32 msg[8];
+    if (is_r) load_msg(msg, msgs, i);
+    prepare_point(ws, i, is_r, pks + (size_t)8 * i, sigs + (size_t)16 * i, msg, mode);
 }
 
 __global__ void __launch_bounds__(64)
@@ -89,16 +89,16 @@ k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap
 
 // Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
 __global__ void __launch_bounds__(64, 3)
-k_verify_fused(const u32 *__restrict__ digests, u32 digest_stride_words, const u32 *__restrict__ pks,
-               const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
-               u32 *__restrict__ nreject) {
+k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+               unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
     __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
     qtab atab; atab.lds = s_atab;
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
-    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, digests + (size_t)digest_stride_words * j,
-                                      mode, g_btab4, atab);
+    u32 msg[8];
+    load_msg(msg, msgs, j);
+    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_btab4, atab);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
     m = (m | (m >> 3)) & 0x0303030303030303ull;
@@ -150,8 +150,8 @@ k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u3
 }
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
 __global__ void __launch_bounds__(64, 3)
-k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, const u32 *__restrict__ digests,
-                u32 digest_stride_words, const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                 unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
@@ -160,10 +160,11 @@ k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, const u
     const bool known = ki_raw < nkeys;
     const u32 ki = known ? ki_raw : 0;
     const u32 *sig = sigs + (size_t)16 * j;
-    u32 kw[8], sw[8], renc[8];
+    u32 kw[8], sw[8], renc[8], msg[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) renc[t] = sig[t];
-    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, digests + (size_t)digest_stride_words * j, true);
+    load_msg(msg, msgs, j);
+    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
     const u32 fl = ks.flag[ki];
     ok = ok && known && (fl & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
@@ -334,18 +335,13 @@ extern "C" const char *hs_ed25519_dominant_kernel(void) {
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
-extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
-                                        const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
-                                        uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
-    if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device: null context");
-    if (n == 0) return 0;
-    if (!d_digests || !d_pks || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
-    if (misaligned(d_digests, 16) || misaligned(d_pks, 16) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) ||
-        misaligned(d_nreject, 4))
+// enqueue the cold path over n signatures whose messages come from `msgs`
+static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n,
+                        uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+    if (!d_pks || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
+    if (misaligned(d_pks, 16) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) || misaligned(d_nreject, 4))
         return fail(HS_ED25519_E_ARG, "verify_device: misaligned pointer");
-    if ((digest_stride != 0 && digest_stride != 32) || mode > 1 || n > 0x3fffffffu)
-        return fail(HS_ED25519_E_ARG, "verify_device: bad digest_stride / mode / n");
+    if (mode > 1 || n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device: bad mode / n");
     int rc = ctx_reserve(ctx, n, ctx->staging);
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -354,13 +350,13 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     ws.np = np; ws.pt = ctx->d_ws; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
     const u32 nn = (u32)n;
     hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
-    const u32 *p_dg = (const u32 *)d_digests, *p_pk = (const u32 *)d_pks, *p_sg = (const u32 *)d_sigs;
-    u32 dsw = (u32)(digest_stride / 4), nn_ = nn, mode_ = mode;
+    const u32 *p_pk = (const u32 *)d_pks, *p_sg = (const u32 *)d_sigs;
+    u32 nn_ = nn, mode_ = mode;
     unsigned long long *p_bm = (unsigned long long *)d_bitmap;
     u32 *p_nr = d_nreject;
-    void *a1[] = { &ws, &p_dg, &dsw, &p_pk, &p_sg, &nn_, &mode_ };
+    void *a1[] = { &ws, &msgs, &p_pk, &p_sg, &nn_, &mode_ };
     void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
-    void *a3[] = { &p_dg, &dsw, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
+    void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     const int kern = g_kernel ? g_kernel : (n <= kQuadMaxBatch ? 3 : 1);
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
@@ -375,6 +371,43 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
         HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
     if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
     return 0;
+}
+static int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride) {
+    if (!d_digests) return fail(HS_ED25519_E_ARG, "verify_device: null digests");
+    if (misaligned(d_digests, 16)) return fail(HS_ED25519_E_ARG, "verify_device: misaligned digests");
+    if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "verify_device: bad digest_stride");
+    m.digests = (const u32 *)d_digests; m.stride_words = (u32)(digest_stride / 4); m.hq_rounds = nullptr; m.round = 0;
+    return 0;
+}
+static int make_tc_src(msg_src &m, uint64_t round, const uint64_t *d_hq) {
+    if (!d_hq) return fail(HS_ED25519_E_ARG, "verify_device_tc: null high_qc_rounds");
+    if (misaligned(d_hq, 8)) return fail(HS_ED25519_E_ARG, "verify_device_tc: misaligned high_qc_rounds");
+    m.digests = nullptr; m.stride_words = 0; m.hq_rounds = (const unsigned long long *)d_hq; m.round = round;
+    return 0;
+}
+
+extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
+                                        const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
+                                        uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device: null context");
+    if (n == 0) return 0;
+    msg_src m;
+    int rc = make_digest_src(m, d_digests, digest_stride);
+    if (rc) return rc;
+    return enqueue_cold(ctx, m, d_pks, d_sigs, n, mode, d_bitmap, d_nreject, stream);
+}
+// TC::verify shape with the per-vote digests built on the device (strict semantics)
+extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, const uint64_t *d_high_qc_rounds,
+                                           const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap,
+                                           uint32_t *d_nreject, void *stream) {
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device_tc: null context");
+    if (n == 0) return 0;
+    msg_src m;
+    int rc = make_tc_src(m, round, d_high_qc_rounds);
+    if (rc) return rc;
+    return enqueue_cold(ctx, m, d_pks, d_sigs, n, HS_ED25519_STRICT, d_bitmap, d_nreject, stream);
 }
 
 extern "C" int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots) {
@@ -484,31 +517,48 @@ extern "C" void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks) {
 }
 extern "C" size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks) { return ks ? ks->nkeys : 0; }
 
+static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint32_t *d_key_idx,
+                          const uint8_t *d_sigs, size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+    if (!d_key_idx || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_cached: null pointer");
+    if (misaligned(d_key_idx, 4) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) || misaligned(d_nreject, 4))
+        return fail(HS_ED25519_E_ARG, "verify_device_cached: misaligned pointer");
+    if (mode > 1 || n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device_cached: bad mode / n");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const u32 np = (u32)round_up(n, 64);
+    keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
+    u32 nkeys = (u32)ks->nkeys, nn = (u32)n, mode_ = mode;
+    const u32 *p_bt = g_base_tab, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
+    unsigned short *p_bm = (unsigned short *)d_bitmap;
+    u32 *p_nr = d_nreject;
+    void *a[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
+    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
+    if (ev) { HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord"); }
+    HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
+    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
+    return 0;
+}
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
                                                size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs,
                                                size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
     if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_cached: null context / key set");
     if (n == 0) return 0;
-    if (!d_digests || !d_key_idx || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_cached: null pointer");
-    if (misaligned(d_digests, 16) || misaligned(d_key_idx, 4) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) ||
-        misaligned(d_nreject, 4))
-        return fail(HS_ED25519_E_ARG, "verify_device_cached: misaligned pointer");
-    if ((digest_stride != 0 && digest_stride != 32) || mode > 1 || n > 0x3fffffffu)
-        return fail(HS_ED25519_E_ARG, "verify_device_cached: bad digest_stride / mode / n");
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    const u32 np = (u32)round_up(n, 64);
-    keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
-    u32 nkeys = (u32)ks->nkeys, dsw = (u32)(digest_stride / 4), nn = (u32)n, mode_ = mode;
-    const u32 *p_bt = g_base_tab, *p_dg = (const u32 *)d_digests, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
-    unsigned short *p_bm = (unsigned short *)d_bitmap;
-    u32 *p_nr = d_nreject;
-    void *a[] = { &kv, &nkeys, &p_bt, &p_dg, &dsw, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
-    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
-    if (ev) { HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord"); }
-    HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
-    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
-    return 0;
+    msg_src m;
+    int rc = make_digest_src(m, d_digests, digest_stride);
+    if (rc) return rc;
+    return enqueue_cached(ctx, ks, m, d_key_idx, d_sigs, n, mode, d_bitmap, d_nreject, stream);
+}
+extern "C" int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, uint64_t round,
+                                                  const uint64_t *d_high_qc_rounds, const uint32_t *d_key_idx,
+                                                  const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap, uint32_t *d_nreject,
+                                                  void *stream) {
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_tc_cached: null context / key set");
+    if (n == 0) return 0;
+    msg_src m;
+    int rc = make_tc_src(m, round, d_high_qc_rounds);
+    if (rc) return rc;
+    return enqueue_cached(ctx, ks, m, d_key_idx, d_sigs, n, HS_ED25519_STRICT, d_bitmap, d_nreject, stream);
 }
 
 // ---- host-pointer API ----------------------------------------------------------------------
@@ -616,4 +666,52 @@ extern "C" int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, cons
 extern "C" int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
                                               const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
     return verify_host_cached(ks, digests, 32, key_idx, sigs, n, mode, bitmap);
+}
+
+// TC::verify from host buffers: the per-vote digests SHA-512(round || high_qc_round)[..32]
+// (consensus/src/messages.rs:307-311) are built on the device; strict semantics.
+// ks == NULL: keys by bytes (pks_or_idx = n*32 key bytes); else pks_or_idx = n uint32 indices.
+static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *hq_rounds, const void *pks_or_idx,
+                          const uint8_t *sigs, size_t n, uint8_t *bitmap) {
+    if (n == 0) return g_init ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!hq_rounds || !pks_or_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_tc: null pointer");
+    hs_ed25519_ctx *c = nullptr;
+    int rc = pool_get(&c);
+    if (rc) return rc;
+    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    size_t want = n > g_max_batch ? n : g_max_batch;
+    rc = ctx_reserve(c, want, true);
+    if (rc) return rc;
+    // staging (128 B per signature available): [hq: 8n][keys: 32n or 4n][sigs: 64n]
+    const size_t key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(8 * n, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
+    memcpy(c->h_in, hq_rounds, 8 * n);
+    memcpy(c->h_in + off_k, pks_or_idx, key_bytes);
+    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    const size_t bm = bitmap_bytes(n);
+    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
+    if (ks)
+        rc = hs_ed25519_verify_device_tc_cached(c, ks, round, (const uint64_t *)c->d_in, (const uint32_t *)(c->d_in + off_k),
+                                                c->d_in + off_sig, n, c->d_out, (uint32_t *)(c->d_out + bm), c->stream);
+    else
+        rc = hs_ed25519_verify_device_tc(c, round, (const uint64_t *)c->d_in, c->d_in + off_k, c->d_in + off_sig, n, c->d_out,
+                                         (uint32_t *)(c->d_out + bm), c->stream);
+    if (rc) return rc;
+    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    uint32_t nrej;
+    memcpy(&nrej, c->h_out + bm, 4);
+    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
+    return nrej == 0 ? 1 : 0;
+}
+extern "C" int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const uint8_t *pks, const uint8_t *sigs,
+                                    size_t n, uint8_t *bitmap) {
+    return verify_host_tc(nullptr, round, high_qc_rounds, pks, sigs, n, bitmap);
+}
+extern "C" int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *high_qc_rounds,
+                                           const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint8_t *bitmap) {
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify_tc_cached: null key set");
+    return verify_host_tc(ks, round, high_qc_rounds, key_idx, sigs, n, bitmap);
 }

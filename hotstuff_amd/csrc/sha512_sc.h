@@ -23,14 +23,9 @@ HS_TABLE u64 SHA512_K[80] = HS_SHA512_K_INIT;
 HS_HD u64 ror64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
 HS_HD u32 bswap32(u32 x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
 
-// in: 24 little-endian words (R, A, M).  out: the 64-byte digest as a
-// little-endian 512-bit integer in 16 words.
-HS_HD void sha512_96(u32 out[16], const u32 in[24]) {
+// one SHA-512 compression of a single padded block w[16] from the initial state
+HS_HD void sha512_oneblock(u64 hh[8], u64 w[16]) {
     const u64 H0[8] = HS_SHA512_H0_INIT;
-    u64 w[16];
-#pragma unroll
-    for (int i = 0; i < 12; i++) w[i] = ((u64)bswap32(in[2 * i]) << 32) | bswap32(in[2 * i + 1]);
-    w[12] = 0x8000000000000000ull; w[13] = 0; w[14] = 0; w[15] = 96 * 8;
     u64 a = H0[0], b = H0[1], c = H0[2], d = H0[3], e = H0[4], f = H0[5], g = H0[6], h = H0[7];
 #pragma nounroll
     for (int r = 0; r < 80; r += 16) {
@@ -51,11 +46,57 @@ HS_HD void sha512_96(u32 out[16], const u32 in[24]) {
             h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
     }
-    const u64 hh[8] = { a + H0[0], b + H0[1], c + H0[2], d + H0[3], e + H0[4], f + H0[5], g + H0[6], h + H0[7] };
+    hh[0] = a + H0[0]; hh[1] = b + H0[1]; hh[2] = c + H0[2]; hh[3] = d + H0[3];
+    hh[4] = e + H0[4]; hh[5] = f + H0[5]; hh[6] = g + H0[6]; hh[7] = h + H0[7];
+}
+
+// in: 24 little-endian words (R, A, M).  out: the 64-byte digest as a
+// little-endian 512-bit integer in 16 words.
+HS_HD void sha512_96(u32 out[16], const u32 in[24]) {
+    u64 w[16], hh[8];
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = ((u64)bswap32(in[2 * i]) << 32) | bswap32(in[2 * i + 1]);
+    w[12] = 0x8000000000000000ull; w[13] = 0; w[14] = 0; w[15] = 96 * 8;
+    sha512_oneblock(hh, w);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         out[2 * i] = bswap32((u32)(hh[i] >> 32));
         out[2 * i + 1] = bswap32((u32)hh[i]);
+    }
+}
+
+// TC::verify's per-vote digest, consensus/src/messages.rs:307-311:
+//   SHA-512(round.to_le_bytes() || high_qc_round.to_le_bytes())[..32]   as 8 little-endian words
+HS_HD u64 bswap64(u64 x) { return ((u64)bswap32((u32)x) << 32) | bswap32((u32)(x >> 32)); }
+HS_HD void tc_vote_digest(u32 out[8], u64 round, u64 high_qc_round) {
+    u64 w[16], hh[8];
+    w[0] = bswap64(round); w[1] = bswap64(high_qc_round); w[2] = 0x8000000000000000ull;
+#pragma unroll
+    for (int i = 3; i < 15; i++) w[i] = 0;
+    w[15] = 16 * 8;
+    sha512_oneblock(hh, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[2 * i] = bswap32((u32)(hh[i] >> 32));
+        out[2 * i + 1] = bswap32((u32)hh[i]);
+    }
+}
+
+// Where signature j's 32-byte message comes from: packed digests (stride 0 = one shared digest)
+// or, for a timeout certificate, derived on the device from (round, high_qc_round_j).
+struct msg_src {
+    const u32 *digests;
+    u32 stride_words;
+    const unsigned long long *hq_rounds;     // non-null: TC mode
+    unsigned long long round;
+};
+HS_HD void load_msg(u32 msg[8], const msg_src &m, u32 j) {
+    if (m.hq_rounds) {
+        tc_vote_digest(msg, m.round, m.hq_rounds[j]);
+    } else {
+        const u32 *p = m.digests + (size_t)m.stride_words * j;
+#pragma unroll
+        for (int t = 0; t < 8; t++) msg[t] = p[t];
     }
 }
 

@@ -130,13 +130,23 @@ class TC:
         return Digest(h.digest()[:32])
 
     def verify(self, committee):
+        """messages.rs:290-315.  The reference hashes every vote's digest on the host and calls
+        Signature::verify n times; here (round, high_qc_rounds) go to the engine, which builds
+        the digests on the device and verifies all votes in one call (strict semantics)."""
+        from . import _lib
         _check_quorum((name for name, _, _ in self.votes), committee, TCRequiresQuorum)
-        digests = [self.vote_digest(r) for _, _, r in self.votes]
+        if not self.votes:
+            return
+        ks = committee.keyset
+        if ks is not None and not all(a.b in ks.index for a, _, _ in self.votes):
+            ks = None
         try:
-            oks = Signature.verify_many(digests, [(a, s) for a, s, _ in self.votes], keyset=committee.keyset)
-        except CryptoError as e:
+            ok, _ = _lib.verify_tc_packed(self.round, [r for _, _, r in self.votes],
+                                          b"".join(a.b for a, _, _ in self.votes),
+                                          b"".join(s.flatten() for _, s, _ in self.votes), keyset=ks)
+        except _lib.EngineError as e:
             raise InvalidSignature() from e
-        if not all(oks):
+        if not ok:
             raise InvalidSignature()
 
     def high_qc_rounds(self):

@@ -127,6 +127,24 @@ int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset
                                     size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n,
                                     uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
 
+/* ---- TC::verify with the per-vote digests built on the device ------------------------------
+ * consensus/src/messages.rs:307-313 hashes SHA-512(round_le || high_qc_round_le)[..32] on the
+ * host for every vote before each Signature::verify; these entry points take the certificate's
+ * round and the n high_qc_round values (uint64, host order) and hash on the GPU, so a timeout
+ * certificate costs one call and no host hashing.  Strict semantics; return values, bitmap and
+ * alignment rules as above (high_qc_rounds: 8-byte aligned on the device form). */
+int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const uint8_t *pks, const uint8_t *sigs,
+                         size_t n, uint8_t *bitmap);
+int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *high_qc_rounds,
+                                const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint8_t *bitmap);
+int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, const uint64_t *d_high_qc_rounds,
+                                const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap,
+                                uint32_t *d_nreject, void *stream);
+int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, uint64_t round,
+                                       const uint64_t *d_high_qc_rounds, const uint32_t *d_key_idx,
+                                       const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap, uint32_t *d_nreject,
+                                       void *stream);
+
 /* Profiling: keep a ring of `slots` HIP-event triples recorded on the launch stream around
  * the two kernels of each hs_ed25519_verify_device call on `ctx` (0 = off).  After the
  * stream has been synchronised, hs_ed25519_ctx_kernel_times returns the summed durations

@@ -38,6 +38,7 @@ void emu_fe_roundtrip(const uint8_t *a, uint8_t *r) {
     u32 wa[8], wr[8]; load_words(wa, a, 8); fe x; fe_from_words(x, wa); fe_to_words(wr, x); memcpy(r, wr, 32);
 }
 void emu_sha512_96(const uint8_t *in, uint8_t *out) { u32 wi[24], wo[16]; load_words(wi, in, 24); sha512_96(wo, wi); memcpy(out, wo, 64); }
+void emu_tc_vote_digest(uint64_t round, uint64_t hq, uint8_t *out) { u32 w[8]; tc_vote_digest(w, round, hq); memcpy(out, w, 32); }
 void emu_sc_reduce512(const uint8_t *in, uint8_t *out) { u32 wi[16], wo[8]; load_words(wi, in, 16); sc_reduce512(wo, wi); memcpy(out, wo, 32); }
 void emu_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { u32 wa[8], wb[8], wo[8]; load_words(wa, a, 8); load_words(wb, b, 8); sc_mul(wo, wa, wb); memcpy(out, wo, 32); }
 int emu_sc_is_canonical(const uint8_t *s) { u32 w[8]; load_words(w, s, 8); return sc_is_canonical(w); }

@@ -76,6 +76,15 @@ def test_sha512_and_scalars(emu):
         assert v == s
 
 
+def test_tc_vote_digest_on_device_matches_messages_rs(emu):
+    """consensus/src/messages.rs:307-311: SHA-512(round_le || high_qc_round_le)[..32]."""
+    import struct
+    o = B(32)
+    for rnd, hq in [(0, 0), (1, 0), (9, 3), (2 ** 64 - 1, 2 ** 63), (123456789012345, 987654321)]:
+        emu.emu_tc_vote_digest(ctypes.c_uint64(rnd), ctypes.c_uint64(hq), o)
+        assert o.raw == hashlib.sha512(struct.pack("<QQ", rnd, hq)).digest()[:32]
+
+
 def test_radix256_recoding(emu):
     rnd = random.Random(13)
     dg = (ctypes.c_int16 * 32)()

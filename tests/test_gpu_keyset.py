@@ -148,3 +148,37 @@ def test_device_resident_cached_api(oracle):
     got = bits(bytes(d_bm.cpu().tolist()), n)
     assert [i for i in range(n) if not got[i]] == [5, 700] and int(d_nr.item()) == 2
     ctx.close(); ks.close()
+
+
+def test_tc_digests_built_on_device_cold_and_cached(oracle):
+    """hs_ed25519_verify_tc[_cached]: (round, high_qc_round_i) in, verdicts equal to hashing on
+    the host (messages.rs:307-311) + strict verification by the oracle."""
+    import hashlib
+    import struct
+    n, rnd = 400, 77
+    hq = [(i * 7919) % 60 for i in range(n)]
+    digests = [hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq]
+    pks, sigs = bytearray(), bytearray()
+    for i in range(n):
+        p, s = synth.sign(synth.key_seed(i), digests[i])
+        pks += p; sigs += s
+    bad = [3, 64, 399]
+    sigs[64 * 3 + 5] ^= 1                    # corrupted signature
+    hq[64] += 1                               # vote claims another high_qc_round than it signed
+    sigs[64 * 399 + 40] ^= 0x80
+    dg = b"".join(hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq)
+    expect = oracle_verify_many(oracle, dg, 32, bytes(pks), bytes(sigs), n, 1)
+    assert [i for i in range(n) if not expect[i]] == bad
+    ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs))
+    assert not ok and bits(bm, n) == expect
+    ks = _lib.KeySet([bytes(pks[32 * i:32 * i + 32]) for i in range(n)])
+    ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs), keyset=ks)
+    assert not ok and bits(bm, n) == expect
+    # the >16,384 two-kernel path hashes in k_prepare
+    old = _lib.set_kernel(_lib.KERNEL_LANE)
+    try:
+        ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs))
+        assert not ok and bits(bm, n) == expect
+    finally:
+        _lib.set_kernel(old)
+    ks.close()
