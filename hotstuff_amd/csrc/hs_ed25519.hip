@@ -13,6 +13,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 #include <vector>
@@ -139,13 +140,11 @@ __global__ void __launch_bounds__(64)
 k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u32 nkeys_pad, u32 negate) {
     const u32 g = blockIdx.x * 16 + (threadIdx.x >> 2);
     const u32 w = g / nkeys_pad, k = g % nkeys_pad;
-    const bool active = k < nkeys;
-    const u32 kk = active ? k : nkeys - 1;
+    if (k >= nkeys) return;     // whole quads leave together; DPP quad_perm never crosses a quad
     fe ax, ay;
 #pragma unroll
-    for (int j = 0; j < 10; j++) { ax.v[j] = axy[(size_t)20 * kk + j]; ay.v[j] = axy[(size_t)20 * kk + 10 + j]; }
-    // inactive tail quads rebuild the last key's window into the same place (identical values)
-    keyset_build_window(tab + (size_t)kk * HS_KS_KEY_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
+    for (int j = 0; j < 10; j++) { ax.v[j] = axy[(size_t)20 * k + j]; ay.v[j] = axy[(size_t)20 * k + 10 + j]; }
+    keyset_build_window(tab + (size_t)k * HS_KS_KEY_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
                         ax, ay, negate != 0, (int)w);
 }
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
@@ -220,7 +219,8 @@ static size_t g_max_batch = 0;
 static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
-static int g_kernel = 0;            // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
+static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own window table
+static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
 static const size_t kQuadMaxBatch = 16384;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -311,7 +311,7 @@ extern "C" int hs_ed25519_init(int device, size_t max_batch) {
     make_base_table_quad(tab4, HS_BTAB_ENTRIES);
     HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
     if (const char *k = getenv("HS_ED25519_KERNEL"))
-        g_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : 0));
+        g_kernel.store(!strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : 0)));
     HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
     return 0;
@@ -320,17 +320,19 @@ extern "C" void hs_ed25519_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (hs_ed25519_ctx *c : g_free) hs_ed25519_ctx_destroy(c);
     g_free.clear(); g_live = 0; g_init = false;
+    if (g_base_tab) { (void)hipFree(g_base_tab); g_base_tab = nullptr; }
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
 // 0 = choose by batch size (default), 1 = k_prepare + k_verify, 2 = k_prepare + k_verify_quad,
 // 3 = k_verify_fused.  For tests and A/B measurements; returns the previous setting.
 extern "C" int hs_ed25519_set_kernel(int which) {
-    const int old = g_kernel;
-    if (which >= 0 && which <= 3) g_kernel = which;
+    const int old = g_kernel.load();
+    if (which >= 0 && which <= 3) g_kernel.store(which);
     return old;
 }
 extern "C" const char *hs_ed25519_dominant_kernel(void) {
-    return g_kernel == 1 ? "k_verify" : (g_kernel == 2 ? "k_verify_quad" : "k_verify_fused");
+    const int k = g_kernel.load();
+    return k == 1 ? "k_verify" : (k == 2 ? "k_verify_quad" : "k_verify_fused");
 }
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
@@ -358,7 +360,8 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
     void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
-    const int kern = g_kernel ? g_kernel : (n <= kQuadMaxBatch ? 3 : 1);
+    const int forced = g_kernel.load();
+    const int kern = forced ? forced : (n <= kQuadMaxBatch ? 3 : 1);
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
     if (kern != 3)
         HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
@@ -442,7 +445,6 @@ struct hs_ed25519_keyset {
     size_t nkeys = 0;
     u32 *d_tab = nullptr, *d_pk = nullptr, *d_flag = nullptr;
 };
-static u32 *g_base_tab = nullptr;       // the base point's own window table (same layout)
 
 static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate, hipStream_t st) {
     const u32 nk = (u32)nkeys, pad = (u32)round_up(nkeys, 16), neg = negate ? 1u : 0u;

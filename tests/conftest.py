@@ -55,6 +55,11 @@ def edge_vectors():
     return json.load(open(os.path.join(GOLDEN, "edge_vectors.json")))["vectors"]
 
 
+@pytest.fixture(scope="session")
+def torsion_fuzz():
+    return json.load(open(os.path.join(GOLDEN, "torsion_fuzz.json")))["vectors"]
+
+
 def oracle_verify_many(orc, digests, stride, pks, sigs, n, mode):
     out = ctypes.create_string_buffer(max(1, n))
     orc.hs_oracle_verify_many(digests, S(32), S(stride), pks, sigs, S(n), mode, out, 1)

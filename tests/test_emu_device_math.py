@@ -186,3 +186,27 @@ def test_cached_path_vs_c_oracle_random(emu, oracle):
     # an index outside the key set rejects that signature only
     got = _emu_cached(emu, pk, [0, 1, 99] + list(range(3, n)), dg, 0, sg, n, 0)
     assert not got[2] and got[:2] == oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)[:2]
+
+
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad"])
+def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
+    vec = torsion_fuzz
+    n = len(vec)
+    msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)
+    pks = b"".join(bytes.fromhex(v["pk"]) for v in vec)
+    sigs = b"".join(bytes.fromhex(v["sig"]) for v in vec)
+    out = B(n)
+    getattr(emu, fn)(msgs, S(32), pks, sigs, S(n), 1, out)
+    assert [bool(b) for b in out.raw] == [v["strict"] for v in vec]
+    getattr(emu, fn)(msgs, S(32), pks, sigs, S(n), 0, out)
+    assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in vec]
+
+
+def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz):
+    vec = torsion_fuzz[:40]
+    n = len(vec)
+    msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)
+    pks = b"".join(bytes.fromhex(v["pk"]) for v in vec)
+    sigs = b"".join(bytes.fromhex(v["sig"]) for v in vec)
+    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1)] == [v["strict"] for v in vec]
+    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0)] == [v["cofactorless"] for v in vec]

@@ -182,3 +182,30 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     finally:
         _lib.set_kernel(old)
     ks.close()
+
+
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED, "cached"])
+def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
+    """160 randomized torsion-mix signatures labelled by the big-int oracle, through every
+    cold kernel variant and the key-cache path, both modes."""
+    vec = torsion_fuzz
+    n = len(vec)
+    dg = b"".join(H(v["msg"]) for v in vec)
+    keys = [H(v["pk"]) for v in vec]
+    sg = b"".join(H(v["sig"]) for v in vec)
+    if kernel == "cached":
+        ks = _lib.KeySet(keys)
+        strict = cached_bits(ks, dg, keys, sg, n, _lib.STRICT, False)
+        batch = cached_bits(ks, dg, keys, sg, n, _lib.BATCH, False)
+        ks.close()
+    else:
+        old = _lib.set_kernel(kernel)
+        try:
+            _, bm = _lib.verify_packed(dg, b"".join(keys), sg, n, _lib.STRICT, shared=False, want_bitmap=True)
+            strict = bits(bm, n)
+            _, bm = _lib.verify_packed(dg, b"".join(keys), sg, n, _lib.BATCH, shared=False, want_bitmap=True)
+            batch = bits(bm, n)
+        finally:
+            _lib.set_kernel(old)
+    assert [bool(b) for b in strict] == [v["strict"] for v in vec]
+    assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]

@@ -113,3 +113,16 @@ def test_batch_sizes_straus_pippenger_switch(oracle):
         if n:
             bad = bytearray(sg[:64 * n]); bad[64 * (n - 1) + 40] ^= 2
             assert oracle.hs_oracle_verify_batch(dg, S(32), S(0), pk, bytes(bad), S(n), ctypes.c_uint64(n)) == 0
+
+
+def test_torsion_fuzz_c_oracle_matches_bigint(oracle, torsion_fuzz):
+    """160 randomized torsion-mix signatures (tests/golden/gen_torsion_fuzz.py)."""
+    n = len(torsion_fuzz)
+    msgs = b"".join(H(v["msg"]) for v in torsion_fuzz)
+    pks = b"".join(H(v["pk"]) for v in torsion_fuzz)
+    sigs = b"".join(H(v["sig"]) for v in torsion_fuzz)
+    strict = oracle_verify_many(oracle, msgs, 32, pks, sigs, n, 1)
+    cl = oracle_verify_many(oracle, msgs, 32, pks, sigs, n, 0)
+    assert [bool(b) for b in strict] == [v["strict"] for v in torsion_fuzz]
+    assert [bool(b) for b in cl] == [v["cofactorless"] for v in torsion_fuzz]
+    assert sum(v["cofactored"] and not v["cofactorless"] for v in torsion_fuzz) > 30    # class iii is well covered
