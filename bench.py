@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
     ap.add_argument("--no-cached", action="store_true", help="skip the committee-key-cache extra")
+    ap.add_argument("--large-committee", type=int, default=100000, help="validators in the cached large-QC extra")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "16")),
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams)")
@@ -340,6 +341,45 @@ def main():
                   "table_bytes_read_per_verify": 64 * 160,
                   "note": "keys pre-registered (static committee); not comparable with `value`, which is the cold path"}
         ks.close()
+        # large committee, one launch (BASELINE configs[3] on ONE GPU): N = 100,000 validators (66 GB of
+        # tables - sized for 288 GB of HBM), QC of 66,667 votes
+        # by distinct keys -> the one-lane-per-signature cached kernel; its table gather is the one
+        # place on this path where HBM bandwidth is a meaningful roofline
+        try:
+            Nv = args.large_committee
+            nl = 2 * Nv // 3 + 1
+            ldg, lpk, lsg = synth.make_batch(nl, shared=True, cache_dir="/tmp/hs_synth")
+            lks = _lib.KeySet([lpk[32 * i:32 * i + 32] for i in range(nl)]
+                              + [synth.key_seed(300_000_000 + i) for i in range(Nv - nl)])
+            l_dg, l_sg = t(ldg), t(lsg)
+            l_ki = torch.arange(nl, dtype=torch.int32, device=dev)
+            l_bm = torch.zeros(8 * ((nl + 63) // 64), dtype=torch.uint8, device=dev)
+            l_nr = torch.zeros(1, dtype=torch.int32, device=dev)
+            lctx = _lib.DeviceContext(nl)
+            lst = torch.cuda.ExternalStream(lctx.stream, device=dev)
+            reps = 30
+            lctx.set_profiling(reps)
+            for i in range(reps + 3):
+                if i == 3:
+                    lst.synchronize(); l_nr.zero_(); torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                lctx.verify_cached(lks, l_dg.data_ptr(), 0, l_ki.data_ptr(), l_sg.data_ptr(), nl, _lib.BATCH,
+                                   l_bm.data_ptr(), l_nr.data_ptr(), lctx.stream)
+            lst.synchronize()
+            l_el = time.perf_counter() - t0
+            assert int(l_nr.item()) == 0
+            lk_ms = lctx.kernel_times()[1] / max(1, lctx.kernel_times()[2])
+            gather = 32 * 160 * nl                      # bytes of the keys' tables read per launch
+            cached["large_committee"] = {
+                "n_validators": Nv, "signatures": nl, "keyset_hbm_bytes": lks.hbm_bytes(),
+                "kernel": "k_verify_cached_lane", "avg_kernel_ms": round(lk_ms, 4),
+                "value": round(nl * reps / l_el, 1), "unit": "verifies/s",
+                "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "algorithmic_bytes_per_launch": gather,
+                             "note": "32 table entries x 160 B per verification gathered from the key set"}}
+            lctx.close(); lks.close()
+        except Exception as e:        # never let the extra break the headline
+            cached["large_committee"] = {"error": str(e)}
 
     traffic = None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)

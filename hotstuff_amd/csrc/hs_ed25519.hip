@@ -185,6 +185,38 @@ k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src
     }
 }
 
+// the throughput form: one lane per signature (verify_cached_lane), for large batches
+__global__ void __launch_bounds__(64)
+k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                     const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject) {
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const u32 ki_raw = key_idx[j];
+    const bool known = ki_raw < nkeys;
+    const u32 ki = known ? ki_raw : 0;
+    const u32 *sig = sigs + (size_t)16 * j;
+    u32 kw[8], sw[8], renc[8], msg[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) renc[t] = sig[t];
+    load_msg(msg, msgs, j);
+    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+    const u32 fl = ks.flag[ki];
+    ok = ok && known && (fl & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
+    const bool curve = verify_cached_lane(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
+    const unsigned long long mask = __ballot(ok && curve && active);
+    if (threadIdx.x == 0) {
+        bitmap[blockIdx.x] = mask;
+        if (nreject) {
+            const u32 lanes = min(64u, n - blockIdx.x * 64);
+            const u32 bad = lanes - (u32)__popcll(mask);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
@@ -220,6 +252,7 @@ static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
 static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own window table
+static const size_t kCachedLaneMin = 16384; // cached path: quad kernel up to here, one lane per signature above
 static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
 static const size_t kQuadMaxBatch = 16384;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
@@ -535,7 +568,13 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     void *a[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
     hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
     if (ev) { HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord"); }
-    HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
+    // four lanes per signature for latency, one lane per signature once the chip is full
+    const int forced = g_kernel.load();
+    const bool lane_form = forced ? forced == 1 : n > kCachedLaneMin;
+    if (lane_form)
+        HS_HIP(hipLaunchKernel((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, 0, st), "launch k_verify_cached_lane");
+    else
+        HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
     if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
     return 0;
 }

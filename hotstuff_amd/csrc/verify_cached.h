@@ -149,4 +149,71 @@ HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw
     return ok && q_quad_and01(q_match_encoding(aff, renc));
 }
 
+// ---- one lane per signature (throughput form, large batches) -------------------------------
+// Same tables, read whole (40 words = 160 contiguous bytes per lookup and lane).  Per signature:
+// 64 serial table additions (8 field multiplications each) + one inversion, against 4x-replicated
+// work in the quad form - ~780 field multiplications per verification.
+struct tab_entry { fe ymx, ypx, t2d, z2; };      // (Y-X, Y+X, 2dT, 2Z) as stored
+
+HS_HD void load_tab_entry(tab_entry &e, const u32 *p) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#else
+    const u32 *w = p;
+#endif
+#pragma unroll
+    for (int i = 0; i < 10; i++) { e.ymx.v[i] = w[i]; e.ypx.v[i] = w[10 + i]; e.t2d.v[i] = w[20 + i]; e.z2.v[i] = w[30 + i]; }
+}
+// r = p +- e  (extended += stored cached entry); 8 multiplications, result reduced
+HS_HD void ge_add_tab(ge_p3 &r, const ge_p3 &p, const tab_entry &e, bool neg) {
+    fe qa, qb, a, b, c, d, t;
+    fe_select(qa, e.ymx, e.ypx, neg);
+    fe_select(qb, e.ypx, e.ymx, neg);
+    fe_sub(t, p.Y, p.X); fe_mul(a, t, qa);        // A = (Y1-X1)(Y2-+X2)
+    fe_add(t, p.Y, p.X); fe_mul(b, t, qb);        // B = (Y1+X1)(Y2+-X2)
+    fe_mul(c, p.T, e.t2d);                        // C = T1 2dT2
+    fe_mul(d, p.Z, e.z2);                         // D = Z1 2Z2
+    fe E, H, zs, zd, F, G;
+    fe_sub(E, b, a);                              // 3x
+    fe_add(H, b, a);                              // 2x
+    fe_add(zs, d, c);                             // 2x
+    fe_sub(zd, d, c);                             // 3x
+    fe_select(F, zd, zs, neg);                    // F = D -+ C
+    fe_select(G, zs, zd, neg);                    // G = D +- C
+    fe_mul(r.X, E, F); fe_mul(r.Y, G, H); fe_mul(r.Z, F, G); fe_mul(r.T, E, H);
+}
+// The curve part of one cached verification on ONE lane.  Returns accept.
+HS_HD bool verify_cached_lane(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+    ge_p3 acc;
+    ge_identity(acc);
+#pragma nounroll
+    for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
+        const int dk = sc_pop_digit8(kw), ds = sc_pop_digit8(sw);
+        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        tab_entry e;
+        load_tab_entry(e, atab + ((size_t)w * HS_KS_ENTRIES + ik) * HS_KS_ENTRY_WORDS);
+        ge_add_tab(acc, acc, e, dk < 0);
+        load_tab_entry(e, btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
+        ge_add_tab(acc, acc, e, ds < 0);
+    }
+    bool ok = true;
+    if (strict) ok = !ge_is_small_order(acc);      // [8]R' == O ?  (R' == R whenever accepted)
+    fe zi, x, y;
+    fe_invert(zi, acc.Z);
+    fe_mul(x, acc.X, zi);
+    fe_mul(y, acc.Y, zi);
+    u32 xw[8], yw[8], ew[8];
+    fe_to_words(xw, x);
+    fe_to_words(yw, y);
+    fe ye; fe_from_words(ye, renc);
+    fe_to_words(ew, ye);
+    u32 dy = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { dy |= yw[i] ^ ew[i]; nz |= xw[i]; }
+    return ok && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0);
+}
+
 }  // namespace hs

@@ -112,6 +112,9 @@ void emu_keyset_build_base(uint32_t *tab) {
     for (int win = 0; win < HS_KS_WINDOWS; win++)
         keyset_build_window(tab + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS, b.X, b.Y, false, win);
 }
+// lane_form = 1: the one-lane-per-signature core (verify_cached_lane), 0: the quad core
+static int g_cached_lane_form = 0;
+void emu_cached_set_lane_form(int v) { g_cached_lane_form = v; }
 void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys, const uint32_t *btab,
                        const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
                        uint32_t mode, uint8_t *out) {
@@ -124,7 +127,10 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
         const u32 fl = flag[ki];
         ok = ok && (fl & HS_F_ONCURVE);
         if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
-        const bool curve = verify_cached_core(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, (mode & HS_MODE_STRICT) != 0);
+        const bool strict = (mode & HS_MODE_STRICT) != 0;
+        const bool curve = g_cached_lane_form
+            ? verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict)
+            : verify_cached_core(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
         out[i] = (ok && curve) ? 1 : 0;
     }
 }

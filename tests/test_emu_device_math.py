@@ -142,8 +142,9 @@ def test_verify_stages_vs_c_oracle_random(emu, oracle, fn):
             assert [i for i in range(n) if not out.raw[i]] == bad
 
 
-def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode):
+def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode, lane_form=0):
     import numpy as np
+    emu.emu_cached_set_lane_form(lane_form)
     emu.emu_keyset_words.restype = ctypes.c_size_t
     kw = emu.emu_keyset_words(S(1))
     nk = len(keys) // 32
@@ -160,7 +161,8 @@ def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode):
     return out.raw
 
 
-def test_cached_path_on_edge_vectors(emu, edge_vectors):
+@pytest.mark.parametrize("lane_form", [0, 1])
+def test_cached_path_on_edge_vectors(emu, edge_vectors, lane_form):
     """Committee key cache algorithm (verify_cached.h: per-key window tables, 64 table additions,
     R checked through one inversion instead of a decompression): the vector's key is
     registered, verdicts must equal the cold path's / the big-int oracle's in both modes."""
@@ -169,9 +171,9 @@ def test_cached_path_on_edge_vectors(emu, edge_vectors):
     msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)
     pks = b"".join(bytes.fromhex(v["pk"]) for v in vec)
     sigs = b"".join(bytes.fromhex(v["sig"]) for v in vec)
-    got = _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1)
+    got = _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1, lane_form)
     assert [bool(b) for b in got] == [v["strict"] for v in vec]
-    got = _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0)
+    got = _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0, lane_form)
     assert [bool(b) for b in got] == [v["cofactorless"] for v in vec]
 
 
@@ -202,11 +204,13 @@ def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
     assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in vec]
 
 
-def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz):
+@pytest.mark.parametrize("lane_form", [0, 1])
+def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz, lane_form):
+    """lane_form 0 = quad core (4 lanes per signature), 1 = one lane per signature."""
     vec = torsion_fuzz[:40]
     n = len(vec)
     msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)
     pks = b"".join(bytes.fromhex(v["pk"]) for v in vec)
     sigs = b"".join(bytes.fromhex(v["sig"]) for v in vec)
-    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1)] == [v["strict"] for v in vec]
-    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0)] == [v["cofactorless"] for v in vec]
+    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1, lane_form)] == [v["strict"] for v in vec]
+    assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0, lane_form)] == [v["cofactorless"] for v in vec]

@@ -209,3 +209,45 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
             _lib.set_kernel(old)
     assert [bool(b) for b in strict] == [v["strict"] for v in vec]
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
+
+
+def test_cached_lane_form_matches_quad_form(oracle, edge_vectors):
+    """The one-lane-per-signature cached kernel (dispatched above 16,384 signatures) forced on
+    small inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
+    old = _lib.set_kernel(_lib.KERNEL_LANE)
+    try:
+        n = len(edge_vectors)
+        keys = [H(v["pk"]) for v in edge_vectors]
+        ks = _lib.KeySet(keys)
+        dg = b"".join(H(v["msg"]) for v in edge_vectors)
+        sg = b"".join(H(v["sig"]) for v in edge_vectors)
+        assert [bool(b) for b in cached_bits(ks, dg, keys, sg, n, _lib.STRICT, False)] == [v["strict"] for v in edge_vectors]
+        assert [bool(b) for b in cached_bits(ks, dg, keys, sg, n, _lib.BATCH, False)] == [v["cofactorless"] for v in edge_vectors]
+        ks.close()
+        n = 700
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+        keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+        ks = _lib.KeySet(keys)
+        for mode in (_lib.BATCH, _lib.STRICT):
+            assert cached_bits(ks, dg, keys, sg, n, mode, True) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+        ks.close()
+    finally:
+        _lib.set_kernel(old)
+
+
+def test_cached_large_qc_takes_the_lane_form():
+    """n > 16,384 with the committee cached: 20,001 votes (N = 30,000 validators, 19.8 GB of
+    tables) by distinct keys; properties on the whole bitmap."""
+    n = 20001
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys + [synth.key_seed(30_000_000 + i) for i in range(30000 - n)])
+    victims = [0, 9999, 16384, 20000]
+    s2 = bytearray(sg)
+    for v in victims:
+        s2[64 * v + 3] ^= 0x40
+    got = cached_bits(ks, dg, keys, bytes(s2), n, _lib.BATCH, True)
+    assert [i for i in range(n) if not got[i]] == victims
+    assert cached_bits(ks, dg, keys, sg, n, _lib.BATCH, True) == b"\x01" * n
+    ks.close()
