@@ -59,6 +59,8 @@ def lib():
                 l.hs_ed25519_verify_device.restype = ctypes.c_int
                 l.hs_ed25519_ctx_set_profiling.argtypes = [vp, sz]
                 l.hs_ed25519_ctx_set_profiling.restype = ctypes.c_int
+                l.hs_ed25519_ctx_set_profiling_stride.argtypes = [vp, sz]
+                l.hs_ed25519_ctx_set_profiling_stride.restype = ctypes.c_int
                 l.hs_ed25519_ctx_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]
                 l.hs_ed25519_ctx_kernel_times.restype = ctypes.c_int
@@ -269,8 +271,9 @@ class DeviceContext:
                                                     int(n), mode, d_bitmap, d_nreject or None, stream or None),
               "hs_ed25519_verify_device_cached")
 
-    def set_profiling(self, slots):
+    def set_profiling(self, slots, every=1):
         check(lib().hs_ed25519_ctx_set_profiling(self._h, int(slots)), "hs_ed25519_ctx_set_profiling")
+        check(lib().hs_ed25519_ctx_set_profiling_stride(self._h, int(every)), "hs_ed25519_ctx_set_profiling_stride")
 
     def kernel_times(self):
         """(prepare_ms_sum, verify_ms_sum, launches) over the recorded calls; synchronise first."""

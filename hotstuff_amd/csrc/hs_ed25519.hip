@@ -240,7 +240,9 @@ struct hs_ed25519_ctx {
     // optional profiling: a ring of (start, after-prepare, after-verify) HIP events recorded
     // on the launch stream, read back by hs_ed25519_ctx_kernel_times after a synchronize
     std::vector<hipEvent_t> ev;
+    std::vector<char> ev_mid;     // slot recorded the middle event (a two-kernel call)
     size_t ev_slots = 0, ev_calls = 0;
+    size_t ev_every = 1, ev_seq = 0;   // record events on every ev_every-th call only
 };
 
 static std::mutex g_mu;
@@ -384,7 +386,9 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     workspace ws;
     ws.np = np; ws.pt = ctx->d_ws; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
     const u32 nn = (u32)n;
-    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
+    const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+    const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+    hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
     const u32 *p_pk = (const u32 *)d_pks, *p_sg = (const u32 *)d_sigs;
     u32 nn_ = nn, mode_ = mode;
     unsigned long long *p_bm = (unsigned long long *)d_bitmap;
@@ -396,9 +400,11 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     const int forced = g_kernel.load();
     const int kern = forced ? forced : (n <= kQuadMaxBatch ? 3 : 1);
     if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
-    if (kern != 3)
+    if (ev) ctx->ev_mid[slot] = kern != 3;
+    if (kern != 3) {
         HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
-    if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");
+        if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");      // single-kernel paths skip this marker
+    }
     if (kern == 3)
         HS_HIP(hipLaunchKernel((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, 0, st), "launch k_verify_fused");
     else if (kern == 2)
@@ -449,13 +455,21 @@ extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, 
 extern "C" int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots) {
     if (!ctx) return fail(HS_ED25519_E_ARG, "set_profiling: null context");
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
-    ctx->ev.clear(); ctx->ev_slots = 0; ctx->ev_calls = 0;
+    ctx->ev.clear(); ctx->ev_slots = 0; ctx->ev_calls = 0; ctx->ev_seq = 0;
+    ctx->ev_mid.assign(slots, 0);
     for (size_t i = 0; i < 3 * slots; i++) {
         hipEvent_t e;
         HS_HIP(hipEventCreate(&e), "hipEventCreate");
         ctx->ev.push_back(e);
     }
     ctx->ev_slots = slots;
+    return 0;
+}
+// Sample only every `every`-th call (event markers are queue packets: at 16 concurrent queues
+// three of them per step cost ~14 % of small-batch throughput).
+extern "C" int hs_ed25519_ctx_set_profiling_stride(hs_ed25519_ctx *ctx, size_t every) {
+    if (!ctx || every == 0) return fail(HS_ED25519_E_ARG, "set_profiling_stride: bad arguments");
+    ctx->ev_every = every; ctx->ev_seq = 0;
     return 0;
 }
 extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
@@ -465,8 +479,12 @@ extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_
     double a = 0, b = 0;
     for (size_t i = 0; i < cnt; i++) {
         float t0 = 0, t1 = 0;
-        HS_HIP(hipEventElapsedTime(&t0, ctx->ev[3 * i], ctx->ev[3 * i + 1]), "hipEventElapsedTime");
-        HS_HIP(hipEventElapsedTime(&t1, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]), "hipEventElapsedTime");
+        if (ctx->ev_mid[i]) {
+            HS_HIP(hipEventElapsedTime(&t0, ctx->ev[3 * i], ctx->ev[3 * i + 1]), "hipEventElapsedTime");
+            HS_HIP(hipEventElapsedTime(&t1, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]), "hipEventElapsedTime");
+        } else {
+            HS_HIP(hipEventElapsedTime(&t1, ctx->ev[3 * i], ctx->ev[3 * i + 2]), "hipEventElapsedTime");
+        }
         a += t0; b += t1;
     }
     *prepare_ms_sum = a; *verify_ms_sum = b; *launches = cnt;
@@ -566,8 +584,10 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     unsigned short *p_bm = (unsigned short *)d_bitmap;
     u32 *p_nr = d_nreject;
     void *a[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
-    hipEvent_t *ev = ctx->ev_slots ? &ctx->ev[3 * (ctx->ev_calls++ % ctx->ev_slots)] : nullptr;
-    if (ev) { HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord"); }
+    const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+    const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+    hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
+    if (ev) { ctx->ev_mid[slot] = 0; HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); }
     // four lanes per signature for latency, one lane per signature once the chip is full
     const int forced = g_kernel.load();
     const bool lane_form = forced ? forced == 1 : n > kCachedLaneMin;

@@ -150,6 +150,10 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
  * stream has been synchronised, hs_ed25519_ctx_kernel_times returns the summed durations
  * (ms) of the prepare and verify kernels over the recorded calls and their count. */
 int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots);
+/* Record the events on every `every`-th call only (default 1).  Event markers are queue
+ * packets; with many small batches in flight sampling keeps the measurement from perturbing
+ * what it measures. */
+int hs_ed25519_ctx_set_profiling_stride(hs_ed25519_ctx *ctx, size_t every);
 int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
                                 size_t *launches);
 
