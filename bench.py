@@ -188,8 +188,8 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=1024, help="signatures per step per GPU")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
@@ -198,12 +198,17 @@ def main():
     ap.add_argument("--no-cached", action="store_true", help="skip the committee-key-cache extra")
     ap.add_argument("--large-committee", type=int, default=100000, help="validators in the cached large-QC extra")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
-    ap.add_argument("--event-stride", type=int, default=4, help="record HIP events on every k-th call per context")
+    ap.add_argument("--event-stride", type=int, default=1, help="record HIP events on every k-th call per context")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "16")),
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to
+    # fd 1 (RCCL prints an info banner there through C stdio) is routed to stderr until the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import synth
@@ -270,8 +275,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    # HIP events around the kernels on every `--event-stride`-th call of each context: markers are
-    # queue packets and would otherwise cost ~14 % of this small-batch throughput
+    # HIP events attached to the kernel dispatches themselves (hipExtLaunchKernel start/stop), on the
+    # launch streams, for every `--event-stride`-th call of each context (default: every call)
     for c in ctxs:
         c.set_profiling(0 if args.no_events else (args.steps + ns - 1) // ns, every=args.event_stride)
     nrej.zero_()
@@ -441,10 +446,19 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if exchange:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)     # C stdio buffers (still pointing at stderr)
+    except Exception:
+        pass
+    if line is not None:
+        os.write(real_stdout, (line + "\n").encode())
 
 
 if __name__ == "__main__":

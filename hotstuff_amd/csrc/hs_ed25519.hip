@@ -9,6 +9,7 @@
 //   k_verify  : n lanes   (joint double-scalar multiplication, compare, ballot -> bitmap)
 // Host side: a pool of stream contexts (pinned staging + device buffers), no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
@@ -372,6 +373,16 @@ extern "C" const char *hs_ed25519_dominant_kernel(void) {
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
+// One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's
+// start/stop events) instead of bracketing it with marker packets: at 16 concurrent queues two
+// markers per step cost 14 % of small-batch throughput, dispatch timestamps ~3 %.
+// (hipExtAnyOrderLaunch was tried for back-to-back independent batches on one stream: no
+// effect on gfx950, as hip_ext.h warns for GFX9xx.)
+static hipError_t launch1(const void *fn, dim3 grid, void **args, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+    if (start || stop) return hipExtLaunchKernel(fn, grid, dim3(64), args, 0, st, start, stop, 0);
+    return hipLaunchKernel(fn, grid, dim3(64), args, 0, st);
+}
+
 // enqueue the cold path over n signatures whose messages come from `msgs`
 static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n,
                         uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
@@ -399,19 +410,20 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     const int forced = g_kernel.load();
     const int kern = forced ? forced : (n <= kQuadMaxBatch ? 3 : 1);
-    if (ev) HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord");
     if (ev) ctx->ev_mid[slot] = kern != 3;
-    if (kern != 3) {
-        HS_HIP(hipLaunchKernel((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, 0, st), "launch k_prepare");
-        if (ev) HS_HIP(hipEventRecord(ev[1], st), "hipEventRecord");      // single-kernel paths skip this marker
+    if (kern == 3) {
+        HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_fused");
+    } else {
+        HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
+               "launch k_prepare");
+        if (kern == 2)
+            HS_HIP(launch1((const void *)k_verify_quad, dim3(np / 16), a2, st, nullptr, ev ? ev[2] : nullptr),
+                   "launch k_verify_quad");
+        else
+            HS_HIP(launch1((const void *)k_verify, dim3(np / 64), a2, st, nullptr, ev ? ev[2] : nullptr),
+                   "launch k_verify");
     }
-    if (kern == 3)
-        HS_HIP(hipLaunchKernel((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, 0, st), "launch k_verify_fused");
-    else if (kern == 2)
-        HS_HIP(hipLaunchKernel((const void *)k_verify_quad, dim3(np / 16), dim3(64), a2, 0, st), "launch k_verify_quad");
-    else
-        HS_HIP(hipLaunchKernel((const void *)k_verify, dim3(np / 64), dim3(64), a2, 0, st), "launch k_verify");
-    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
     return 0;
 }
 static int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride) {
@@ -587,15 +599,16 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
     const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
     hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
-    if (ev) { ctx->ev_mid[slot] = 0; HS_HIP(hipEventRecord(ev[0], st), "hipEventRecord"); }
+    if (ev) ctx->ev_mid[slot] = 0;
     // four lanes per signature for latency, one lane per signature once the chip is full
     const int forced = g_kernel.load();
     const bool lane_form = forced ? forced == 1 : n > kCachedLaneMin;
     if (lane_form)
-        HS_HIP(hipLaunchKernel((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, 0, st), "launch k_verify_cached_lane");
+        HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_cached_lane");
     else
-        HS_HIP(hipLaunchKernel((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, 0, st), "launch k_verify_cached");
-    if (ev) HS_HIP(hipEventRecord(ev[2], st), "hipEventRecord");
+        HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_cached");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,

@@ -145,8 +145,9 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
                                        const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap, uint32_t *d_nreject,
                                        void *stream);
 
-/* Profiling: keep a ring of `slots` HIP-event triples recorded on the launch stream around
- * the two kernels of each hs_ed25519_verify_device call on `ctx` (0 = off).  After the
+/* Profiling: keep a ring of `slots` HIP-event triples attached to the kernel dispatches of each
+ * hs_ed25519_verify_device* call on `ctx` (hipExtLaunchKernel start/stop events, on the launch
+ * stream; 0 = off).  After the
  * stream has been synchronised, hs_ed25519_ctx_kernel_times returns the summed durations
  * (ms) of the prepare and verify kernels over the recorded calls and their count. */
 int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots);
