@@ -50,6 +50,15 @@ def test_no_gpu_means_loud_failure_never_success():
         Signature.verify_batch(Digest(), [(PublicKey(), Signature())])
     # the empty batch never reaches the engine: Ok, as lib.rs:206-219 returns for an empty iterator
     assert Signature.verify_batch(Digest(), []) is None
+    # key cache and TC entry points fail loudly too
+    with pytest.raises(_lib.EngineError):
+        _lib.KeySet([bytes(32)])
+    with pytest.raises(_lib.EngineError):
+        _lib.verify_tc_packed(1, [0], bytes(32), bytes(64))
+    from hotstuff_amd.messages import InvalidSignature
+    c = Committee({PublicKey(bytes([i]) * 32): 1 for i in range(4)})
+    with pytest.raises(InvalidSignature):
+        TC(3, [(PublicKey(bytes([i]) * 32), Signature(), 1) for i in range(3)]).verify(c)
 
 
 def _fixture(openssl_vectors):

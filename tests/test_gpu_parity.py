@@ -323,3 +323,32 @@ def test_streamed_rounds_through_the_host_api():
     print("streamed rounds: %.1f M signatures/s sustained from host memory, %d calls, p50 %.3f ms, p99 %.3f ms"
           % (rate / 1e6, sum(counts), allat[len(allat) // 2] * 1e3, allat[int(len(allat) * 0.99)] * 1e3))
     assert rate > 1e6
+
+
+def test_lifecycle_shutdown_reinit_and_keyset_churn():
+    """hs_ed25519_shutdown releases the pooled contexts and the base-point table; a later init
+    brings everything back.  Creating and destroying key sets repeatedly must not leak HBM."""
+    n = 64
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    assert _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True)[0]
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys); ks.close()                 # warm: base table + allocator pools
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        ks = _lib.KeySet(keys)
+        packed, _ = ks.indices(keys)
+        assert ks.verify_packed(dg, packed, sg, n, _lib.BATCH, True)[0]
+        ks.close()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < 64 << 20      # no 42 MB-per-round leak
+    _lib.lib().hs_ed25519_shutdown()
+    bufs = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    rc = _lib.lib().hs_ed25519_verify_shared(*[ctypes.addressof(b) for b in bufs], n, 0, None)
+    assert rc == -1                                                   # HS_ED25519_E_NOT_INIT, never "accepted"
+    _lib.init(0, 8192)
+    assert _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True)[0]
+    ks = _lib.KeySet(keys)
+    packed, _ = ks.indices(keys)
+    assert ks.verify_packed(dg, packed, sg, n, _lib.STRICT, True)[0]
+    ks.close()
