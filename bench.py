@@ -351,7 +351,7 @@ def main():
         ks.close()
         # large committee, one launch (BASELINE configs[3] on ONE GPU): N = 100,000 validators (66 GB of
         # tables - sized for 288 GB of HBM), QC of 66,667 votes
-        # by distinct keys -> the one-lane-per-signature cached kernel; its table gather is the one
+        # by distinct keys -> the two-lanes-per-signature cached kernel; its table gather is the one
         # place on this path where HBM bandwidth is a meaningful roofline
         try:
             Nv = args.large_committee
@@ -379,7 +379,7 @@ def main():
             gather = 32 * 160 * nl                      # bytes of the keys' tables read per launch
             cached["large_committee"] = {
                 "n_validators": Nv, "signatures": nl, "keyset_hbm_bytes": lks.hbm_bytes(),
-                "kernel": "k_verify_cached_lane", "avg_kernel_ms": round(lk_ms, 4),
+                "kernel": "k_verify_cached_lane2" if 16384 < nl <= 131072 else "k_verify_cached*", "avg_kernel_ms": round(lk_ms, 4),
                 "value": round(nl * reps / l_el, 1), "unit": "verifies/s",
                 "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -186,7 +186,47 @@ k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src
     }
 }
 
-// the throughput form: one lane per signature (verify_cached_lane), for large batches
+// two lanes per signature (verify_cached_lane2): a wavefront covers 32 signatures
+__global__ void __launch_bounds__(64)
+k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                      const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                      u32 *__restrict__ bitmap32, u32 *__restrict__ nreject) {
+    const u32 i = blockIdx.x * 32 + (threadIdx.x >> 1);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const u32 ki_raw = key_idx[j];
+    const bool known = ki_raw < nkeys;
+    const u32 ki = known ? ki_raw : 0;
+    const u32 *sig = sigs + (size_t)16 * j;
+    u32 kw[8], sw[8], renc[8], msg[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) renc[t] = sig[t];
+    load_msg(msg, msgs, j);
+    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+    const u32 fl = ks.flag[ki];
+    ok = ok && known && (fl & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
+    const bool curve = verify_cached_lane2(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
+    unsigned long long m = __ballot(ok && curve && active);
+    m &= m >> 1;                         // both lanes of the pair
+    m &= 0x5555555555555555ull;          // gather bit 2q -> bit q
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0xffffffffull;
+    if (threadIdx.x == 0) {
+        bitmap32[blockIdx.x] = (u32)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 32;
+            const u32 sigs_here = first < n ? min(32u, n - first) : 0u;
+            const u32 bad = sigs_here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
+// the throughput form: one lane per signature (verify_cached_lane), for the largest batches
 __global__ void __launch_bounds__(64)
 k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
                      const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
@@ -255,7 +295,8 @@ static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
 static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own window table
-static const size_t kCachedLaneMin = 16384; // cached path: quad kernel up to here, one lane per signature above
+static const size_t kCachedLaneMin = 16384;    // cached path: 4 lanes per signature up to here, 2 above ...
+static const size_t kCachedLane1Min = 131072;  // ... and 1 lane per signature above this
 static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
 static const size_t kQuadMaxBatch = 16384;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
@@ -600,12 +641,16 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
     hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
     if (ev) ctx->ev_mid[slot] = 0;
-    // four lanes per signature for latency, one lane per signature once the chip is full
+    // four lanes per signature for latency, two in the middle, one once the chip is full anyway
     const int forced = g_kernel.load();
-    const bool lane_form = forced ? forced == 1 : n > kCachedLaneMin;
-    if (lane_form)
+    const int lanes = forced ? (forced == 1 ? 1 : (forced == 2 ? 2 : 4))
+                             : (n > kCachedLane1Min ? 1 : (n > kCachedLaneMin ? 2 : 4));
+    if (lanes == 1)
         HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane");
+    else if (lanes == 2)
+        HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_cached_lane2");
     else
         HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached");

@@ -185,20 +185,20 @@ HS_HD void ge_add_tab(ge_p3 &r, const ge_p3 &p, const tab_entry &e, bool neg) {
     fe_select(G, zs, zd, neg);                    // G = D +- C
     fe_mul(r.X, E, F); fe_mul(r.Y, G, H); fe_mul(r.Z, F, G); fe_mul(r.T, E, H);
 }
-// The curve part of one cached verification on ONE lane.  Returns accept.
-HS_HD bool verify_cached_lane(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
-    ge_p3 acc;
+// sum_w T[w][d_w] over the 32 windows of one table and one radix-256 recoded scalar
+HS_HD void cached_chain(ge_p3 &acc, const u32 *tab, u32 dw[8]) {
     ge_identity(acc);
 #pragma nounroll
     for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
-        const int dk = sc_pop_digit8(kw), ds = sc_pop_digit8(sw);
-        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
+        const int d = sc_pop_digit8(dw);
+        const int id = d < 0 ? -d : d;
         tab_entry e;
-        load_tab_entry(e, atab + ((size_t)w * HS_KS_ENTRIES + ik) * HS_KS_ENTRY_WORDS);
-        ge_add_tab(acc, acc, e, dk < 0);
-        load_tab_entry(e, btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
-        ge_add_tab(acc, acc, e, ds < 0);
+        load_tab_entry(e, tab + ((size_t)w * HS_KS_ENTRIES + id) * HS_KS_ENTRY_WORDS);
+        ge_add_tab(acc, acc, e, d < 0);
     }
+}
+// The check of R' = (X:Y:Z:T) against R's encoding (and the strict small-order test).
+HS_HD bool cached_finish(const ge_p3 &acc, const u32 renc[8], bool strict) {
     bool ok = true;
     if (strict) ok = !ge_is_small_order(acc);      // [8]R' == O ?  (R' == R whenever accepted)
     fe zi, x, y;
@@ -215,5 +215,40 @@ HS_HD bool verify_cached_lane(const u32 *atab, const u32 *btab, u32 kw[8], u32 s
     for (int i = 0; i < 8; i++) { dy |= yw[i] ^ ew[i]; nz |= xw[i]; }
     return ok && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0);
 }
+// p + q for two extended points (q converted to cached form on the fly)
+HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {
+    ge_cached c;
+    ge_to_cached(c, q);
+    ge_p1p1 t;
+    ge_add(t, p, c, false);
+    ge_p1p1_to_p3(r, t, true);
+}
+// The curve part of one cached verification on ONE lane (both chains serially).
+HS_HD bool verify_cached_lane(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+    ge_p3 pa, pb, acc;
+    cached_chain(pa, atab, kw);
+    cached_chain(pb, btab, sw);
+    ge_add_p3(acc, pa, pb);
+    return cached_finish(acc, renc, strict);
+}
+#if defined(__HIPCC__)
+// TWO lanes per signature: the even lane walks the key's table with k, the odd lane the base
+// point's table with s - one instruction stream, per-lane table pointer and digit source -
+// then one DPP exchange and one addition join them.  Half the serial additions per lane and
+// twice the wavefronts for the same batch.
+HS_Q bool verify_cached_lane2(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+    const bool odd = threadIdx.x & 1u;
+    const u32 *tab = odd ? btab : atab;
+    u32 dw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) dw[i] = odd ? sw[i] : kw[i];
+    ge_p3 mine, other, acc;
+    cached_chain(mine, tab, dw);
+    other.X = q_perm<1, 0, 3, 2>(mine.X); other.Y = q_perm<1, 0, 3, 2>(mine.Y);
+    other.Z = q_perm<1, 0, 3, 2>(mine.Z); other.T = q_perm<1, 0, 3, 2>(mine.T);
+    ge_add_p3(acc, mine, other);          // both lanes of the pair now hold R' (addition commutes)
+    return cached_finish(acc, renc, strict);
+}
+#endif
 
 }  // namespace hs

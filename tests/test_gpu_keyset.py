@@ -211,10 +211,12 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-def test_cached_lane_form_matches_quad_form(oracle, edge_vectors):
-    """The one-lane-per-signature cached kernel (dispatched above 16,384 signatures) forced on
-    small inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
-    old = _lib.set_kernel(_lib.KERNEL_LANE)
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD])
+def test_cached_lane_forms_match_quad_form(oracle, edge_vectors, kernel):
+    """The one- and two-lanes-per-signature cached kernels (dispatched above 131,072 / 16,384
+    signatures; selector 1 / 2) forced on small inputs: edge vectors in both modes and a
+    corrupted QC vs the oracle."""
+    old = _lib.set_kernel(kernel)
     try:
         n = len(edge_vectors)
         keys = [H(v["pk"]) for v in edge_vectors]
@@ -236,8 +238,8 @@ def test_cached_lane_form_matches_quad_form(oracle, edge_vectors):
         _lib.set_kernel(old)
 
 
-def test_cached_large_qc_takes_the_lane_form():
-    """n > 16,384 with the committee cached: 20,001 votes (N = 30,000 validators, 19.8 GB of
+def test_cached_large_qc_takes_the_two_lane_form():
+    """n > 16,384 with the committee cached (k_verify_cached_lane2): 20,001 votes (N = 30,000 validators, 19.8 GB of
     tables) by distinct keys; properties on the whole bitmap."""
     n = 20001
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
