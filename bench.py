@@ -124,6 +124,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     nr = torch.zeros(1, dtype=torch.int32, device=dev)
     ctx = _lib.DeviceContext(n)
     st = torch.cuda.ExternalStream(ctx.stream, device=dev)     # the context's own stream
+    torch.cuda.synchronize(dev)                                # uploads / fills above ran on torch's stream
     devt = []
     with torch.cuda.stream(st):
         for i in range(calls + 20):
@@ -324,6 +325,7 @@ def main():
         build_ms = (time.perf_counter() - t0) * 1e3
         d_ki = torch.arange(n, dtype=torch.int32, device=dev)
         p_ki = d_ki.data_ptr()
+        torch.cuda.synchronize(dev)
         for c in ctxs:
             c.set_profiling((args.steps + ns - 1) // ns, every=args.event_stride)
 
@@ -365,6 +367,7 @@ def main():
             l_nr = torch.zeros(1, dtype=torch.int32, device=dev)
             lctx = _lib.DeviceContext(nl)
             lst = torch.cuda.ExternalStream(lctx.stream, device=dev)
+            torch.cuda.synchronize(dev)
             reps = 30
             lctx.set_profiling(reps)
             for i in range(reps + 3):

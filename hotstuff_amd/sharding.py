@@ -64,19 +64,33 @@ class GpuShardVerifier:
     """verify_shard callable for device-resident inputs: slices the packed tensors and
     runs this rank's range through the C-ABI device entry point on the current stream."""
 
-    def __init__(self, digests, digest_stride, pks, sigs, mode, max_batch=None):
+    def __init__(self, digests, digest_stride, pks, sigs, mode, max_batch=None, keyset=None, key_idx=None):
+        """keyset / key_idx (int32 device tensor, one index per signature): verify through the
+        committee key cache instead of by key bytes (`pks` may then be None)."""
         from . import _lib
         self._lib = _lib
         self.digests, self.digest_stride, self.pks, self.sigs, self.mode = digests, digest_stride, pks, sigs, mode
+        self.keyset, self.key_idx = keyset, key_idx
         self.ctx = _lib.DeviceContext(max_batch or 1024)
+        # the kernels run on the context's own stream; consumers on torch's current stream (the
+        # all-gather) are ordered behind it explicitly - a raw handle of 0 would mean "the
+        # context's stream" to the C-ABI, not torch's null stream
+        self._stream = torch.cuda.ExternalStream(self.ctx.stream, device=sigs.device)
 
     def __call__(self, lo, hi, S):
-        dev = self.pks.device
+        dev = self.sigs.device
         bitmap = torch.zeros(S // 8, dtype=torch.uint8, device=dev)
         n = hi - lo
         if n > 0:
             dg = self.digests if self.digest_stride == 0 else self.digests[32 * lo:]
-            self.ctx.verify(dg.data_ptr(), self.digest_stride, self.pks[32 * lo:].data_ptr(),
-                            self.sigs[64 * lo:].data_ptr(), n, self.mode, bitmap.data_ptr(), 0,
-                            torch.cuda.current_stream().cuda_stream)
+            cur = torch.cuda.current_stream(dev)
+            self._stream.wait_stream(cur)            # inputs / the zeroed bitmap were produced on `cur`
+            stream = self.ctx.stream
+            if self.keyset is not None:
+                self.ctx.verify_cached(self.keyset, dg.data_ptr(), self.digest_stride, self.key_idx[lo:].data_ptr(),
+                                       self.sigs[64 * lo:].data_ptr(), n, self.mode, bitmap.data_ptr(), 0, stream)
+            else:
+                self.ctx.verify(dg.data_ptr(), self.digest_stride, self.pks[32 * lo:].data_ptr(),
+                                self.sigs[64 * lo:].data_ptr(), n, self.mode, bitmap.data_ptr(), 0, stream)
+            cur.wait_stream(self._stream)            # whoever reads the bitmap on `cur` sees the result
         return bitmap

@@ -89,7 +89,10 @@ int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const ui
  *                 (zero it before the call); may be NULL
  *   stream        hipStream_t to enqueue on (NULL = the context's own stream)
  * Enqueues and returns immediately: 0 on success or HS_ED25519_E_*.  The scratch
- * workspace belongs to `ctx`; a context serves one call at a time per stream order. */
+ * workspace belongs to `ctx`; a context serves one call at a time per stream order.
+ * NOTE: stream = NULL selects the context's own NON-BLOCKING stream, not HIP's null stream;
+ * work on other streams (including the null stream) that produces the inputs or consumes the
+ * bitmap must be ordered against it explicitly (event / stream wait / synchronize). */
 typedef struct hs_ed25519_ctx hs_ed25519_ctx;
 int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch);
 void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);

@@ -142,6 +142,7 @@ def test_device_resident_cached_api(oracle):
     d_bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
     d_nr = torch.zeros(1, dtype=torch.int32, device=dev)
     ctx = _lib.DeviceContext(n)
+    torch.cuda.synchronize()        # the fills above ran on torch's stream; the engine uses its own
     ctx.verify_cached(ks, d_dg.data_ptr(), 0, d_ki.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, d_bm.data_ptr(),
                       d_nr.data_ptr(), ctx.stream)
     torch.cuda.synchronize()

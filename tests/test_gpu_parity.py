@@ -171,8 +171,9 @@ def test_device_resident_api_matches_host_api(oracle):
     d_bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
     d_nr = torch.zeros(1, dtype=torch.int32, device=dev)
     ctx = _lib.DeviceContext(n)
+    torch.cuda.synchronize()        # the fills above ran on torch's stream; the engine uses its own
     ctx.verify(d_dg.data_ptr(), 32, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.STRICT, d_bm.data_ptr(),
-               d_nr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+               d_nr.data_ptr(), ctx.stream)
     torch.cuda.synchronize()
     got = bits(bytes(d_bm.cpu().tolist()), n)
     assert got == oracle_verify_many(oracle, dg, 32, pk, sg, n, 1)
@@ -235,6 +236,14 @@ def test_single_gpu_sharded_path_over_rccl():
         ok, bm = verify_sharded(v, n)
         b = bits(bytes(bm.cpu().tolist()), n)
         assert not ok and [i for i in range(n) if not b[i]] == [77]
+        # the same shard through the committee key cache
+        ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(n)])
+        v = GpuShardVerifier(t(dg), 0, None, t(bytes(s2)), _lib.BATCH, n, keyset=ks,
+                             key_idx=torch.arange(n, dtype=torch.int32, device=dev))
+        ok, bm = verify_sharded(v, n)
+        b = bits(bytes(bm.cpu().tolist()), n)
+        assert not ok and [i for i in range(n) if not b[i]] == [77]
+        ks.close()
     finally:
         if created:
             dist.destroy_process_group()
