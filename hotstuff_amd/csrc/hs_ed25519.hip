@@ -298,7 +298,7 @@ static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own wind
 static const size_t kCachedLaneMin = 16384;    // cached path: 4 lanes per signature up to here, 2 above ...
 static const size_t kCachedLane1Min = 131072;  // ... and 1 lane per signature above this
 static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
-static const size_t kQuadMaxBatch = 16384;   // fused quad kernel up to here (latency), lane kernels above (throughput)
+static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }

@@ -162,7 +162,7 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
                                 size_t *launches);
 
 /* Cold-path kernel choice: 0 = by batch size (default: fused 4-lanes-per-signature kernel up to
- * 16,384 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
+ * 32,768 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
  * 2 = two kernels with the quad stage 2, 3 = fused.  (The key-cache path maps 1 / 2 / 3 to its
  * one- / two- / four-lanes-per-signature kernels.)  All variants have the same accept set; this
  * exists for tests and A/B measurements (env HS_ED25519_KERNEL=lane|quad|fused sets it at init).

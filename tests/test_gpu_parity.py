@@ -272,21 +272,21 @@ def test_every_kernel_variant_has_the_same_accept_set(oracle, edge_vectors, kern
 
 
 def test_large_batch_takes_the_two_kernel_path(oracle):
-    """n > 16,384 dispatches k_prepare + k_verify (one lane per signature).  20,000 signatures
+    """n > 32,768 dispatches k_prepare + k_verify (one lane per signature).  40,000 signatures
     (6,667 distinct, tiled): oracle on a window, properties on the whole."""
     base = 6667
     dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
-    n = 20000
-    pk_t = (pk * 3)[: 32 * n]
-    sg_t = bytearray((sg * 3)[: 64 * n])
-    victims = [1, 6667, 16384, 19999]
+    n = 40000
+    pk_t = (pk * 6)[: 32 * n]
+    sg_t = bytearray((sg * 6)[: 64 * n])
+    victims = [1, 6667, 32768, 39999]
     for v in victims:
         sg_t[64 * v + 33] ^= 0x08
     sg_t = bytes(sg_t)
     ok, bm = _lib.verify_packed(dg, pk_t, sg_t, n, _lib.BATCH, shared=True, want_bitmap=True)
     b = bits(bm, n)
     assert not ok and [i for i in range(n) if not b[i]] == victims
-    lo = 16000
+    lo = 32500
     assert b[lo:lo + 800] == oracle_verify_many(oracle, dg, 0, pk_t[32 * lo:], sg_t[64 * lo:], 800, 0)
 
 
