@@ -118,6 +118,7 @@ def ensure_init():
 
 
 KERNEL_AUTO, KERNEL_LANE, KERNEL_QUAD, KERNEL_FUSED = 0, 1, 2, 3
+KERNEL_CACHED_SINGLE_ROLE = 10    # key-cache path only: quad kernel finishing by inversion
 
 
 def set_kernel(which):

@@ -186,6 +186,72 @@ k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src
     }
 }
 
+// Latency form of the cached path: a workgroup of FIVE wavefronts covers 64 signatures.
+// Wavefronts 0-3 run the quad addition chains (16 signatures each); wavefront 4 meanwhile
+// decompresses the 64 R's, one lane per signature, and hands (x_R, y_R, flags) over through LDS.
+// After the barrier the chains finish with a projective comparison (2 multiplications) instead
+// of an inversion: the square root is off the critical path.
+__global__ void __launch_bounds__(320)
+k_verify_cached_5w(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                   const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                   unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
+    __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool strict = (mode & HS_MODE_STRICT) != 0;
+    qv acc;
+    bool ok = false, active = false;
+    if (wave == 4) {
+        const u32 i = blockIdx.x * 64 + lane;
+        const u32 j = i < n ? i : n - 1;
+        u32 enc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) enc[t] = sigs[(size_t)16 * j + t];
+        ge_p3 R;
+        u32 fl = ge_decompress(R, enc) ? HS_F_ONCURVE : 0;
+        if (strict) fl |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+#pragma unroll
+        for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
+        s_r[20][lane] = fl;
+    } else {
+        const u32 i = blockIdx.x * 64 + wave * 16 + (lane >> 2);
+        active = i < n;
+        const u32 j = active ? i : n - 1;
+        const u32 ki_raw = key_idx[j];
+        const bool known = ki_raw < nkeys;
+        const u32 ki = known ? ki_raw : 0;
+        const u32 *sig = sigs + (size_t)16 * j;
+        u32 kw[8], sw[8], msg[8];
+        load_msg(msg, msgs, j);
+        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+        const u32 fl = ks.flag[ki];
+        ok = ok && known && (fl & HS_F_ONCURVE);
+        if (strict) ok = ok && !(fl & HS_F_SMALL);
+        acc = cached_quad_chain(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw);
+    }
+    __syncthreads();
+    if (wave == 4) return;
+    const u32 slot = wave * 16 + (lane >> 2);
+    fe rx, ry;
+#pragma unroll
+    for (int t = 0; t < 10; t++) { rx.v[t] = s_r[t][slot]; ry.v[t] = s_r[10 + t][slot]; }
+    const bool curve = cached_quad_match_point(acc, rx, ry, s_r[20][slot], strict);
+    unsigned long long m = __ballot(ok && curve && active);
+    m &= 0x1111111111111111ull;         // the verdict is quad-uniform: take lane 0 of each quad
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    if (lane == 0) {
+        bitmap16[blockIdx.x * 4 + wave] = (unsigned short)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 64 + wave * 16;
+            const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
+            const u32 bad = sigs_here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
 // two lanes per signature (verify_cached_lane2): a wavefront covers 32 signatures
 __global__ void __launch_bounds__(64)
 k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
@@ -406,7 +472,7 @@ extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
 // 3 = k_verify_fused.  For tests and A/B measurements; returns the previous setting.
 extern "C" int hs_ed25519_set_kernel(int which) {
     const int old = g_kernel.load();
-    if (which >= 0 && which <= 3) g_kernel.store(which);
+    if ((which >= 0 && which <= 3) || which == 10) g_kernel.store(which);
     return old;
 }
 extern "C" const char *hs_ed25519_dominant_kernel(void) {
@@ -452,7 +518,7 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     const int forced = g_kernel.load();
-    const int kern = forced ? forced : (n <= kQuadMaxBatch ? 3 : 1);
+    const int kern = forced == 10 ? 3 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1));
     if (ev) ctx->ev_mid[slot] = kern != 3;
     if (kern == 3) {
         HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
@@ -645,7 +711,7 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     if (ev) ctx->ev_mid[slot] = 0;
     // four lanes per signature for latency, two in the middle, one once the chip is full anyway
     const int forced = g_kernel.load();
-    const int lanes = forced ? (forced == 1 ? 1 : (forced == 2 ? 2 : 4))
+    const int lanes = forced ? (forced == 1 ? 1 : (forced == 2 ? 2 : 4))      /* 3 and 10 -> 4 lanes */
                              : (n > kCachedLane1Min ? 1 : (n > kCachedLaneMin ? 2 : 4));
     if (lanes == 1)
         HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
@@ -653,9 +719,12 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     else if (lanes == 2)
         HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane2");
-    else
+    else if (forced == 2 + 8)      // selector 10: the single-wavefront-role quad kernel (A/B measurements)
         HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached");
+    else
+        HS_HIP(hipExtLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st,
+                                  ev ? ev[0] : nullptr, ev ? ev[2] : nullptr, 0), "launch k_verify_cached_5w");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,

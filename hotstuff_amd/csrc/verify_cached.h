@@ -128,7 +128,7 @@ HS_Q void keyset_build_window(u32 *win /* [129][40] */, const fe &ax, const fe &
 // atab: this key's table; btab: the base point's table (same layout, +B).
 // kw, sw: radix-256 recodings of k and s.  renc: the 8 words of R's encoding.
 // strict: also reject when [8]R' = O.   Returns the quad-uniform verdict of the curve part.
-HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+HS_Q qv cached_quad_chain(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8]) {
     qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
 #pragma nounroll
     for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
@@ -139,6 +139,10 @@ HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw
         acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
         acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
     }
+    return acc;
+}
+HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+    const qv acc = cached_quad_chain(atab, btab, kw, sw);
     bool ok = true;
     if (strict) {       // [8]R' == O ?  (R' == R whenever the signature is accepted)
         qv t = q_dbl(q_dbl(q_dbl(acc)));
@@ -147,6 +151,18 @@ HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw
     const qv zinv = q_invert(q_perm<2, 2, 2, 2>(acc));
     const qv aff = q_mul(acc, zinv);                        // (x', y', 1, t')
     return ok && q_quad_and01(q_match_encoding(aff, renc));
+}
+// The other way to finish: R was decompressed elsewhere (concurrently, by another wavefront of
+// the workgroup) to affine (rx, ry); compare as points, X == x_R Z and Y == y_R Z - two
+// multiplications instead of an inversion on the critical path.  r_flags: HS_F_* of R.
+HS_Q bool cached_quad_match_point(const qv &acc, const fe &rx, const fe &ry, u32 r_flags, bool strict) {
+    const qv z = q_perm<2, 2, 2, 2>(acc);
+    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
+    const qv lhs = q_sel<0b1100>(acc, z);
+    const qflags f = q_eq(rhs, q_carry(lhs));
+    bool ok = (r_flags & HS_F_ONCURVE) != 0;
+    if (strict) ok = ok && !(r_flags & HS_F_SMALL);
+    return ok && q_quad_and01(f);
 }
 
 // ---- one lane per signature (throughput form, large batches) -------------------------------

@@ -164,7 +164,8 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
 /* Cold-path kernel choice: 0 = by batch size (default: fused 4-lanes-per-signature kernel up to
  * 32,768 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
  * 2 = two kernels with the quad stage 2, 3 = fused.  (The key-cache path maps 1 / 2 / 3 to its
- * one- / two- / four-lanes-per-signature kernels.)  All variants have the same accept set; this
+ * one- / two- / four-lanes-per-signature kernels; 10 = its four-lane kernel without the
+ * concurrent R-decompression wavefront.)  All variants have the same accept set; this
  * exists for tests and A/B measurements (env HS_ED25519_KERNEL=lane|quad|fused sets it at init).
  * Returns the previous setting. */
 int hs_ed25519_set_kernel(int which);

@@ -15,6 +15,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a clean clone has no built artefacts: build the engine (hipcc cross-compiles without a GPU)
+    # and the CPU checker before collecting, exactly what __graft_entry__.build() does
+    lib = os.path.join(ROOT, "hotstuff_amd", "libhs_ed25519.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build_engine()
 
 
 def _make(path):

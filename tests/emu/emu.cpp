@@ -128,9 +128,17 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
         ok = ok && (fl & HS_F_ONCURVE);
         if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
         const bool strict = (mode & HS_MODE_STRICT) != 0;
-        const bool curve = g_cached_lane_form
-            ? verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict)
-            : verify_cached_core(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
+        bool curve;
+        if (g_cached_lane_form == 1) {
+            curve = verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
+        } else if (g_cached_lane_form == 2) {      // chain + R decompressed separately (the 5-wavefront kernel)
+            ge_p3 R; u32 rf = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
+            if (strict) rf |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+            const qv acc = cached_quad_chain(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw);
+            curve = cached_quad_match_point(acc, R.X, R.Y, rf, strict);
+        } else {
+            curve = verify_cached_core(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
+        }
         out[i] = (ok && curve) ? 1 : 0;
     }
 }

@@ -212,11 +212,12 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD])
-def test_cached_lane_forms_match_quad_form(oracle, edge_vectors, kernel):
-    """The one- and two-lanes-per-signature cached kernels (dispatched above 131,072 / 16,384
-    signatures; selector 1 / 2) forced on small inputs: edge vectors in both modes and a
-    corrupted QC vs the oracle."""
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_CACHED_SINGLE_ROLE])
+def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
+    """The default cached kernel up to 16,384 signatures is the 5-wavefront one (chains +
+    concurrent R decompression).  Force the others - one / two lanes per signature (dispatched
+    above 131,072 / 16,384) and the single-role quad kernel finishing by inversion - on small
+    inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
     old = _lib.set_kernel(kernel)
     try:
         n = len(edge_vectors)
