@@ -3,12 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path (hs_ed25519_verify_device: k_prepare + k_verify) over one
-batch of synthetic input that is already resident in HBM.  Default workload = BASELINE.json
+A "step" is one pass of the hot path (one hs_ed25519_verify_device call: the fused k_verify_fused
+kernel at this batch size) over one batch of synthetic input that is already resident in HBM.  Default workload = BASELINE.json
 configs[1]: 1,024 distinct (digest, pk, sig) tuples, one digest per tuple, strict semantics
 (the TC::verify / Signature::verify predicate, consensus/src/messages.rs:307-313).  Steps are
-enqueued round-robin on `--streams` HIP streams so that independent batches overlap on the
-chip, the way a node under load issues them; the timed region is bracketed by a barrier and a
+enqueued round-robin on `--streams` HIP streams, each restricted to its own slice of the CUs
+(`--partitions`), so that independent batches overlap on the chip the way a node under load
+issues them; the timed region is bracketed by a barrier and a
 device synchronize on both sides and the maximum over ranks is taken.
 
 With N > 1 every rank owns an equal shard (its own 1,024 tuples per step: weak scaling) and
@@ -17,10 +18,13 @@ one exchange step the north star names.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      algorithmic bytes (128 B per verification) of the dominant kernel
-                divided by its average duration, measured live with HIP events on the launch
-                streams inside the timed region, against the 8 TB/s HBM peak.  This path is
-                integer-VALU bound, so the fraction is tiny by construction; `int_roofline`
-                (extra) prices the same kernel against the measured v_mad_u64_u32 issue rate.
+                divided by its average duration, measured live with HIP events attached to the
+                dispatches on the launch streams inside the timed region, against the 8 TB/s HBM
+                peak.  This path is integer-VALU bound, so the fraction is tiny by construction;
+                `int_roofline` (extra) prices the same kernel against the measured
+                v_mad_u64_u32 issue rate.
+  extras        `committee_cached` (same workload with the keys registered as a key set, and the
+                100,000-validator QC on one GPU), `qc_verify_latency` (p50 at N = 10,000).
   cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"),
                 timed on the host's cores on a bounded sample of the same workload.
 """

@@ -9,6 +9,8 @@ One hot path only (BASELINE.json north_star): what sits under
   hotstuff_amd.crypto    Digest / PublicKey / Signature mirror of the reference types
   hotstuff_amd.messages  QC / TC / Committee call-site mirror
   hotstuff_amd.sharding  multi-GPU sharding of one large committee (RCCL all-gather)
+  hotstuff_amd.ingest    callers either side of the path: batched vote ingest, verified-QC cache
+  hotstuff_amd._lib      ctypes binding incl. KeySet (committee key cache) and DeviceContext
 
 There is no CPU fallback: without the HIP library and a GPU every verify raises.
 """

@@ -24,10 +24,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HS_HD __host__ __device__ __forceinline__
-#define HS_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define HS_HD inline
-#define HS_HD_NOINLINE
 #endif
 
 namespace hs {
@@ -82,7 +80,7 @@ HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
     c = h[9] >> 25; r.v[9] = (u32)h[9] & HS_M25;
     u64 t = (u64)r.v[0] + 19 * c;              // c < 2^39
     r.v[0] = (u32)t & HS_M26;
-    t = (t >> 26) + r.v[1];                    // < 2^26: limb 1 keeps <= 1 bit of slack
+    t = (t >> 26) + r.v[1];                    // t >> 26 < 2^18
     r.v[1] = (u32)t & HS_M25;
     r.v[2] += (u32)(t >> 25);
 }

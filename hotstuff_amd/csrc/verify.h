@@ -4,7 +4,8 @@
 //                            small-order flag; the R lane also hashes
 //                            k = SHA-512(R||A||M) mod L, range-checks s and recodes both scalars.
 //   stage 2  verify_lane   : one lane per signature; [k](-A) + [s]B by a joint
-//                            fixed-window (signed radix-16) double-scalar multiplication
+//                            fixed-window double-scalar multiplication (signed radix 16 on -A,
+//                            signed radix 256 on B from a 129-entry L2-resident table)
 //                            - lane-uniform control flow, table entries chosen per lane -
 //                            then the projective comparison with R.
 //
@@ -13,7 +14,9 @@
 //   mode HS_MODE_BATCH   = the per-signature cofactorless equation that
 //                          dalek::verify_batch sums  (crypto/src/lib.rs:206-219);
 //                          a batch verdict is the AND over its signatures
-//                          (classes i and ii exact, class iii -> reject).
+//                          (exact wherever dalek is deterministic; on torsion-carrying inputs,
+//                          where dalek's answer depends on its random z_i, this per-signature
+//                          verdict is returned - DESIGN.md section 3).
 #pragma once
 #include "ge25519.h"
 #include "sha512_sc.h"
