@@ -204,9 +204,13 @@ def main():
     ap.add_argument("--large-committee", type=int, default=100000, help="validators in the cached large-QC extra")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
     ap.add_argument("--event-stride", type=int, default=1, help="record HIP events on every k-th call per context")
-    ap.add_argument("--partitions", type=int, default=int(os.environ.get("HS_BENCH_PARTITIONS", "16")),
-                    help="CU-masked streams: split the chip into this many slices (0 = plain streams)")
+    ap.add_argument("--partitions", type=int, default=None,
+                    help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
+                         "default 16 for batches up to 4,096 signatures, 0 above)")
     args = ap.parse_args()
+    if args.partitions is None:
+        env = os.environ.get("HS_BENCH_PARTITIONS")
+        args.partitions = int(env) if env is not None else (16 if args.batch <= 4096 else 0)
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to
@@ -399,7 +403,7 @@ def main():
     traffic = None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        kname = _lib.lib().hs_ed25519_dominant_kernel().decode()
+        kname = _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
         if pmc.get("signatures_per_launch") == n and kname in pmc["kernels"]:
             traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
     except Exception:
@@ -425,7 +429,7 @@ def main():
                 "exchange": "RCCL all-gather of per-shard accept bitmaps" if exchange else "none (1 GPU)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel().decode(),
+                "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
                 "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
                 "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"

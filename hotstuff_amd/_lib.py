@@ -43,6 +43,8 @@ def lib():
                 l.hs_ed25519_last_error.restype = ctypes.c_char_p
                 l.hs_ed25519_dominant_kernel.argtypes = []
                 l.hs_ed25519_dominant_kernel.restype = ctypes.c_char_p
+                l.hs_ed25519_dominant_kernel_for.argtypes = [sz]
+                l.hs_ed25519_dominant_kernel_for.restype = ctypes.c_char_p
                 l.hs_ed25519_verify_shared.argtypes = [vp, vp, vp, sz, u32, vp]
                 l.hs_ed25519_verify_shared.restype = ctypes.c_int
                 l.hs_ed25519_verify_multi.argtypes = [vp, vp, vp, sz, u32, vp]

@@ -475,10 +475,12 @@ extern "C" int hs_ed25519_set_kernel(int which) {
     if ((which >= 0 && which <= 3) || which == 10) g_kernel.store(which);
     return old;
 }
-extern "C" const char *hs_ed25519_dominant_kernel(void) {
-    const int k = g_kernel.load();
+extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
+    const int forced = g_kernel.load();
+    const int k = forced == 10 ? 3 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1));
     return k == 1 ? "k_verify" : (k == 2 ? "k_verify_quad" : "k_verify_fused");
 }
+extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 

@@ -171,7 +171,8 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
 int hs_ed25519_set_kernel(int which);
 
 /* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
-const char *hs_ed25519_dominant_kernel(void);
+const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
+const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 
 #ifdef __cplusplus
 }
