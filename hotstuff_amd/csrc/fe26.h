@@ -28,6 +28,16 @@
 #define HS_HD inline
 #endif
 
+// HS_BOUND_CHECK (host builds of tests/emu only): every field operation asserts the
+// preconditions documented above and that no 32- / 64-bit intermediate wraps.
+#if defined(HS_BOUND_CHECK) && !defined(__HIPCC__)
+#include <cstdio>
+#include <cstdlib>
+#define HS_CHECK(cond, what) do { if (!(cond)) { std::fprintf(stderr, "HS_BOUND_CHECK failed: %s (%s:%d)\n", what, __FILE__, __LINE__); std::abort(); } } while (0)
+#else
+#define HS_CHECK(cond, what) do { } while (0)
+#endif
+
 namespace hs {
 
 typedef uint32_t u32;
@@ -46,17 +56,26 @@ HS_HD void fe_1(fe &r) { fe_0(r); r.v[0] = 1; }
 
 HS_HD void fe_add(fe &r, const fe &a, const fe &b) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+    for (int i = 0; i < 10; i++) {
+        HS_CHECK((u64)a.v[i] + b.v[i] < (1ull << 32), "fe_add overflows a limb");
+        r.v[i] = a.v[i] + b.v[i];
+    }
 }
 // r = a - b + 2p; b must be reduced.
 HS_HD void fe_sub(fe &r, const fe &a, const fe &b) {
-    r.v[0] = a.v[0] + 0x7ffffdau - b.v[0];
 #pragma unroll
-    for (int i = 1; i < 10; i++) r.v[i] = a.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - b.v[i];
+    for (int i = 0; i < 10; i++) {
+        const u32 bias = i == 0 ? 0x7ffffdau : ((i & 1) ? 0x3fffffeu : 0x7fffffeu);
+        HS_CHECK(b.v[i] <= bias, "fe_sub: subtrahend limb exceeds the 2p bias (not reduced)");
+        HS_CHECK((u64)a.v[i] + bias < (1ull << 32), "fe_sub overflows a limb");
+        r.v[i] = a.v[i] + bias - b.v[i];
+    }
 }
 // 32-bit carry pass: any limbs < 2^31 -> reduced.
 HS_HD void fe_carry(fe &r) {
     u32 c;
+#pragma unroll
+    for (int i = 0; i < 10; i++) HS_CHECK(r.v[i] < 0xf0000000u, "fe_carry: limb too large for a 32-bit carry pass");
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         if (i & 1) { c = r.v[i] >> 25; r.v[i] &= HS_M25; }
@@ -88,7 +107,11 @@ HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
 HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
     u32 g19[10], f2[10];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i]; }
+    for (int i = 0; i < 10; i++) {
+        HS_CHECK((u64)19 * g.v[i] < (1ull << 32), "fe_mul: 19*g does not fit 32 bits (second operand above ~3.3x)");
+        HS_CHECK((u64)2 * f.v[i] < (1ull << 32), "fe_mul: 2*f does not fit 32 bits");
+        g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i];
+    }
     u64 h[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -99,8 +122,10 @@ HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
             const bool wrap = i > k;
             const u32 fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
             const u32 gj = wrap ? g19[j] : g.v[j];
+            HS_CHECK(acc + (u64)fi * gj >= acc, "fe_mul: 64-bit column accumulator wrapped");
             acc += (u64)fi * gj;
         }
+        HS_CHECK(acc < (1ull << 63), "fe_mul: column too large for the carry chain");
         h[k] = acc;
     }
     fe_reduce_cols(r, h);
@@ -111,7 +136,11 @@ HS_HD void fe_sq(fe &r, const fe &f) {
     // x2 more when both odd, x19 when i+j >= 10.
     u32 f2[10], f19[10], f38[10];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i]; }
+    for (int i = 0; i < 10; i++) {
+        HS_CHECK((u64)19 * f.v[i] < (1ull << 32), "fe_sq: 19*f does not fit 32 bits");
+        HS_CHECK(!(i & 1) || (u64)38 * f.v[i] < (1ull << 32), "fe_sq: 38*f (odd limb) does not fit 32 bits");
+        f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i];
+    }
     u64 h[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -126,15 +155,18 @@ HS_HD void fe_sq(fe &r, const fe &f) {
                 // f_i^2 * (2 if odd) * (19 if wrap)
                 const u32 a = oo ? f2[i] : f.v[i];
                 const u32 b = wrap ? f19[i] : f.v[i];
+                HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
                 acc += (u64)a * b;
             } else {
                 // 2 f_i f_j * (2 if both odd) * (19 if wrap); keep each factor < 2^32:
                 // a = 2 f_i ; b = f_j * (1 | 2 | 19 | 38)
                 const u32 a = f2[i];
                 const u32 b = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]);
+                HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
                 acc += (u64)a * b;
             }
         }
+        HS_CHECK(acc < (1ull << 63), "fe_sq: column too large for the carry chain");
         h[k] = acc;
     }
     fe_reduce_cols(r, h);

@@ -37,6 +37,15 @@ void emu_fe_invert(const uint8_t *a, uint8_t *r) {
 void emu_fe_roundtrip(const uint8_t *a, uint8_t *r) {
     u32 wa[8], wr[8]; load_words(wa, a, 8); fe x; fe_from_words(x, wa); fe_to_words(wr, x); memcpy(r, wr, 32);
 }
+// deliberately breaks a documented bound (second multiplication operand far above 3x): the
+// HS_BOUND_CHECK build must abort here, the plain build silently computes garbage
+void emu_violate_bounds(uint8_t *r) {
+    fe x; for (int i = 0; i < 10; i++) x.v[i] = 0x03ffffff;
+    fe y = x;
+    for (int k = 0; k < 4; k++) fe_add(y, y, y);      // 16x
+    fe z; fe_mul(z, x, y);
+    u32 w[8]; fe_to_words(w, z); memcpy(r, w, 32);
+}
 void emu_sha512_96(const uint8_t *in, uint8_t *out) { u32 wi[24], wo[16]; load_words(wi, in, 24); sha512_96(wo, wi); memcpy(out, wo, 64); }
 void emu_tc_vote_digest(uint64_t round, uint64_t hq, uint8_t *out) { u32 w[8]; tc_vote_digest(w, round, hq); memcpy(out, w, 32); }
 void emu_sc_reduce512(const uint8_t *in, uint8_t *out) { u32 wi[16], wo[8]; load_words(wi, in, 16); sc_reduce512(wo, wi); memcpy(out, wo, 32); }
