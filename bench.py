@@ -24,7 +24,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 `int_roofline` (extra) prices the same kernel against the measured
                 v_mad_u64_u32 issue rate.
   extras        `committee_cached` (same workload with the keys registered as a key set, and the
-                100,000-validator QC on one GPU), `qc_verify_latency` (p50 at N = 10,000).
+                100,000-validator QC on one GPU), `qc_verify_latency` (p50 at N = 10,000),
+                `streamed_rounds` (configs[4]: rounds from host memory through the pinned ring,
+                one hipGraph launch each).
   cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"),
                 timed on the host's cores on a bounded sample of the same workload.
 """
@@ -188,6 +190,55 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
             "committee_cached": {"keys": validators, "keyset_hbm_bytes": ks_bytes, "keyset_build_ms": round(build_ms, 1),
                                  "p50_ms_host_api": round(med(hostc) * 1e3, 4),
                                  "p50_ms_device_resident": round(med(devc) * 1e3, 4)}}
+
+
+def streamed_rounds(_lib, synth, validators=10000, slots=4, seconds=0.6):
+    """BASELINE configs[4]: QC rounds streamed from host memory by ONE host thread (the
+    reference's single Core task) through the round ring - pinned slots, H2D / kernel / D2H of
+    different slots overlapped on separate HIP streams, one hipGraph launch per round (and, for
+    comparison, the same three operations issued to the stream one by one).  PCIe-inclusive."""
+    import numpy as np
+    n = 2 * validators // 3 + 1
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    out = {"n_validators": validators, "signatures_per_round": n, "slots": slots, "host_threads": 1,
+           "target_signatures_per_s": 1e6}
+    for cached in (False, True):
+        ks = _lib.KeySet(keys) if cached else None
+        kb = ks.indices(keys)[0] if cached else pk
+        src = [np.frombuffer(x, dtype=np.uint8) for x in (dg, kb, sg)]
+        for use_graph in (True, False):
+            ring = _lib.RoundRing(n, slots=slots, keyset=ks, use_graph=use_graph)
+            inflight, lat, t_sub, done, r = set(), [], {}, 0, 0
+            warm = 2 * slots
+            t0 = t_end = None
+            while t_end is None or time.perf_counter() < t_end or inflight:
+                if r == warm:
+                    t0 = time.perf_counter(); t_end = t0 + seconds; done = 0; lat = []
+                slot = r % slots
+                if slot in inflight:
+                    ok, _ = ring.wait(slot, want_bitmap=False)
+                    lat.append(time.perf_counter() - t_sub[slot])
+                    assert ok, "streamed round rejected"
+                    inflight.discard(slot)
+                    done += 1
+                if t_end is None or time.perf_counter() < t_end:
+                    d, k, s_ = ring.begin(slot, n, True)
+                    d[:] = src[0]; k[:] = src[1]; s_[:] = src[2]
+                    t_sub[slot] = time.perf_counter()
+                    ring.submit(slot, _lib.BATCH)
+                    inflight.add(slot)
+                r += 1
+            wall = time.perf_counter() - t0
+            captures, _ = ring.stats()
+            ring.close()
+            lat.sort()
+            out[("key_cache" if cached else "cold") + ("_hipgraph" if use_graph else "_stream_ops")] = {
+                "signatures_per_s": round(done * n / wall, 1), "rounds": done,
+                "submit_to_verdict_p50_ms": round(lat[len(lat) // 2] * 1e3, 4), "graph_captures": captures}
+        if ks:
+            ks.close()
+    return out
 
 
 def main():
@@ -454,6 +505,7 @@ def main():
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
             out["qc_verify_latency"] = qc_latency(_lib, torch, synth, dev)
+            out["streamed_rounds"] = streamed_rounds(_lib, synth)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)

@@ -91,6 +91,21 @@ def lib():
                 l.hs_ed25519_verify_multi_cached.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_cached.argtypes = [vp, vp, vp, sz, vp, vp, sz, u32, vp, vp, vp]
                 l.hs_ed25519_verify_device_cached.restype = ctypes.c_int
+                pp = ctypes.POINTER(ctypes.c_void_p)
+                l.hs_ed25519_ring_create.argtypes = [pp, sz, ctypes.c_uint, vp, u32]
+                l.hs_ed25519_ring_create.restype = ctypes.c_int
+                l.hs_ed25519_ring_destroy.argtypes = [vp]
+                l.hs_ed25519_ring_destroy.restype = None
+                l.hs_ed25519_ring_begin.argtypes = [vp, ctypes.c_uint, sz, sz, pp, pp, pp]
+                l.hs_ed25519_ring_begin.restype = ctypes.c_int
+                l.hs_ed25519_ring_submit.argtypes = [vp, ctypes.c_uint, u32]
+                l.hs_ed25519_ring_submit.restype = ctypes.c_int
+                l.hs_ed25519_ring_poll.argtypes = [vp, ctypes.c_uint]
+                l.hs_ed25519_ring_poll.restype = ctypes.c_int
+                l.hs_ed25519_ring_wait.argtypes = [vp, ctypes.c_uint, vp]
+                l.hs_ed25519_ring_wait.restype = ctypes.c_int
+                l.hs_ed25519_ring_stats.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+                l.hs_ed25519_ring_stats.restype = ctypes.c_int
                 _lib = l
     return _lib
 
@@ -288,6 +303,72 @@ class DeviceContext:
     def close(self):
         if getattr(self, "_h", None):
             lib().hs_ed25519_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+RING_NO_GRAPH = 1
+
+
+class RoundRing:
+    """hs_ed25519_ring: streamed rounds (BASELINE config 5).  `slots` rounds in flight, each one
+    hipGraph launch (pinned H2D -> kernels -> D2H) on its own stream.
+
+        dg, keys, sg = ring.begin(slot, n, shared=True)   # numpy uint8 views of PINNED memory
+        dg[:] = ...; keys[:] = ...; sg[:] = ...            # write the packed tuples in place
+        ring.submit(slot, mode)                            # asynchronous
+        ok, bitmap = ring.wait(slot)
+
+    With a key set `keys` is n little-endian uint32 indices (4n bytes), else n*32 key bytes."""
+
+    def __init__(self, slot_batch, slots=4, keyset=None, use_graph=True):
+        ensure_init()
+        self._h = ctypes.c_void_p()
+        self.keyset = keyset            # keeps the key set alive as long as the ring
+        self.slot_batch, self.slots = int(slot_batch), int(slots)
+        self._n = [0] * self.slots
+        check(lib().hs_ed25519_ring_create(ctypes.byref(self._h), self.slot_batch, self.slots,
+                                           keyset.handle if keyset is not None else None,
+                                           0 if use_graph else RING_NO_GRAPH), "hs_ed25519_ring_create")
+
+    def begin(self, slot, n, shared):
+        import numpy as np
+        d, k, s = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib().hs_ed25519_ring_begin(self._h, int(slot), int(n), 0 if shared else 32, ctypes.byref(d),
+                                          ctypes.byref(k), ctypes.byref(s)), "hs_ed25519_ring_begin")
+        self._n[slot] = int(n)
+
+        def view(p, nbytes):
+            return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_ubyte)), shape=(nbytes,))
+        return (view(d, 32 if shared else 32 * n), view(k, (4 if self.keyset is not None else 32) * n), view(s, 64 * n))
+
+    def submit(self, slot, mode):
+        check(lib().hs_ed25519_ring_submit(self._h, int(slot), int(mode)), "hs_ed25519_ring_submit")
+
+    def poll(self, slot):
+        return check(lib().hs_ed25519_ring_poll(self._h, int(slot)), "hs_ed25519_ring_poll") == 1
+
+    def wait(self, slot, want_bitmap=True):
+        n = self._n[slot]
+        bm = (ctypes.c_ubyte * ((n + 7) // 8))() if want_bitmap else None
+        rc = check(lib().hs_ed25519_ring_wait(self._h, int(slot), ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
+                   "hs_ed25519_ring_wait")
+        return rc == 1, (bytes(bm) if bm is not None else None)
+
+    def stats(self):
+        """(graph captures / updates, rounds submitted)"""
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().hs_ed25519_ring_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "hs_ed25519_ring_stats")
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hs_ed25519_ring_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -725,8 +725,9 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
         HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached");
     else
-        HS_HIP(hipExtLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st,
-                                  ev ? ev[0] : nullptr, ev ? ev[2] : nullptr, 0), "launch k_verify_cached_5w");
+        HS_HIP(ev ? hipExtLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st, ev[0], ev[2], 0)
+                  : hipLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st),
+               "launch k_verify_cached_5w");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
@@ -906,4 +907,159 @@ extern "C" int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t
                                            const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint8_t *bitmap) {
     if (!ks) return fail(HS_ED25519_E_ARG, "verify_tc_cached: null key set");
     return verify_host_tc(ks, round, high_qc_rounds, key_idx, sigs, n, bitmap);
+}
+
+// ---- round ring: streamed rounds through pinned slots, one hipGraph launch per round -----------
+// BASELINE config 5.  A slot owns a stream, pinned host staging and device buffers.  The caller
+// writes a round's packed tuples straight into the slot's pinned memory (begin), submits it
+// (one hipGraphLaunch: H2D copy -> verification kernel(s) -> D2H copy of the bitmap) and collects
+// the verdict later (wait / poll); slots in flight overlap their copies and kernels on separate
+// streams.  The graph of a slot is captured once and re-launched while (n, digest form, mode) stay
+// the same - the steady state of a fixed committee, whose QCs carry exactly 2f+1 votes - and is
+// updated in place (hipGraphExecUpdate) when they change.
+struct ring_slot {
+    hs_ed25519_ctx *ctx = nullptr;
+    hipGraphExec_t exec = nullptr;
+    size_t g_n = 0, g_stride = 0; uint32_t g_mode = 0; int g_sel = -1;     // what `exec` was captured for
+    size_t n = 0, stride = 0, off_key = 0, off_sig = 0, in_bytes = 0;       // the round begun in this slot
+    bool begun = false, inflight = false;
+};
+struct hs_ed25519_ring {
+    std::vector<ring_slot> slots;
+    size_t cap = 0;
+    const hs_ed25519_keyset *ks = nullptr;
+    bool use_graph = true;
+    size_t captures = 0, launches = 0;
+};
+
+extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
+    if (!r) return;
+    for (ring_slot &s : r->slots) {
+        if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
+        if (s.exec) (void)hipGraphExecDestroy(s.exec);
+        if (s.ctx) hs_ed25519_ctx_destroy(s.ctx);
+    }
+    delete r;
+}
+
+extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, unsigned slots,
+                                      const hs_ed25519_keyset *ks, uint32_t flags) {
+    if (!out || slot_batch == 0 || slots == 0 || slots > 64 || slot_batch > 0x3fffffffu || (flags & ~1u))
+        return fail(HS_ED25519_E_ARG, "ring_create: bad arguments");
+    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    hs_ed25519_ring *r = new (std::nothrow) hs_ed25519_ring();
+    if (!r) return fail(HS_ED25519_E_NOMEM, "ring_create: out of memory");
+    r->cap = round_up(slot_batch, 64); r->ks = ks; r->use_graph = !(flags & HS_ED25519_RING_NO_GRAPH);
+    r->slots.resize(slots);
+    for (ring_slot &s : r->slots) {
+        int rc = hs_ed25519_ctx_create(&s.ctx, 64);
+        if (!rc) rc = ctx_reserve(s.ctx, r->cap, true);      // all allocation happens here, none under capture
+        if (rc) { hs_ed25519_ring_destroy(r); return rc; }
+    }
+    *out = r;
+    return 0;
+}
+
+extern "C" int hs_ed25519_ring_begin(hs_ed25519_ring *r, unsigned slot, size_t n, size_t digest_stride,
+                                     uint8_t **digests, uint8_t **keys, uint8_t **sigs) {
+    if (!r || slot >= r->slots.size() || !digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "ring_begin: bad arguments");
+    if (n == 0 || n > r->cap) return fail(HS_ED25519_E_ARG, "ring_begin: n must be in [1, slot_batch]");
+    if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "ring_begin: bad digest_stride");
+    ring_slot &s = r->slots[slot];
+    if (s.inflight) return fail(HS_ED25519_E_ARG, "ring_begin: slot still in flight (wait for it first)");
+    // one contiguous transfer: [digests][keys: 32n bytes, or 4n index bytes with a key set][sigs: 64n]
+    const size_t dg_bytes = digest_stride ? 32 * n : 32;
+    s.n = n; s.stride = digest_stride;
+    s.off_key = round_up(dg_bytes, 16);
+    s.off_sig = round_up(s.off_key + (r->ks ? 4 : 32) * n, 16);
+    s.in_bytes = s.off_sig + 64 * n;
+    s.begun = true;
+    *digests = s.ctx->h_in; *keys = s.ctx->h_in + s.off_key; *sigs = s.ctx->h_in + s.off_sig;
+    return 0;
+}
+
+static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
+    hs_ed25519_ctx *c = s.ctx;
+    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, s.in_bytes, hipMemcpyHostToDevice, c->stream), "ring H2D");
+    int rc;
+    if (r->ks)
+        rc = hs_ed25519_verify_device_cached(c, r->ks, c->d_in, s.stride, (const uint32_t *)(c->d_in + s.off_key),
+                                             c->d_in + s.off_sig, s.n, mode, c->d_out, nullptr, c->stream);
+    else
+        rc = hs_ed25519_verify_device(c, c->d_in, s.stride, c->d_in + s.off_key, c->d_in + s.off_sig, s.n, mode,
+                                      c->d_out, nullptr, c->stream);
+    if (rc) return rc;
+    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(s.n), hipMemcpyDeviceToHost, c->stream), "ring D2H");
+    return 0;
+}
+
+extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_t mode) {
+    if (!r || slot >= r->slots.size() || mode > 1) return fail(HS_ED25519_E_ARG, "ring_submit: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.begun || s.inflight) return fail(HS_ED25519_E_ARG, "ring_submit: slot not begun / already in flight");
+    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    hipStream_t st = s.ctx->stream;
+    if (!r->use_graph) {
+        int rc = ring_enqueue(r, s, mode);
+        if (rc) return rc;
+    } else {
+        const int sel = g_kernel.load();
+        if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode || s.g_sel != sel) {
+            hipGraph_t g = nullptr;
+            HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            int rc = ring_enqueue(r, s, mode);
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipStreamEndCapture", e);
+            if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
+                hipGraphNode_t bad = nullptr;
+                hipGraphExecUpdateResult res;
+                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
+            }
+            if (!s.exec) {
+                e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
+                if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
+            }
+            (void)hipGraphDestroy(g);
+            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode; s.g_sel = sel;
+            r->captures++;
+        }
+        HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
+    }
+    r->launches++;
+    s.inflight = true; s.begun = false;
+    return 0;
+}
+
+// 1 = the slot's round has completed (or nothing is in flight), 0 = still running
+extern "C" int hs_ed25519_ring_poll(hs_ed25519_ring *r, unsigned slot) {
+    if (!r || slot >= r->slots.size()) return fail(HS_ED25519_E_ARG, "ring_poll: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.inflight) return 1;
+    hipError_t e = hipStreamQuery(s.ctx->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(HS_ED25519_E_DEVICE, "hipStreamQuery", e);
+}
+
+extern "C" int hs_ed25519_ring_wait(hs_ed25519_ring *r, unsigned slot, uint8_t *bitmap) {
+    if (!r || slot >= r->slots.size()) return fail(HS_ED25519_E_ARG, "ring_wait: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.inflight) return fail(HS_ED25519_E_ARG, "ring_wait: nothing submitted in this slot");
+    hipError_t e = hipStreamSynchronize(s.ctx->stream);
+    s.inflight = false;
+    if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "ring stream sync", e);
+    const uint8_t *bm = s.ctx->h_out;
+    const size_t n = s.n, whole = n / 8;
+    if (bitmap) memcpy(bitmap, bm, (n + 7) / 8);
+    bool ok = true;
+    for (size_t i = 0; i < whole && ok; i++) ok = bm[i] == 0xff;
+    if (ok && (n & 7)) ok = bm[whole] == (uint8_t)((1u << (n & 7)) - 1);
+    return ok ? 1 : 0;
+}
+
+extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {
+    if (!r || !graph_captures || !launches) return fail(HS_ED25519_E_ARG, "ring_stats: null");
+    *graph_captures = r->captures; *launches = r->launches;
+    return 0;
 }

@@ -148,6 +148,36 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
                                        const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap, uint32_t *d_nreject,
                                        void *stream);
 
+/* ---- round ring: streamed rounds (BASELINE config 5) -----------------------------------------
+ * The reference's Core task verifies one certificate per message as rounds stream by
+ * (consensus/src/core.rs:379, 401 -> QC::verify messages.rs:197).  A ring keeps `slots` rounds in
+ * flight: each slot owns a HIP stream, PINNED host staging and device buffers, and its round is
+ * one hipGraph launch (H2D copy -> verification kernel(s) -> D2H copy of the bitmap), captured
+ * once and re-launched while (n, digest form, mode) repeat - the steady state of a fixed
+ * committee - and updated in place when they change.  Copies and kernels of different slots
+ * overlap.  Protocol per slot:  begin (get the pinned pointers, write the packed tuples in
+ * place - no second host copy) -> submit (asynchronous) -> poll / wait (verdict + bitmap).
+ *   ks != NULL: the ring verifies through that key set; `keys` then holds n uint32 indices,
+ *               otherwise n*32 key bytes.
+ *   digest_stride 0: `digests` holds one shared 32-byte digest; 32: one per signature.
+ *   flags: HS_ED25519_RING_NO_GRAPH issues the same three operations to the stream one by one
+ *          (A/B measurements).
+ * A ring is driven by one thread at a time (the reference's single Core task); different rings
+ * are independent.  wait returns 1 / 0 / <0 like every verify call; poll returns 1 when the
+ * slot's round has completed, 0 while it runs. */
+#define HS_ED25519_RING_NO_GRAPH 1u
+typedef struct hs_ed25519_ring hs_ed25519_ring;
+int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, unsigned slots,
+                           const hs_ed25519_keyset *ks, uint32_t flags);
+void hs_ed25519_ring_destroy(hs_ed25519_ring *ring);
+int hs_ed25519_ring_begin(hs_ed25519_ring *ring, unsigned slot, size_t n, size_t digest_stride,
+                          uint8_t **digests, uint8_t **keys, uint8_t **sigs);
+int hs_ed25519_ring_submit(hs_ed25519_ring *ring, unsigned slot, uint32_t mode);
+int hs_ed25519_ring_poll(hs_ed25519_ring *ring, unsigned slot);
+int hs_ed25519_ring_wait(hs_ed25519_ring *ring, unsigned slot, uint8_t *bitmap);
+/* Number of graph captures / updates and of rounds submitted so far. */
+int hs_ed25519_ring_stats(const hs_ed25519_ring *ring, size_t *graph_captures, size_t *launches);
+
 /* Profiling: keep a ring of `slots` HIP-event triples attached to the kernel dispatches of each
  * hs_ed25519_verify_device* call on `ctx` (hipExtLaunchKernel start/stop events, on the launch
  * stream; 0 = off).  After the

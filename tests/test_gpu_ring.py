@@ -1,0 +1,196 @@
+"""GPU parity of the round ring (hs_ed25519_ring_*: pinned slots, one hipGraph launch per
+round - BASELINE config 5) against the oracle, through the C-ABI."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+
+pytestmark = pytest.mark.gpu
+CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    assert torch.cuda.is_available()
+    _lib.init(0, 8192)
+    yield
+
+
+def fill(ring, slot, dg, keys, sg, n, shared):
+    d, k, s = ring.begin(slot, n, shared)
+    d[:] = np.frombuffer(dg, dtype=np.uint8)
+    k[:] = np.frombuffer(keys, dtype=np.uint8)
+    s[:] = np.frombuffer(sg, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_rounds_of_every_shape_vs_oracle(oracle, use_graph):
+    """Rounds of different sizes, digest forms and modes through three slots, several in flight;
+    every bitmap equals the oracle's.  Each change of (n, form, mode) re-captures / updates the
+    slot's graph."""
+    ring = _lib.RoundRing(2048, slots=3, use_graph=use_graph)
+    cases = [(n, shared, mode) for n in (1, 63, 64, 65, 1000, 2048) for shared in (True, False)
+             for mode in (_lib.BATCH, _lib.STRICT)]
+    pending = {}
+    for i, (n, shared, mode) in enumerate(cases):
+        slot = i % 3
+        if slot in pending:
+            check_round(oracle, ring, slot, *pending.pop(slot))
+        dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)
+        fill(ring, slot, dg, pk, sg, n, shared)
+        ring.submit(slot, mode)
+        pending[slot] = (dg, pk, sg, n, shared, mode, bad)
+    for slot, args in pending.items():
+        check_round(oracle, ring, slot, *args)
+    captures, launches = ring.stats()
+    assert launches == len(cases)
+    assert captures == (len(cases) if use_graph else 0)
+    ring.close()
+
+
+def check_round(oracle, ring, slot, dg, pk, sg, n, shared, mode, bad):
+    ok, bm = ring.wait(slot)
+    got = bits(bm, n)
+    assert got == oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, mode)
+    assert [i for i in range(n) if not got[i]] == bad
+    assert ok == (not bad)
+
+
+def test_steady_state_replays_one_graph_per_slot_and_follows_the_data(oracle):
+    """The steady state: the same (n, form, mode) every round.  The graph is captured once per
+    slot and re-launched; what it verifies is whatever the pinned slot holds at submit time."""
+    n, slots, rounds = 667, 4, 40
+    ring = _lib.RoundRing(1024, slots=slots)
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    expect = {}
+    for r in range(rounds):
+        slot = r % slots
+        if slot in expect:
+            ok, bm = ring.wait(slot)
+            got = bits(bm, n)
+            assert [i for i in range(n) if not got[i]] == expect[slot] and ok == (not expect[slot])
+        sg_r = bytearray(sg)
+        bad = sorted({(7 * r + 3) % n, (13 * r) % n}) if r % 3 else []
+        for i in bad:
+            sg_r[64 * i + (r % 64)] ^= 1 << (r % 8)
+        fill(ring, slot, dg, pk, bytes(sg_r), n, True)
+        ring.submit(slot, _lib.BATCH)
+        expect[slot] = bad
+    for slot, bad in expect.items():
+        ok, bm = ring.wait(slot)
+        got = bits(bm, n)
+        assert [i for i in range(n) if not got[i]] == bad
+    assert ring.stats() == (slots, rounds)
+    ring.close()
+
+
+def test_ring_over_the_committee_key_cache(oracle):
+    n = 500
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    ring = _lib.RoundRing(512, slots=2, keyset=ks)
+    dg2, pk2, sg2, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+    packed, idx = ks.indices([pk2[32 * i:32 * i + 32] for i in range(n)])
+    for slot, mode in ((0, _lib.BATCH), (1, _lib.STRICT)):
+        fill(ring, slot, dg2, packed, sg2, n, True)
+        ring.submit(slot, mode)
+    for slot, mode in ((0, _lib.BATCH), (1, _lib.STRICT)):
+        ok, bm = ring.wait(slot)
+        got = bits(bm, n)
+        assert not ok and [i for i in range(n) if not got[i]] == bad
+        assert got == oracle_verify_many(oracle, dg2, 0, pk2, sg2, n, mode)
+    # an all-valid round reports 1
+    packed, _ = ks.indices(keys)
+    fill(ring, 0, dg, packed, sg, n, True)
+    ring.submit(0, _lib.STRICT)
+    ok, bm = ring.wait(0)
+    assert ok and all(bits(bm, n))
+    ring.close()
+    ks.close()
+
+
+def test_ring_protocol_errors_are_errors():
+    ring = _lib.RoundRing(128, slots=2)
+    with pytest.raises(_lib.EngineError):
+        ring.submit(0, _lib.BATCH)                       # nothing begun
+    with pytest.raises(_lib.EngineError):
+        ring.begin(0, 129, True)                         # beyond the slot's capacity
+    with pytest.raises(_lib.EngineError):
+        ring.begin(0, 0, True)
+    with pytest.raises(_lib.EngineError):
+        ring.begin(2, 1, True)                           # no such slot
+    with pytest.raises(_lib.EngineError):
+        ring.wait(1)                                     # nothing submitted
+    dg, pk, sg = synth.make_batch(8, shared=True, cache_dir=CACHE)
+    fill(ring, 0, dg, pk, sg, 8, True)
+    with pytest.raises(_lib.EngineError):
+        ring.submit(0, 2)                                # bad mode: still begun, not in flight
+    ring.submit(0, _lib.STRICT)
+    with pytest.raises(_lib.EngineError):
+        ring.begin(0, 8, True)                           # in flight: wait first
+    with pytest.raises(_lib.EngineError):
+        ring.submit(0, _lib.STRICT)
+    ok, bm = ring.wait(0)
+    assert ok and bm == b"\xff"
+    assert ring.poll(0) and ring.poll(1)
+    ring.close()
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_streamed_rounds_single_thread_sustained_rate(cached):
+    """BASELINE config 5: 10,000-validator QC rounds (6,667 signatures) streamed from ONE host
+    thread - the reference's single Core task - through a 4-slot ring: fill the pinned slot,
+    one graph launch, collect the oldest.  Must clear 1 M signatures/s by a wide margin."""
+    n, slots = 6667, 4
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    ks = None
+    keys_bytes = pk
+    if cached:
+        keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+        ks = _lib.KeySet(keys)
+        keys_bytes, _ = ks.indices(keys)
+    bad_sg = bytearray(sg); bad_sg[64 * 100 + 1] ^= 1; bad_sg = bytes(bad_sg)
+    src = [np.frombuffer(x, dtype=np.uint8) for x in (dg, keys_bytes, sg, bad_sg)]
+    results = {}
+    for use_graph in (True, False):
+        ring = _lib.RoundRing(n, slots=slots, keyset=ks, use_graph=use_graph)
+        expect, lat, t_sub = {}, [], {}
+        done = 0
+        t_end = time.perf_counter() + 1.0
+        t0 = time.perf_counter()
+        r = 0
+        while time.perf_counter() < t_end or expect:
+            slot = r % slots
+            if slot in expect:
+                ok, _ = ring.wait(slot, want_bitmap=False)
+                lat.append(time.perf_counter() - t_sub[slot])
+                assert ok == expect.pop(slot)
+                done += 1
+            if time.perf_counter() < t_end:
+                use_bad = r % 7 == 3
+                d, k, s = ring.begin(slot, n, True)
+                d[:] = src[0]; k[:] = src[1]; s[:] = src[3 if use_bad else 2]
+                t_sub[slot] = time.perf_counter()
+                ring.submit(slot, _lib.BATCH)
+                expect[slot] = not use_bad
+            r += 1
+        wall = time.perf_counter() - t0
+        lat.sort()
+        results[use_graph] = done * n / wall
+        print("streamed rounds (%s, %s): %.1f M signatures/s from one host thread, %d rounds, submit->verdict p50 %.3f ms"
+              % ("key cache" if cached else "cold", "hipGraph" if use_graph else "plain stream ops",
+                 results[use_graph] / 1e6, done, lat[len(lat) // 2] * 1e3))
+        if use_graph:
+            assert ring.stats()[0] == slots
+        ring.close()
+    assert results[True] > 1e6 and results[False] > 1e6
+    if ks:
+        ks.close()
