@@ -195,8 +195,9 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
 def streamed_rounds(_lib, synth, validators=10000, slots=4, seconds=0.6):
     """BASELINE configs[4]: QC rounds streamed from host memory by ONE host thread (the
     reference's single Core task) through the round ring - pinned slots, H2D / kernel / D2H of
-    different slots overlapped on separate HIP streams, one hipGraph launch per round (and, for
-    comparison, the same three operations issued to the stream one by one).  PCIe-inclusive."""
+    different slots overlapped on separate HIP streams; a round travels as one hipGraph launch,
+    as the same three operations issued to the stream one by one, or with no copies at all (the
+    kernels read the pinned slot over PCIe).  PCIe-inclusive."""
     import numpy as np
     n = 2 * validators // 3 + 1
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
@@ -207,8 +208,8 @@ def streamed_rounds(_lib, synth, validators=10000, slots=4, seconds=0.6):
         ks = _lib.KeySet(keys) if cached else None
         kb = ks.indices(keys)[0] if cached else pk
         src = [np.frombuffer(x, dtype=np.uint8) for x in (dg, kb, sg)]
-        for use_graph in (True, False):
-            ring = _lib.RoundRing(n, slots=slots, keyset=ks, use_graph=use_graph)
+        for kind in ("graph", "stream-ops", "zero-copy"):
+            ring = _lib.RoundRing(n, slots=slots, keyset=ks, kind=kind)
             inflight, lat, t_sub, done, r = set(), [], {}, 0, 0
             warm = 2 * slots
             t0 = t_end = None
@@ -233,7 +234,7 @@ def streamed_rounds(_lib, synth, validators=10000, slots=4, seconds=0.6):
             captures, _ = ring.stats()
             ring.close()
             lat.sort()
-            out[("key_cache" if cached else "cold") + ("_hipgraph" if use_graph else "_stream_ops")] = {
+            out[("key_cache_" if cached else "cold_") + kind.replace("-", "_")] = {
                 "signatures_per_s": round(done * n / wall, 1), "rounds": done,
                 "submit_to_verdict_p50_ms": round(lat[len(lat) // 2] * 1e3, 4), "graph_captures": captures}
         if ks:

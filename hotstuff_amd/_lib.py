@@ -7,6 +7,10 @@ import ctypes
 import os
 import threading
 
+# one hardware queue per stream context (HIP's default of 4 multiplexes the pool / ring slots);
+# read by the HIP runtime when it initialises, i.e. at the first device call in the process
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhs_ed25519.so")
 
@@ -312,12 +316,13 @@ class DeviceContext:
             pass
 
 
-RING_NO_GRAPH = 1
+RING_KINDS = {"auto": 0, "graph": 1, "stream-ops": 2, "zero-copy": 3}
 
 
 class RoundRing:
-    """hs_ed25519_ring: streamed rounds (BASELINE config 5).  `slots` rounds in flight, each one
-    hipGraph launch (pinned H2D -> kernels -> D2H) on its own stream.
+    """hs_ed25519_ring: streamed rounds (BASELINE config 5).  `slots` rounds in flight on their own
+    streams; kind = "graph" (pinned H2D -> kernels -> D2H as one hipGraph launch), "stream-ops"
+    (the same, issued one by one), "zero-copy" (kernels read the pinned slot directly) or "auto".
 
         dg, keys, sg = ring.begin(slot, n, shared=True)   # numpy uint8 views of PINNED memory
         dg[:] = ...; keys[:] = ...; sg[:] = ...            # write the packed tuples in place
@@ -326,7 +331,7 @@ class RoundRing:
 
     With a key set `keys` is n little-endian uint32 indices (4n bytes), else n*32 key bytes."""
 
-    def __init__(self, slot_batch, slots=4, keyset=None, use_graph=True):
+    def __init__(self, slot_batch, slots=4, keyset=None, kind="auto"):
         ensure_init()
         self._h = ctypes.c_void_p()
         self.keyset = keyset            # keeps the key set alive as long as the ring
@@ -334,7 +339,7 @@ class RoundRing:
         self._n = [0] * self.slots
         check(lib().hs_ed25519_ring_create(ctypes.byref(self._h), self.slot_batch, self.slots,
                                            keyset.handle if keyset is not None else None,
-                                           0 if use_graph else RING_NO_GRAPH), "hs_ed25519_ring_create")
+                                           RING_KINDS[kind]), "hs_ed25519_ring_create")
 
     def begin(self, slot, n, shared):
         import numpy as np

@@ -364,6 +364,7 @@ static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own wind
 static const size_t kCachedLaneMin = 16384;    // cached path: 4 lanes per signature up to here, 2 above ...
 static const size_t kCachedLane1Min = 131072;  // ... and 1 lane per signature above this
 static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
+static const size_t kZeroCopyMax = 16384;   // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -445,6 +446,11 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
 extern "C" int hs_ed25519_init(int device, size_t max_batch) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_init) { if (max_batch > g_max_batch) g_max_batch = max_batch; return 0; }
+    // The pool, the ring slots and the CU-partitioned contexts each want a hardware queue of their
+    // own; HIP's default of 4 multiplexes them (streamed rounds: 22 vs 34 M signatures/s).  The
+    // runtime reads this when it initialises, so it only takes effect when this library is the
+    // process's first HIP user (the Rust node); an explicit setting by the host is respected.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int count = 0;
     HS_HIP(hipGetDeviceCount(&count), "hipGetDeviceCount");
     if (device < 0 || device >= count) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
@@ -755,6 +761,16 @@ extern "C" int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_
 }
 
 // ---- host-pointer API ----------------------------------------------------------------------
+// the call's verdict from the accept bitmap (the host forms pass no reject counter to the kernels)
+static bool bitmap_all_ones(const uint8_t *bm, size_t n) {
+    const size_t words = n / 64;
+    for (size_t i = 0; i < words; i++) { uint64_t w; memcpy(&w, bm + 8 * i, 8); if (w != ~(uint64_t)0) return false; }
+    for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
+    return true;
+}
+// Up to kZeroCopyMax signatures the kernels read the pinned staging and write the pinned bitmap
+// directly over PCIe (hipHostMalloc memory is mapped on the device; every input byte is read
+// exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
 static int pool_get(hs_ed25519_ctx **out) {
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
@@ -795,18 +811,15 @@ static int verify_host(const uint8_t *digests, size_t digest_stride, const uint8
     memcpy(c->h_in, digests, dg_bytes);
     memcpy(c->h_in + off_pk, pks, 32 * n);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
-    const size_t bm = bitmap_bytes(n);
-    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
-    rc = hs_ed25519_verify_device(c, c->d_in, digest_stride, c->d_in + off_pk, c->d_in + off_sig, n, mode, c->d_out,
-                                  (uint32_t *)(c->d_out + bm), c->stream);
+    const bool zc = n <= kZeroCopyMax;
+    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
+    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_pk, in + off_sig, n, mode, outp, nullptr, c->stream);
     if (rc) return rc;
-    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
-    uint32_t nrej;
-    memcpy(&nrej, c->h_out + bm, 4);
     if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
-    return nrej == 0 ? 1 : 0;
+    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
 }
 
 extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
@@ -839,18 +852,16 @@ static int verify_host_cached(const hs_ed25519_keyset *ks, const uint8_t *digest
     memcpy(c->h_in, digests, dg_bytes);
     memcpy(c->h_in + off_ki, key_idx, 4 * n);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
-    const size_t bm = bitmap_bytes(n);
-    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
-    rc = hs_ed25519_verify_device_cached(c, ks, c->d_in, digest_stride, (const uint32_t *)(c->d_in + off_ki), c->d_in + off_sig,
-                                         n, mode, c->d_out, (uint32_t *)(c->d_out + bm), c->stream);
+    const bool zc = n <= kZeroCopyMax;
+    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
+    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_ki), in + off_sig,
+                                         n, mode, outp, nullptr, c->stream);
     if (rc) return rc;
-    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
-    uint32_t nrej;
-    memcpy(&nrej, c->h_out + bm, 4);
     if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
-    return nrej == 0 ? 1 : 0;
+    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
 }
 extern "C" int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
                                                const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
@@ -882,22 +893,19 @@ static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uin
     memcpy(c->h_in, hq_rounds, 8 * n);
     memcpy(c->h_in + off_k, pks_or_idx, key_bytes);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
-    const size_t bm = bitmap_bytes(n);
-    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    HS_HIP(hipMemsetAsync(c->d_out + bm, 0, 16, c->stream), "memset");
+    const bool zc = n <= kZeroCopyMax;
+    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
+    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
     if (ks)
-        rc = hs_ed25519_verify_device_tc_cached(c, ks, round, (const uint64_t *)c->d_in, (const uint32_t *)(c->d_in + off_k),
-                                                c->d_in + off_sig, n, c->d_out, (uint32_t *)(c->d_out + bm), c->stream);
+        rc = hs_ed25519_verify_device_tc_cached(c, ks, round, (const uint64_t *)in, (const uint32_t *)(in + off_k),
+                                                in + off_sig, n, outp, nullptr, c->stream);
     else
-        rc = hs_ed25519_verify_device_tc(c, round, (const uint64_t *)c->d_in, c->d_in + off_k, c->d_in + off_sig, n, c->d_out,
-                                         (uint32_t *)(c->d_out + bm), c->stream);
+        rc = hs_ed25519_verify_device_tc(c, round, (const uint64_t *)in, in + off_k, in + off_sig, n, outp, nullptr, c->stream);
     if (rc) return rc;
-    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bm + 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
-    uint32_t nrej;
-    memcpy(&nrej, c->h_out + bm, 4);
     if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
-    return nrej == 0 ? 1 : 0;
+    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
 }
 extern "C" int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const uint8_t *pks, const uint8_t *sigs,
                                     size_t n, uint8_t *bitmap) {
@@ -928,7 +936,8 @@ struct hs_ed25519_ring {
     std::vector<ring_slot> slots;
     size_t cap = 0;
     const hs_ed25519_keyset *ks = nullptr;
-    bool use_graph = true;
+    bool use_graph = false;
+    bool zero_copy = false;      // kernels read the pinned slot / write the pinned bitmap directly over PCIe
     size_t captures = 0, launches = 0;
 };
 
@@ -944,12 +953,17 @@ extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
 
 extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, unsigned slots,
                                       const hs_ed25519_keyset *ks, uint32_t flags) {
-    if (!out || slot_batch == 0 || slots == 0 || slots > 64 || slot_batch > 0x3fffffffu || (flags & ~1u))
+    if (!out || slot_batch == 0 || slots == 0 || slots > 64 || slot_batch > 0x3fffffffu || flags > 3u)
         return fail(HS_ED25519_E_ARG, "ring_create: bad arguments");
     if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     hs_ed25519_ring *r = new (std::nothrow) hs_ed25519_ring();
     if (!r) return fail(HS_ED25519_E_NOMEM, "ring_create: out of memory");
-    r->cap = round_up(slot_batch, 64); r->ks = ks; r->use_graph = !(flags & HS_ED25519_RING_NO_GRAPH);
+    r->cap = round_up(slot_batch, 64); r->ks = ks; // AUTO follows the measurements (profiles/r1_ring_sweep.md): zero-copy wins or ties up to QC-sized rounds of a
+    // 10,000-validator committee; above that the copy engines' bulk transfers are as good and plain stream
+    // operations overlap best.  The graph form never won on gfx950 / ROCm 7 and is kept selectable.
+    if (flags == HS_ED25519_RING_AUTO) flags = r->cap <= kZeroCopyMax ? HS_ED25519_RING_ZERO_COPY : HS_ED25519_RING_STREAM_OPS;
+    r->zero_copy = flags == HS_ED25519_RING_ZERO_COPY;
+    r->use_graph = flags == HS_ED25519_RING_GRAPH;
     r->slots.resize(slots);
     for (ring_slot &s : r->slots) {
         int rc = hs_ed25519_ctx_create(&s.ctx, 64);
@@ -980,16 +994,21 @@ extern "C" int hs_ed25519_ring_begin(hs_ed25519_ring *r, unsigned slot, size_t n
 
 static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
     hs_ed25519_ctx *c = s.ctx;
-    HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, s.in_bytes, hipMemcpyHostToDevice, c->stream), "ring H2D");
+    // zero-copy: hipHostMalloc memory is mapped into the device's address space, so the kernels can
+    // take the slot's pinned buffers as they are - every input byte is read exactly once anyway
+    uint8_t *in = r->zero_copy ? c->h_in : c->d_in, *outp = r->zero_copy ? c->h_out : c->d_out;
+    if (!r->zero_copy)
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, s.in_bytes, hipMemcpyHostToDevice, c->stream), "ring H2D");
     int rc;
     if (r->ks)
-        rc = hs_ed25519_verify_device_cached(c, r->ks, c->d_in, s.stride, (const uint32_t *)(c->d_in + s.off_key),
-                                             c->d_in + s.off_sig, s.n, mode, c->d_out, nullptr, c->stream);
+        rc = hs_ed25519_verify_device_cached(c, r->ks, in, s.stride, (const uint32_t *)(in + s.off_key),
+                                             in + s.off_sig, s.n, mode, outp, nullptr, c->stream);
     else
-        rc = hs_ed25519_verify_device(c, c->d_in, s.stride, c->d_in + s.off_key, c->d_in + s.off_sig, s.n, mode,
-                                      c->d_out, nullptr, c->stream);
+        rc = hs_ed25519_verify_device(c, in, s.stride, in + s.off_key, in + s.off_sig, s.n, mode,
+                                      outp, nullptr, c->stream);
     if (rc) return rc;
-    HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(s.n), hipMemcpyDeviceToHost, c->stream), "ring D2H");
+    if (!r->zero_copy)
+        HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(s.n), hipMemcpyDeviceToHost, c->stream), "ring D2H");
     return 0;
 }
 
@@ -1049,13 +1068,8 @@ extern "C" int hs_ed25519_ring_wait(hs_ed25519_ring *r, unsigned slot, uint8_t *
     hipError_t e = hipStreamSynchronize(s.ctx->stream);
     s.inflight = false;
     if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "ring stream sync", e);
-    const uint8_t *bm = s.ctx->h_out;
-    const size_t n = s.n, whole = n / 8;
-    if (bitmap) memcpy(bitmap, bm, (n + 7) / 8);
-    bool ok = true;
-    for (size_t i = 0; i < whole && ok; i++) ok = bm[i] == 0xff;
-    if (ok && (n & 7)) ok = bm[whole] == (uint8_t)((1u << (n & 7)) - 1);
-    return ok ? 1 : 0;
+    if (bitmap) memcpy(bitmap, s.ctx->h_out, (s.n + 7) / 8);
+    return bitmap_all_ones(s.ctx->h_out, s.n) ? 1 : 0;
 }
 
 extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {

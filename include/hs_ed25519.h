@@ -151,21 +151,27 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
 /* ---- round ring: streamed rounds (BASELINE config 5) -----------------------------------------
  * The reference's Core task verifies one certificate per message as rounds stream by
  * (consensus/src/core.rs:379, 401 -> QC::verify messages.rs:197).  A ring keeps `slots` rounds in
- * flight: each slot owns a HIP stream, PINNED host staging and device buffers, and its round is
- * one hipGraph launch (H2D copy -> verification kernel(s) -> D2H copy of the bitmap), captured
- * once and re-launched while (n, digest form, mode) repeat - the steady state of a fixed
- * committee - and updated in place when they change.  Copies and kernels of different slots
- * overlap.  Protocol per slot:  begin (get the pinned pointers, write the packed tuples in
+ * flight: each slot owns a HIP stream, PINNED host staging and device buffers; copies and kernels
+ * of different slots overlap.  Protocol per slot:  begin (get the pinned pointers, write the packed tuples in
  * place - no second host copy) -> submit (asynchronous) -> poll / wait (verdict + bitmap).
  *   ks != NULL: the ring verifies through that key set; `keys` then holds n uint32 indices,
  *               otherwise n*32 key bytes.
  *   digest_stride 0: `digests` holds one shared 32-byte digest; 32: one per signature.
- *   flags: HS_ED25519_RING_NO_GRAPH issues the same three operations to the stream one by one
- *          (A/B measurements).
+ *   flags: how a round travels (all four have the same results):
+ *     HS_ED25519_RING_GRAPH       H2D copy -> kernel(s) -> D2H copy as ONE hipGraph launch, captured
+ *                                 once per slot and re-launched / updated in place
+ *     HS_ED25519_RING_STREAM_OPS  the same three operations issued to the slot's stream one by one
+ *     HS_ED25519_RING_ZERO_COPY   no copies: the kernels read the pinned slot and write the pinned
+ *                                 bitmap directly over PCIe (every input byte is read exactly once)
+ *     HS_ED25519_RING_AUTO        the engine's choice by measurement (profiles/r1_ring_sweep.md):
+ *                                 zero-copy for slot_batch <= 16,384, stream operations above
  * A ring is driven by one thread at a time (the reference's single Core task); different rings
  * are independent.  wait returns 1 / 0 / <0 like every verify call; poll returns 1 when the
  * slot's round has completed, 0 while it runs. */
-#define HS_ED25519_RING_NO_GRAPH 1u
+#define HS_ED25519_RING_AUTO 0u
+#define HS_ED25519_RING_GRAPH 1u
+#define HS_ED25519_RING_STREAM_OPS 2u
+#define HS_ED25519_RING_ZERO_COPY 3u
 typedef struct hs_ed25519_ring hs_ed25519_ring;
 int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, unsigned slots,
                            const hs_ed25519_keyset *ks, uint32_t flags);

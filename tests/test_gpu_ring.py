@@ -29,12 +29,13 @@ def fill(ring, slot, dg, keys, sg, n, shared):
     s[:] = np.frombuffer(sg, dtype=np.uint8)
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_rounds_of_every_shape_vs_oracle(oracle, use_graph):
+@pytest.mark.parametrize("kind", ["graph", "stream-ops", "zero-copy", "auto"])
+def test_rounds_of_every_shape_vs_oracle(oracle, kind):
     """Rounds of different sizes, digest forms and modes through three slots, several in flight;
     every bitmap equals the oracle's.  Each change of (n, form, mode) re-captures / updates the
     slot's graph."""
-    ring = _lib.RoundRing(2048, slots=3, use_graph=use_graph)
+    use_graph = kind == "graph"
+    ring = _lib.RoundRing(2048, slots=3, kind=kind)
     cases = [(n, shared, mode) for n in (1, 63, 64, 65, 1000, 2048) for shared in (True, False)
              for mode in (_lib.BATCH, _lib.STRICT)]
     pending = {}
@@ -67,7 +68,7 @@ def test_steady_state_replays_one_graph_per_slot_and_follows_the_data(oracle):
     """The steady state: the same (n, form, mode) every round.  The graph is captured once per
     slot and re-launched; what it verifies is whatever the pinned slot holds at submit time."""
     n, slots, rounds = 667, 4, 40
-    ring = _lib.RoundRing(1024, slots=slots)
+    ring = _lib.RoundRing(1024, slots=slots, kind="graph")
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
     expect = {}
     for r in range(rounds):
@@ -160,8 +161,9 @@ def test_streamed_rounds_single_thread_sustained_rate(cached):
     bad_sg = bytearray(sg); bad_sg[64 * 100 + 1] ^= 1; bad_sg = bytes(bad_sg)
     src = [np.frombuffer(x, dtype=np.uint8) for x in (dg, keys_bytes, sg, bad_sg)]
     results = {}
-    for use_graph in (True, False):
-        ring = _lib.RoundRing(n, slots=slots, keyset=ks, use_graph=use_graph)
+    for kind in ("graph", "stream-ops", "zero-copy"):
+        use_graph = kind == "graph"
+        ring = _lib.RoundRing(n, slots=slots, keyset=ks, kind=kind)
         expect, lat, t_sub = {}, [], {}
         done = 0
         t_end = time.perf_counter() + 1.0
@@ -184,13 +186,12 @@ def test_streamed_rounds_single_thread_sustained_rate(cached):
             r += 1
         wall = time.perf_counter() - t0
         lat.sort()
-        results[use_graph] = done * n / wall
+        results[kind] = done * n / wall
         print("streamed rounds (%s, %s): %.1f M signatures/s from one host thread, %d rounds, submit->verdict p50 %.3f ms"
-              % ("key cache" if cached else "cold", "hipGraph" if use_graph else "plain stream ops",
-                 results[use_graph] / 1e6, done, lat[len(lat) // 2] * 1e3))
+              % ("key cache" if cached else "cold", kind, results[kind] / 1e6, done, lat[len(lat) // 2] * 1e3))
         if use_graph:
             assert ring.stats()[0] == slots
         ring.close()
-    assert results[True] > 1e6 and results[False] > 1e6
+    assert all(v > 1e6 for v in results.values())
     if ks:
         ks.close()

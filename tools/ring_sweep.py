@@ -1,5 +1,5 @@
 """Streamed-rounds sweep for the round ring (hs_ed25519_ring_*): hipGraph launch vs the same
-three stream operations issued one by one, cold and key-cache paths, by pipeline depth.
+three stream operations issued one by one vs zero-copy kernels, cold and key-cache paths, by pipeline depth.
 
   python tools/ring_sweep.py > gpurun_out/ring_sweep.md        (on a GPU box)
 
@@ -20,8 +20,8 @@ from hotstuff_amd import _lib  # noqa: E402
 CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
 
 
-def run(n, slots, ks, src, use_graph, seconds=1.0):
-    ring = _lib.RoundRing(n, slots=slots, keyset=ks, use_graph=use_graph)
+def run(n, slots, ks, src, kind, seconds=1.0):
+    ring = _lib.RoundRing(n, slots=slots, keyset=ks, kind=kind)
     for slot in range(slots):                      # warm: capture + first launch
         d, k, s = ring.begin(slot, n, True)
         d[:] = src[0]; k[:] = src[1]; s[:] = src[2]
@@ -65,10 +65,10 @@ def main():
             kb = ks.indices(keys)[0] if cached else pk
             src = [np.frombuffer(x, dtype=np.uint8) for x in (dg, kb, sg)]
             for slots in (1, 2, 4, 8):
-                for use_graph in (True, False):
-                    rate, p50, p99 = run(n, slots, ks, src, use_graph)
+                for kind in ("graph", "stream-ops", "zero-copy"):
+                    rate, p50, p99 = run(n, slots, ks, src, kind)
                     print("| %d | %d | %s | %s | %d | %.1f | %.3f | %.3f |"
-                          % (N, n, "key cache" if cached else "cold", "hipGraph" if use_graph else "stream ops",
+                          % (N, n, "key cache" if cached else "cold", kind,
                              slots, rate / 1e6, p50, p99), flush=True)
             if ks:
                 ks.close()
