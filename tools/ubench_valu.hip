@@ -18,6 +18,9 @@ __global__ void __launch_bounds__(256) bench(uint32_t *out, uint32_t seed) {
     double d[CH];
     for (int i = 0; i < CH; i++) { a[i] = seed + threadIdx.x * 7 + i; b[i] = seed * 3 + i; c[i] = a[i]; d[i] = 1.0 + 1e-9 * a[i]; }
     const uint32_t m = seed | 1;
+    const unsigned long long mk = __ballot((threadIdx.x + seed) & 1);       // a lane mask in an SGPR pair
+    const uint32_t mv = ((threadIdx.x + seed) & 1) ? 0xffffffffu : 0u;      // the same mask as a per-lane word
+    if (OP == 14) asm volatile("s_mov_b64 vcc, %0" :: "s"(mk) : "vcc");
     const double dm = 1.0000001, da = 1e-7;
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
@@ -38,6 +41,15 @@ __global__ void __launch_bounds__(256) bench(uint32_t *out, uint32_t seed) {
             if (OP == 13) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(b[i]));
             if (OP == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : );
             if (OP == 15) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[0]) : "v"(a[i]), "v"(m) : "vcc");   // one dependent chain
+            if (OP == 16) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "s"(mk));
+            if (OP == 17) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(mv), "v"(m));
+            if (OP == 18) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            if (OP == 19) asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(m));
+            if (OP == 20) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(b[i]));
+            if (OP == 21) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(m));
+            if (OP == 22) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (OP == 23) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 24) asm volatile("v_mov_b64 %0, %1" : "+v"(c[i]) : "v"(c[(i + 1) % CH]));
         }
     }
     uint32_t r = 0;
@@ -60,6 +72,10 @@ int main(int argc, char **argv) {
         {"v_and_b32", bench<9>, 1}, {"v_mul_u32_u24", bench<10>, 1}, {"v_mul_hi_u32_u24", bench<11>, 1},
         {"v_lshl_add_u64", bench<12>, 1}, {"v_fma_f32", bench<13>, 1}, {"v_cndmask_b32", bench<14>, 1},
         {"v_mad_u64_u32 (1 dependent chain)", bench<15>, 1},
+        {"v_cndmask_b32_e64 (SGPR-pair mask)", bench<16>, 1}, {"v_bfi_b32", bench<17>, 1},
+        {"v_mov_b32_dpp quad_perm", bench<18>, 1}, {"v_add_u32_dpp quad_perm", bench<19>, 1},
+        {"v_add3_u32", bench<20>, 1}, {"v_lshl_add_u32", bench<21>, 1}, {"v_xor_b32", bench<22>, 1},
+        {"v_mov_b32", bench<23>, 1}, {"v_mov_b64", bench<24>, 1},
     };
     uint32_t *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
