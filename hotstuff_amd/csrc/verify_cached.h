@@ -136,8 +136,8 @@ HS_Q qv cached_quad_chain(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8]
         const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
         const qv ea = q_load_entry(atab + ((size_t)w * HS_KS_ENTRIES + ik) * HS_KS_ENTRY_WORDS);
         const qv eb = q_load_entry(btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
-        acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
-        acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+        acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
+        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
     }
     return acc;
 }

@@ -46,6 +46,50 @@ HS_Q qv q_add(const qv &a, const qv &b) { qv r; fe_add(r, a, b); return r; }
 HS_Q qv q_sub(const qv &a, const qv &b) { qv r; fe_sub(r, a, b); return r; }
 HS_Q qv q_carry(const qv &a) { qv r = a; fe_carry(r); return r; }
 HS_Q qv q_pick(const qv &a, const qv &b, bool pick_b) { qv r; fe_select(r, a, b, pick_b); return r; }
+// The workhorse between two multiplication rounds: lane i <- a[PA_i] (+|-) b[PB_i], where the lanes
+// in NEG subtract (a + 2p - b; b reduced), the lanes in ZERO take a[PA_i] alone and the others add.
+// Every lane runs the same three instructions per limb - the sign is data: b ^ mask + (mask & (2p + 1))
+// is 2p - b (mod 2^32) when mask is all ones and b when it is zero - instead of computing every
+// combination in every lane and selecting (which cost the doubling 250 of its 503 instructions).
+template <int PA, int PB, int NEG, int ZERO>
+HS_Q qv q_comb(const qv &a, const qv &b) {
+    const u32 lane = q_lane();
+    u32 neg = ((NEG >> lane) & 1) ? 0xffffffffu : 0u;
+    const u32 keep = ((ZERO >> lane) & 1) ? 0u : 0xffffffffu;
+    // NEVER write this as `pa + bias - qb`: the compiler folds the DPP move into the subtraction as
+    // v_subrev_u32_dpp, and on gfx950 that instruction permutes its OTHER operand (measured:
+    // tools/dpp_subrev_check.hip, profiles/r1_dpp_subrev.txt) - silently wrong lanes.  With every lane
+    // negating, the mask is kept opaque so that the xor/add form cannot be turned back into a subtraction;
+    // __graft_entry__.build_engine() refuses a code object that contains a v_sub*rev*_dpp.
+    if (NEG == 0xf) asm volatile("" : "+v"(neg));
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const u32 bias = i == 0 ? 0x7ffffdau : ((i & 1) ? 0x3fffffeu : 0x7fffffeu);
+        const u32 pa = (u32)__builtin_amdgcn_mov_dpp((int)a.v[i], PA, 0xf, 0xf, true);
+        u32 qb = (u32)__builtin_amdgcn_mov_dpp((int)b.v[i], PB, 0xf, 0xf, true);
+        if (ZERO) qb &= keep;
+        if (NEG) r.v[i] = pa + (qb ^ neg) + (neg & (bias + 1));
+        else r.v[i] = pa + qb;
+    }
+    return r;
+}
+// a cached entry (Y-X, Y+X, 2dT, 2Z) or, where `negate` (uniform over the quad), its negative
+// (Y+X, Y-X, 2p - 2dT, 2Z): swap lanes 0/1 and negate lane 2, again with the sign as data
+HS_Q qv q_cached_signed(const qv &e, bool negate) {
+    u32 m = negate ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));              // keep it a mask: (sw & m) | (e & ~m) is one v_bfi_b32, a VCC select costs 4x
+    const u32 n2 = q_lane() == 2 ? m : 0u;
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const u32 bias = i == 0 ? 0x7ffffdau : ((i & 1) ? 0x3fffffeu : 0x7fffffeu);
+        const u32 sw = (u32)__builtin_amdgcn_mov_dpp((int)e.v[i], 1 | (0 << 2) | (2 << 4) | (3 << 6), 0xf, 0xf, true);
+        const u32 x = (sw & m) | (e.v[i] & ~m);
+        r.v[i] = (x ^ n2) + (n2 & (bias + 1));
+    }
+    return r;
+}
 HS_Q qv q_lanes(const fe &c0, const fe &c1, const fe &c2, const fe &c3) {   // per-lane constant
     const u32 l = q_lane();
     qv r; fe_select(r, c0, c1, l == 1); fe_select(r, r, c2, l == 2); fe_select(r, r, c3, l == 3); return r;
@@ -69,6 +113,23 @@ HS_Q qv q_add(const qv &a, const qv &b) { qv r; for (int i = 0; i < 4; i++) fe_a
 HS_Q qv q_sub(const qv &a, const qv &b) { qv r; for (int i = 0; i < 4; i++) fe_sub(r.l[i], a.l[i], b.l[i]); return r; }
 HS_Q qv q_carry(const qv &a) { qv r = a; for (int i = 0; i < 4; i++) fe_carry(r.l[i]); return r; }
 HS_Q qv q_pick(const qv &a, const qv &b, bool pick_b) { return pick_b ? b : a; }
+template <int PA, int PB, int NEG, int ZERO>
+HS_Q qv q_comb(const qv &a, const qv &b) {
+    qv r;
+    for (int i = 0; i < 4; i++) {
+        const fe &x = a.l[(PA >> (2 * i)) & 3], &y = b.l[(PB >> (2 * i)) & 3];
+        if ((ZERO >> i) & 1) r.l[i] = x;
+        else if ((NEG >> i) & 1) fe_sub(r.l[i], x, y);
+        else fe_add(r.l[i], x, y);
+    }
+    return r;
+}
+HS_Q qv q_cached_signed(const qv &e, bool negate) {
+    if (!negate) return e;
+    qv r; fe z; fe_0(z);
+    r.l[0] = e.l[1]; r.l[1] = e.l[0]; fe_sub(r.l[2], z, e.l[2]); r.l[3] = e.l[3];
+    return r;
+}
 HS_Q qv q_lanes(const fe &c0, const fe &c1, const fe &c2, const fe &c3) { qv r; r.l[0] = c0; r.l[1] = c1; r.l[2] = c2; r.l[3] = c3; return r; }
 HS_Q qv q_load(const fe (*tab)[4], int idx) { qv r; for (int i = 0; i < 4; i++) r.l[i] = tab[idx][i]; return r; }
 struct qflags { bool f[4]; };
@@ -104,14 +165,10 @@ HS_Q void qtab_store(qtab &t, int j, const qv &e) { t.e[j] = e; }
 HS_Q qv qtab_load(const qtab &t, int j) { return t.e[j]; }
 #endif
 
-// (X, Y, Z, T) -> (Y-X, Y+X, T, Z): the left operands of an addition's first round
+#define HS_QP(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
+// (X, Y, Z, T) -> (Y-X, Y+X, T, Z): the left operands of an addition's first round    (<= 3x)
 HS_Q qv q_add_lhs(const qv &p) {
-    const qv u = q_perm<1, 1, 3, 2>(p);               // (Y, Y, T, Z)
-    const qv x = q_perm<0, 0, 0, 0>(p);               // X everywhere
-    const qv zero = q_lanes(fe_small(0), fe_small(0), fe_small(0), fe_small(0));
-    const qv d = q_sub(u, x);                         // lane 0: Y - X            (3x)
-    const qv s = q_add(u, q_sel<0b1100>(x, zero));    // lane 1: Y + X; lanes 2,3: u + 0
-    return q_sel<0b0001>(s, d);
+    return q_comb<HS_QP(1, 1, 3, 2), HS_QP(0, 0, 0, 0), 0b0001, 0b1100>(p, p);
 }
 // cached form (Y-X, Y+X, 2dT, 2Z) of an extended point: one vector multiplication by constants
 HS_Q qv q_to_cached(const qv &p) {
@@ -119,33 +176,26 @@ HS_Q qv q_to_cached(const qv &p) {
     return q_mul(q_add_lhs(p), k);
 }
 // negate a cached entry: swap lanes 0/1, negate lane 2
-HS_Q qv q_cached_neg(const qv &e) {
-    const qv sw = q_perm<1, 0, 2, 3>(e);
-    const qv zero = q_lanes(fe_small(0), fe_small(0), fe_small(0), fe_small(0));
-    return q_sel<0b0100>(sw, q_sub(zero, sw));        // lane 2: 2p - 2dT  (2x)
-}
+HS_Q qv q_cached_neg(const qv &e) { return q_cached_signed(e, true); }
 // p + e  (e cached, already sign-adjusted) -> extended
 HS_Q qv q_add_cached(const qv &p, const qv &e) {
     const qv m = q_mul(q_add_lhs(p), e);              // (A, B, C, D), reduced
-    const qv a = q_perm<0, 0, 0, 0>(m), b = q_perm<1, 1, 1, 1>(m), c = q_perm<2, 2, 2, 2>(m), d = q_perm<3, 3, 3, 3>(m);
-    const qv E = q_sub(b, a), H = q_add(b, a), F = q_sub(d, c), G = q_add(d, c);   // 3x, 2x, 3x, 2x
-    const qv l = q_sel<0b0100>(q_sel<0b0010>(E, G), F);     // (E, G, F, E)
-    const qv r = q_sel<0b0100>(q_sel<0b0001>(H, F), G);     // (F, H, G, H)
-    return q_mul(l, r);                                     // (EF, GH, FG, EH)
+    // E = B - A, H = B + A, F = D - C, G = D + C
+    const qv l = q_comb<HS_QP(1, 3, 3, 1), HS_QP(0, 2, 2, 0), 0b1101, 0>(m, m);   // (E, G, F, E)   <= 3x
+    const qv r = q_comb<HS_QP(3, 1, 3, 1), HS_QP(2, 0, 2, 0), 0b0001, 0>(m, m);   // (F, H, G, H)   <= 3x
+    return q_mul(l, r);                                                             // (EF, GH, FG, EH)
 }
 // 2p -> extended (input T unused)
 HS_Q qv q_dbl(const qv &p) {
-    const qv x = q_perm<0, 0, 0, 0>(p), y = q_perm<1, 1, 1, 1>(p);
-    const qv a = q_sel<0b1000>(p, q_add(x, y));       // (X, Y, Z, X+Y)
-    const qv s = q_sq(a);                             // (XX, YY, ZZ, AA), reduced
-    const qv xx = q_perm<0, 0, 0, 0>(s), yy = q_perm<1, 1, 1, 1>(s), zz = q_perm<2, 2, 2, 2>(s), aa = q_perm<3, 3, 3, 3>(s);
-    const qv S = q_carry(q_add(yy, xx));              // Y3' = YY + XX     (1x)
-    const qv D = q_carry(q_sub(yy, xx));              // Z3' = YY - XX     (1x)
-    const qv E = q_sub(aa, S);                        // X3' = AA - S      (3x)
-    const qv F = q_sub(q_add(zz, zz), D);             // T3' = 2ZZ - D     (4x)
-    const qv l = q_sel<0b0100>(q_sel<0b0010>(E, S), D);     // (E, S, D, E)   <= 3x
-    const qv r = q_sel<0b1000>(q_sel<0b0010>(F, D), S);     // (F, D, F, S)   <= 4x
-    return q_mul(r, l);                                     // (EF, SD, DF, ES)
+    const qv a = q_comb<HS_QP(0, 1, 2, 0), HS_QP(0, 0, 0, 1), 0, 0b0111>(p, p);    // (X, Y, Z, X+Y)
+    const qv s = q_sq(a);                                                           // (XX, YY, ZZ, AA), reduced
+    // t = (S, D, 2ZZ, AA) with S = YY + XX, D = YY - XX; one carry for all four
+    const qv t = q_carry(q_comb<HS_QP(1, 1, 2, 3), HS_QP(0, 0, 2, 0), 0b0010, 0b1000>(s, s));
+    // w = (E, F, F, E) with E = AA - S, F = 2ZZ - D                                  (3x)
+    const qv w = q_comb<HS_QP(3, 2, 2, 3), HS_QP(0, 1, 1, 0), 0b1111, 0>(t, t);
+    const qv l = q_sel<0b0010>(w, t);                                               // (E, D, F, E)
+    const qv r = q_sel<0b0001>(q_perm<0, 0, 1, 0>(t), q_perm<1, 1, 1, 1>(w));       // (F, S, D, S)
+    return q_mul(l, r);                                                             // (EF, DS, FD, ES)
 }
 
 // The quad stage-2 core.  ax, ay, rx, ry (affine A and R) and the recoded scalars are uniform
@@ -180,12 +230,12 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
         const int dk = sc_pop_digit(kw);
         const int ik = dk < 0 ? -dk : dk;
         const qv ea = qtab_load(atab, ik);
-        acc = q_add_cached(acc, q_pick(ea, q_cached_neg(ea), dk < 0));
+        acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
         if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
             const int ds = sc_pop_digit8(sw);
             const int is = ds < 0 ? -ds : ds;
             const qv eb = q_load(btab, is);
-            acc = q_add_cached(acc, q_pick(eb, q_cached_neg(eb), ds < 0));
+            acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
         }
     }
     // acc == R as points: X == x_R Z (lane 0), Y == y_R Z (lane 1); lanes 2, 3 compare Z with Z

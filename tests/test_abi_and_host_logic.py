@@ -102,3 +102,15 @@ def test_qc_structural_errors_precede_crypto(openssl_vectors):
     tc = TC(7, tc_votes)
     import hashlib, struct
     assert tc.vote_digest(3).b == hashlib.sha512(struct.pack("<QQ", 7, 3)).digest()[:32]   # messages.rs:307-311
+
+
+def test_code_object_has_no_reversed_subtract_with_dpp():
+    """gfx950 applies the lane permutation of v_subrev_u32_dpp to the wrong operand
+    (tools/dpp_subrev_check.hip, profiles/r1_dpp_subrev.txt) and LLVM's DPP combiner emits that
+    instruction for `x - mov_dpp(y)`.  The kernels avoid the pattern; this checks the library that
+    will actually be loaded."""
+    import __graft_entry__ as g
+    bad = g.forbidden_instructions(g.LIB)
+    if bad is None:
+        pytest.skip("LLVM tools not installed")
+    assert bad == []
