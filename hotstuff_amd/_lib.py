@@ -12,7 +12,7 @@ import threading
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhs_ed25519.so")
+LIB_PATH = os.environ.get("HS_ED25519_LIB") or os.path.join(_HERE, "libhs_ed25519.so")   # override: A/B measurements
 
 BATCH = 0
 STRICT = 1

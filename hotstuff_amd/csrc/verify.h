@@ -87,6 +87,18 @@ HS_HD int sc_pop_digit8(u32 w[8]) {
 }
 #define HS_BTAB_ENTRIES 129   // j*B, j = 0..128: 8-bit signed windows for the base point
 
+// acc == (rx, ry) as points:  X == x_R Z  and  Y == y_R Z  and  Z != 0.
+// The complete formulas never produce Z = 0, so the last test changes no verdict; it makes the
+// comparison FAIL CLOSED: an all-zero accumulator (what an arithmetic fault produces - it is
+// absorbing under these formulas, and 0 == x_R * 0) satisfies both equalities for every signature.
+HS_HD bool ge_match_point(ge_p3 acc, const fe &rx, const fe &ry) {
+    fe a, b;
+    fe_mul(a, rx, acc.Z);
+    fe_mul(b, ry, acc.Z);
+    fe_carry(acc.X); fe_carry(acc.Y); fe_carry(acc.Z);
+    return fe_eq(a, acc.X) && fe_eq(b, acc.Y) && !fe_iszero(acc.Z);
+}
+
 // btab: HS_BTAB_ENTRIES affine Niels entries j*B (entry 0 = identity), L2-resident.
 HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *btab) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
@@ -147,12 +159,7 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *bta
         }
         ge_p1p1_to_p3(acc, t, false);
     }
-    // acc == R as points:  X == x_R Z  and  Y == y_R Z
-    fe a, b;
-    fe_mul(a, rx, acc.Z);
-    fe_mul(b, ry, acc.Z);
-    fe_carry(acc.X); fe_carry(acc.Y);
-    return ok && fe_eq(a, acc.X) && fe_eq(b, acc.Y);
+    return ok && ge_match_point(acc, rx, ry);
 }
 
 // ---- base-point table (computed once on the host at init) ----------------------------------

@@ -45,6 +45,12 @@ HS_Q bool q_quad_and01(const qflags &f) {     // lanes 0 and 1 both set, uniform
     const int b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
     return a && b;
 }
+HS_Q bool q_quad_all(const qflags &f) {       // all four lanes set, uniform over the quad
+    const int v = f.f ? 1 : 0;
+    const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true), b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
+    const int c = __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true), d = __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true);
+    return a && b && c && d;
+}
 HS_Q qv q_load_entry(const u32 *entry) {      // this lane's coordinate of a 40-word entry
     const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * q_lane());
     qv r;
@@ -57,7 +63,7 @@ HS_Q void q_store_entry(u32 *entry, const qv &e) {
 #pragma unroll
     for (int i = 0; i < 5; i++) p[i] = make_uint2(e.v[2 * i], e.v[2 * i + 1]);
 }
-// lane 0: x' has the encoded sign (or x' = 0); lane 1: y' equals the encoded y; lanes 2,3: true
+// lane 0: x' has the encoded sign (or x' = 0); lane 1: y' equals the encoded y; lane 2: Z != 0; lane 3: true
 HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
     u32 w[8];
     fe_to_words(w, affine);
@@ -69,7 +75,8 @@ HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
     for (int i = 0; i < 8; i++) { dy |= w[i] ^ yw[i]; nz |= w[i]; }
     const u32 lane = q_lane();
     qflags r;
-    r.f = lane == 0 ? ((w[0] & 1) == (enc[7] >> 31) || nz == 0) : (lane == 1 ? dy == 0 : true);
+    // lane 2 holds Z * Z^-1: 1, or 0 when Z = 0 (a faulted accumulator) - fail closed (ge_match_point, verify.h)
+    r.f = lane == 0 ? ((w[0] & 1) == (enc[7] >> 31) || nz == 0) : (lane == 1 ? dy == 0 : (lane == 2 ? nz != 0 : true));
     return r;
 }
 // lane 0: X == 0; lane 1: Y == Z; (identity test of a projective point held in a quad)
@@ -83,6 +90,7 @@ HS_Q qflags q_identity_lanes(const qv &p) {
 #else
 HS_Q qv q_invert(const qv &z) { qv r; for (int i = 0; i < 4; i++) fe_invert(r.l[i], z.l[i]); return r; }
 HS_Q bool q_quad_and01(const qflags &f) { return f.f[0] && f.f[1]; }
+HS_Q bool q_quad_all(const qflags &f) { return f.f[0] && f.f[1] && f.f[2] && f.f[3]; }
 HS_Q qv q_load_entry(const u32 *entry) {
     qv r; for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i]; return r;
 }
@@ -95,7 +103,7 @@ HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
     fe ye; fe_from_words(ye, enc); fe_to_words(yw, ye);
     u32 dy = 0, nz = 0;
     for (int i = 0; i < 8; i++) { dy |= wy[i] ^ yw[i]; nz |= wx[i]; }
-    qflags r; r.f[0] = (wx[0] & 1) == (enc[7] >> 31) || nz == 0; r.f[1] = dy == 0; r.f[2] = r.f[3] = true;
+    qflags r; r.f[0] = (wx[0] & 1) == (enc[7] >> 31) || nz == 0; r.f[1] = dy == 0; r.f[2] = !fe_iszero(affine.l[2]); r.f[3] = true;
     return r;
 }
 HS_Q qflags q_identity_lanes(const qv &p) {
@@ -150,19 +158,16 @@ HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw
     }
     const qv zinv = q_invert(q_perm<2, 2, 2, 2>(acc));
     const qv aff = q_mul(acc, zinv);                        // (x', y', 1, t')
-    return ok && q_quad_and01(q_match_encoding(aff, renc));
+    return ok && q_quad_all(q_match_encoding(aff, renc));
 }
 // The other way to finish: R was decompressed elsewhere (concurrently, by another wavefront of
 // the workgroup) to affine (rx, ry); compare as points, X == x_R Z and Y == y_R Z - two
 // multiplications instead of an inversion on the critical path.  r_flags: HS_F_* of R.
 HS_Q bool cached_quad_match_point(const qv &acc, const fe &rx, const fe &ry, u32 r_flags, bool strict) {
-    const qv z = q_perm<2, 2, 2, 2>(acc);
-    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
-    const qv lhs = q_sel<0b1100>(acc, z);
-    const qflags f = q_eq(rhs, q_carry(lhs));
+    const qflags f = q_match_point(acc, rx, ry);
     bool ok = (r_flags & HS_F_ONCURVE) != 0;
     if (strict) ok = ok && !(r_flags & HS_F_SMALL);
-    return ok && q_quad_and01(f);
+    return ok && q_quad_all(f);
 }
 
 // ---- one lane per signature (throughput form, large batches) -------------------------------
@@ -229,7 +234,8 @@ HS_HD bool cached_finish(const ge_p3 &acc, const u32 renc[8], bool strict) {
     u32 dy = 0, nz = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { dy |= yw[i] ^ ew[i]; nz |= xw[i]; }
-    return ok && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0);
+    // Z != 0: fail closed on a faulted (all-zero) accumulator, whose "affine" image is (0, 0) - ge_match_point, verify.h
+    return ok && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0) && !fe_iszero(acc.Z);
 }
 // p + q for two extended points (q converted to cached form on the fly)
 HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {

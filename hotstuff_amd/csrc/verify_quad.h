@@ -99,6 +99,11 @@ HS_Q qv q_load(const fe (*tab)[4], int idx) { return tab[idx][q_lane()]; }
 // per-lane equality of canonical values -> one flag per lane
 struct qflags { bool f; };
 HS_Q qflags q_eq(const qv &a, const qv &b_reduced) { qflags r; r.f = fe_eq(a, b_reduced); return r; }
+// lanes 0, 1: a == b; lanes 2, 3: b != 0
+HS_Q qflags q_eq_nz(const qv &a, const qv &b_reduced) {
+    qflags r; const bool eq = fe_eq(a, b_reduced), nz = !fe_iszero(b_reduced);
+    r.f = q_lane() < 2 ? eq : nz; return r;
+}
 #else
 // ------------------------------------------------------------------ host: qv = four lanes
 #define HS_Q inline
@@ -134,6 +139,9 @@ HS_Q qv q_lanes(const fe &c0, const fe &c1, const fe &c2, const fe &c3) { qv r; 
 HS_Q qv q_load(const fe (*tab)[4], int idx) { qv r; for (int i = 0; i < 4; i++) r.l[i] = tab[idx][i]; return r; }
 struct qflags { bool f[4]; };
 HS_Q qflags q_eq(const qv &a, const qv &b_reduced) { qflags r; for (int i = 0; i < 4; i++) r.f[i] = fe_eq(a.l[i], b_reduced.l[i]); return r; }
+HS_Q qflags q_eq_nz(const qv &a, const qv &b_reduced) {
+    qflags r; for (int i = 0; i < 4; i++) r.f[i] = i < 2 ? fe_eq(a.l[i], b_reduced.l[i]) : !fe_iszero(b_reduced.l[i]); return r;
+}
 #endif
 
 HS_HD fe fe_small(u32 c) { fe r; fe_0(r); r.v[0] = c; return r; }
@@ -198,6 +206,15 @@ HS_Q qv q_dbl(const qv &p) {
     return q_mul(l, r);                                                             // (EF, DS, FD, ES)
 }
 
+// acc == (rx, ry) as points: X == x_R Z (lane 0), Y == y_R Z (lane 1), and Z != 0 (lanes 2, 3) -
+// see ge_match_point (verify.h) for why the last test is there.  The caller ANDs the four flags.
+HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
+    const qv z = q_perm<2, 2, 2, 2>(acc);
+    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
+    const qv lhs = q_carry(q_sel<0b1100>(acc, z));
+    return q_eq_nz(rhs, lhs);
+}
+
 // The quad stage-2 core.  ax, ay, rx, ry (affine A and R) and the recoded scalars are uniform
 // across the four lanes of a quad.  atab entries are per lane: on the GPU each lane keeps its
 // own component in private memory.
@@ -238,11 +255,7 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
             acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
         }
     }
-    // acc == R as points: X == x_R Z (lane 0), Y == y_R Z (lane 1); lanes 2, 3 compare Z with Z
-    const qv z = q_perm<2, 2, 2, 2>(acc);
-    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
-    const qv lhs = q_sel<0b1100>(acc, z);
-    return q_eq(rhs, q_carry(lhs));
+    return q_match_point(acc, rx, ry);
 }
 
 // stage 2 reading the workspace written by k_prepare

@@ -101,6 +101,40 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
         out[i] = (fl && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
     }
 }
+// Every finishing form must reject an all-zero accumulator (what an arithmetic fault leaves behind:
+// it is absorbing under the addition formulas and satisfies X == x*Z, Y == y*Z trivially).
+// Bit i of the result is set when form i ACCEPTED it: 0 lane, 1 quad point match, 2 quad
+// encoding match (inversion), 3 one-lane cached finish.  Batch mode, R = (sqrt(-1), 0) / y = 0.
+uint32_t emu_zero_accumulator_accepts(void) {
+    fe zero, one; fe_0(zero); fe_1(one);
+    ge_p3 acc; acc.X = acc.Y = acc.Z = acc.T = zero;
+    u32 out = 0;
+    // any point will do for the comparisons; use the base point as "R"
+    ge_p3 b; ge_basepoint(b);
+    if (ge_match_point(acc, b.X, b.Y)) out |= 1;
+    const qv q = q_lanes(zero, zero, zero, zero);
+    const qflags f = q_match_point(q, b.X, b.Y);
+    if (f.f[0] && f.f[1] && f.f[2] && f.f[3]) out |= 2;
+    u32 renc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // encoding of y = 0, sign 0
+    if (q_quad_all(q_match_encoding(q_mul(q, q_invert(q_perm<2, 2, 2, 2>(q))), renc))) out |= 4;
+    if (cached_finish(acc, renc, false)) out |= 8;
+    return out;
+}
+// sanity of the same four forms on a genuine point: acc = 3B scaled by Z = 5, R = 3B
+uint32_t emu_genuine_point_accepts(void) {
+    ge_p3 b, p; ge_basepoint(b);
+    ge_p1p1 t; ge_cached c; ge_dbl(t, b); ge_p1p1_to_p3(p, t, true); ge_to_cached(c, b); ge_add(t, p, c, false); ge_p1p1_to_p3(p, t, true);
+    fe zi, ax, ay; fe_invert(zi, p.Z); fe_mul(ax, p.X, zi); fe_mul(ay, p.Y, zi);
+    u32 out = 0;
+    if (ge_match_point(p, ax, ay)) out |= 1;
+    const qv q = q_lanes(p.X, p.Y, p.Z, p.T);
+    const qflags f = q_match_point(q, ax, ay);
+    if (f.f[0] && f.f[1] && f.f[2] && f.f[3]) out |= 2;
+    u32 renc[8]; fe_to_words(renc, ay); { u32 xw[8]; fe_to_words(xw, ax); renc[7] |= (xw[0] & 1) << 31; }
+    if (q_quad_all(q_match_encoding(q_mul(q, q_invert(q_perm<2, 2, 2, 2>(q))), renc))) out |= 4;
+    if (cached_finish(p, renc, false)) out |= 8;
+    return out;
+}
 // ---- committee key cache (verify_cached.h) ----
 size_t emu_keyset_words(size_t nkeys) { return nkeys * (size_t)HS_KS_KEY_WORDS; }
 // tab: nkeys * HS_KS_KEY_WORDS words; flag: nkeys words.  Key `nkeys` is not stored here: the

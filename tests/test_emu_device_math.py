@@ -215,3 +215,15 @@ def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz, lane_form):
     sigs = b"".join(bytes.fromhex(v["sig"]) for v in vec)
     assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 1, lane_form)] == [v["strict"] for v in vec]
     assert [bool(b) for b in _emu_cached(emu, pks, list(range(n)), msgs, 32, sigs, n, 0, lane_form)] == [v["cofactorless"] for v in vec]
+
+
+def test_every_finishing_form_fails_closed_on_a_zero_accumulator(emu):
+    """An all-zero accumulator is absorbing under the addition formulas and satisfies
+    X == x_R * Z and Y == y_R * Z for every R; it is what a faulted doubling produced on the GPU
+    once (the v_subrev_u32_dpp trap) and every signature verified.  All four ways the
+    kernels finish must reject it - and still accept a genuine point."""
+    import ctypes
+    emu.emu_zero_accumulator_accepts.restype = ctypes.c_uint32
+    emu.emu_genuine_point_accepts.restype = ctypes.c_uint32
+    assert emu.emu_genuine_point_accepts() == 0b1111
+    assert emu.emu_zero_accumulator_accepts() == 0
