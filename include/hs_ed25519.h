@@ -152,8 +152,9 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
  * The reference's Core task verifies one certificate per message as rounds stream by
  * (consensus/src/core.rs:379, 401 -> QC::verify messages.rs:197).  A ring keeps `slots` rounds in
  * flight: each slot owns a HIP stream, PINNED host staging and device buffers; copies and kernels
- * of different slots overlap.  Protocol per slot:  begin (get the pinned pointers, write the packed tuples in
- * place - no second host copy) -> submit (asynchronous) -> poll / wait (verdict + bitmap).
+ * of different slots overlap.  Protocol per slot:  begin (get the pinned pointers, write the
+ * packed tuples in place - no second host copy) -> submit (asynchronous) -> poll / wait
+ * (verdict + bitmap).
  *   ks != NULL: the ring verifies through that key set; `keys` then holds n uint32 indices,
  *               otherwise n*32 key bytes.
  *   digest_stride 0: `digests` holds one shared 32-byte digest; 32: one per signature.
@@ -167,7 +168,10 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
  *                                 zero-copy for slot_batch <= 16,384, stream operations above
  * A ring is driven by one thread at a time (the reference's single Core task); different rings
  * are independent.  wait returns 1 / 0 / <0 like every verify call; poll returns 1 when the
- * slot's round has completed, 0 while it runs. */
+ * slot's round has completed, 0 while it runs.  The slot's pinned buffers belong to the round
+ * from begin until wait returns: do not write them while it is in flight.  A key set given to
+ * hs_ed25519_ring_create must outlive the ring; destroy rings, contexts and key sets before
+ * hs_ed25519_shutdown. */
 #define HS_ED25519_RING_AUTO 0u
 #define HS_ED25519_RING_GRAPH 1u
 #define HS_ED25519_RING_STREAM_OPS 2u
