@@ -24,11 +24,18 @@ def shard_bounds(n, world, rank):
     return lo, hi, S
 
 
+_gather_out = {}     # (device, bytes) -> reusable output buffer: one QC per call, no allocation on the path
+
+
 def gather_bitmaps(local_bitmap, group=None):
     """All-gather equal-sized uint8 bitmap slices -> concatenated uint8 tensor
-    (world * len(local_bitmap) bytes) on every rank."""
+    (world * len(local_bitmap) bytes) on every rank.  The returned tensor is reused by the next
+    call with the same shape on the same device: copy it to keep it."""
     world = dist.get_world_size(group)
-    out = torch.empty(world * local_bitmap.numel(), dtype=torch.uint8, device=local_bitmap.device)
+    key = (local_bitmap.device, world * local_bitmap.numel())
+    out = _gather_out.get(key)
+    if out is None:
+        out = _gather_out[key] = torch.empty(key[1], dtype=torch.uint8, device=local_bitmap.device)
     dist.all_gather_into_tensor(out, local_bitmap.contiguous(), group=group)
     return out
 
@@ -39,7 +46,7 @@ def verify_sharded(verify_shard, n, group=None, device=None):
     verify_shard(lo, hi, S) -> uint8 tensor of S // 8 bytes on `device`: the accept
     bitmap of signatures [lo, hi) (bit j = signature lo + j; bits past hi - lo zero).
     Returns (all_ok: bool, bitmap: uint8 tensor of ceil(n / 8) bytes), identical on
-    every rank.
+    every rank.  `bitmap` aliases a buffer the next call of the same shape overwrites.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -78,10 +85,14 @@ class GpuShardVerifier:
         # all-gather) are ordered behind it explicitly - a raw handle of 0 would mean "the
         # context's stream" to the C-ABI, not torch's null stream
         self._stream = torch.cuda.ExternalStream(self.ctx.stream, device=sigs.device)
+        self._buf, self._buf_key = None, None
 
     def __call__(self, lo, hi, S):
         dev = self.sigs.device
-        bitmap = torch.zeros(S // 8, dtype=torch.uint8, device=dev)
+        # the kernels write whole 64-bit words for [lo, hi); the tail up to S stays zero from here
+        if self._buf is None or self._buf_key != (lo, hi, S):
+            self._buf, self._buf_key = torch.zeros(S // 8, dtype=torch.uint8, device=dev), (lo, hi, S)
+        bitmap = self._buf
         n = hi - lo
         if n > 0:
             dg = self.digests if self.digest_stride == 0 else self.digests[32 * lo:]
