@@ -92,6 +92,32 @@ def test_steady_state_replays_one_graph_per_slot_and_follows_the_data(oracle):
     ring.close()
 
 
+@pytest.mark.parametrize("kind", ["graph", "auto"])
+def test_ring_slot_changes_kernel_topology_between_rounds(kind):
+    """A slot whose rounds cross the 32,768-signature threshold alternates between the fused
+    kernel (one kernel node) and k_prepare + k_verify (two): the captured graph cannot be updated
+    in place and is re-instantiated.  40,000 signatures (6,667 distinct, tiled) / 1,000 / 40,000."""
+    base = 6667
+    dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
+    big = 40000
+    pk_t = (pk * 6)[: 32 * big]
+    sg_t = bytearray((sg * 6)[: 64 * big])
+    victims = [1, 6667, 32768, 39999]
+    for v in victims:
+        sg_t[64 * v + 33] ^= 0x08
+    sg_t = bytes(sg_t)
+    ring = _lib.RoundRing(big, slots=1, kind=kind)
+    for n, expect in ((big, victims), (1000, [1]), (big, victims), (big, victims)):
+        fill(ring, 0, dg, pk_t[: 32 * n], sg_t[: 64 * n], n, True)
+        ring.submit(0, _lib.BATCH)
+        ok, bm = ring.wait(0)
+        got = bits(bm, n)
+        assert not ok and [i for i in range(n) if not got[i]] == expect
+    if kind == "graph":
+        assert ring.stats() == (3, 4)        # captured for 40,000, 1,000, 40,000; the last round replays
+    ring.close()
+
+
 def test_ring_over_the_committee_key_cache(oracle):
     n = 500
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
