@@ -114,3 +114,19 @@ def test_code_object_has_no_reversed_subtract_with_dpp():
     if bad is None:
         pytest.skip("LLVM tools not installed")
     assert bad == []
+
+
+def test_the_dpp_guard_is_live(tmp_path):
+    """The guard must flag a code object that does contain the instruction: the characterisation
+    program (tools/dpp_subrev_check.hip) issues v_subrev_u32_dpp on purpose."""
+    import subprocess
+    import __graft_entry__ as g
+    if not os.path.exists(g.HIPCC):
+        pytest.skip("hipcc not installed")
+    so = str(tmp_path / "dpp_check.so")
+    subprocess.run([g.HIPCC, "--offload-arch=gfx950", "-O2", "-shared", "-fPIC",
+                    os.path.join(ROOT, "tools", "dpp_subrev_check.hip"), "-o", so], check=True, capture_output=True)
+    bad = g.forbidden_instructions(so, marker="s_endpgm")
+    if bad is None:
+        pytest.skip("LLVM tools not installed")
+    assert len(bad) == 3 and all("v_subrev_u32_dpp" in l for l in bad)
