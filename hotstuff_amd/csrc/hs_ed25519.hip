@@ -59,6 +59,19 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
     }
 }
 
+// TC::verify's per-vote digests SHA-512(round_le || high_qc_round_le)[..32]
+// (consensus/src/messages.rs:307-311), one lane per vote, ahead of the verify kernels.
+__global__ void __launch_bounds__(64)
+k_tc_digests(unsigned long long round, const unsigned long long *__restrict__ hq_rounds, u32 n, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 d[8];
+    tc_vote_digest(d, round, hq_rounds[i]);
+    uint4 *o = reinterpret_cast<uint4 *>(out + (size_t)8 * i);
+    o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
 // Four lanes per signature (verify_quad.h): a wavefront covers 16 signatures, so a
 // 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
 __device__ fe g_btab4[HS_BTAB_ENTRIES][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
@@ -343,6 +356,8 @@ struct hs_ed25519_ctx {
     uint8_t *d_out = nullptr;     // bitmap (8*ceil(cap/64)) | nreject (4) padded
     uint8_t *h_in = nullptr;      // pinned mirror of d_in
     uint8_t *h_out = nullptr;     // pinned mirror of d_out
+    u32 *d_tc = nullptr;          // timeout-certificate digests built by k_tc_digests (tc_cap signatures)
+    size_t tc_cap = 0;
     bool staging = false;
     // optional profiling: a ring of (start, after-prepare, after-verify) HIP events recorded
     // on the launch stream, read back by hs_ed25519_ctx_kernel_times after a synchronize
@@ -439,6 +454,7 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->d_tc) (void)hipFree(c->d_tc);
     ctx_release(c);
     delete c;
 }
@@ -547,13 +563,31 @@ static int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_s
     if (!d_digests) return fail(HS_ED25519_E_ARG, "verify_device: null digests");
     if (misaligned(d_digests, 16)) return fail(HS_ED25519_E_ARG, "verify_device: misaligned digests");
     if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "verify_device: bad digest_stride");
-    m.digests = (const u32 *)d_digests; m.stride_words = (u32)(digest_stride / 4); m.hq_rounds = nullptr; m.round = 0;
+    m.digests = (const u32 *)d_digests; m.stride_words = (u32)(digest_stride / 4);
     return 0;
 }
-static int make_tc_src(msg_src &m, uint64_t round, const uint64_t *d_hq) {
+// timeout certificate: build the n per-vote digests into the context's buffer (k_tc_digests, same stream)
+static int make_tc_src(hs_ed25519_ctx *ctx, msg_src &m, uint64_t round, const uint64_t *d_hq, size_t n, void *stream) {
     if (!d_hq) return fail(HS_ED25519_E_ARG, "verify_device_tc: null high_qc_rounds");
     if (misaligned(d_hq, 8)) return fail(HS_ED25519_E_ARG, "verify_device_tc: misaligned high_qc_rounds");
-    m.digests = nullptr; m.stride_words = 0; m.hq_rounds = (const unsigned long long *)d_hq; m.round = round;
+    if (n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device_tc: bad n");
+    if (n > ctx->tc_cap) {
+        const size_t cap = round_up(n < 1024 ? 1024 : n, 64);
+        hipStream_t own = ctx->stream;
+        HS_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : own), "stream sync");    // the old buffer may be in use
+        if (ctx->d_tc) (void)hipFree(ctx->d_tc);
+        ctx->d_tc = nullptr; ctx->tc_cap = 0;
+        HS_HIP(hipMalloc((void **)&ctx->d_tc, cap * 32), "hipMalloc TC digests");
+        ctx->tc_cap = cap;
+    }
+    unsigned long long r = round;
+    const unsigned long long *p_hq = (const unsigned long long *)d_hq;
+    u32 nn = (u32)n;
+    u32 *p_out = ctx->d_tc;
+    void *a[] = { &r, &p_hq, &nn, &p_out };
+    HS_HIP(hipLaunchKernel((const void *)k_tc_digests, dim3((nn + 63) / 64), dim3(64), a, 0,
+                           stream ? (hipStream_t)stream : ctx->stream), "launch k_tc_digests");
+    m.digests = ctx->d_tc; m.stride_words = 8;
     return 0;
 }
 
@@ -576,7 +610,7 @@ extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, 
     if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device_tc: null context");
     if (n == 0) return 0;
     msg_src m;
-    int rc = make_tc_src(m, round, d_high_qc_rounds);
+    int rc = make_tc_src(ctx, m, round, d_high_qc_rounds, n, stream);
     if (rc) return rc;
     return enqueue_cold(ctx, m, d_pks, d_sigs, n, HS_ED25519_STRICT, d_bitmap, d_nreject, stream);
 }
@@ -755,7 +789,7 @@ extern "C" int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_
     if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_tc_cached: null context / key set");
     if (n == 0) return 0;
     msg_src m;
-    int rc = make_tc_src(m, round, d_high_qc_rounds);
+    int rc = make_tc_src(ctx, m, round, d_high_qc_rounds, n, stream);
     if (rc) return rc;
     return enqueue_cached(ctx, ks, m, d_key_idx, d_sigs, n, HS_ED25519_STRICT, d_bitmap, d_nreject, stream);
 }

@@ -99,22 +99,19 @@ HS_HD void tc_vote_digest(u32 out[8], u64 round, u64 high_qc_round) {
     }
 }
 
-// Where signature j's 32-byte message comes from: packed digests (stride 0 = one shared digest)
-// or, for a timeout certificate, derived on the device from (round, high_qc_round_j).
+// Where signature j's 32-byte message comes from: packed digests, stride 0 = one shared digest.
+// (A timeout certificate's per-vote digests are built on the device too, but by a kernel of their own -
+// k_tc_digests - rather than inside every verify kernel: a second inlined SHA-512 made each of them
+// ~5,000 instructions longer, and the five-wavefront cached kernel, whose wavefronts run two different
+// code regions at once, 4-6 % slower on the common QC path.)
 struct msg_src {
     const u32 *digests;
     u32 stride_words;
-    const unsigned long long *hq_rounds;     // non-null: TC mode
-    unsigned long long round;
 };
 HS_HD void load_msg(u32 msg[8], const msg_src &m, u32 j) {
-    if (m.hq_rounds) {
-        tc_vote_digest(msg, m.round, m.hq_rounds[j]);
-    } else {
-        const u32 *p = m.digests + (size_t)m.stride_words * j;
+    const u32 *p = m.digests + (size_t)m.stride_words * j;
 #pragma unroll
-        for (int t = 0; t < 8; t++) msg[t] = p[t];
-    }
+    for (int t = 0; t < 8; t++) msg[t] = p[t];
 }
 
 // ---------------------------------------------------------------- scalars mod L, 32-bit limbs
