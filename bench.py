@@ -446,7 +446,7 @@ def main():
         assert int(nrej.sum().item()) == 0, "cached path rejected valid signatures"
         k_ms = sum(c.kernel_times()[1] for c in ctxs) / max(1, sum(c.kernel_times()[2] for c in ctxs))
         cached = {"value": round(n * args.steps / c_elapsed, 1), "unit": "verifies/s",
-                  "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": "k_verify_cached",
+                  "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": _lib.lib().hs_ed25519_cached_kernel_for(n).decode(),
                   "avg_kernel_ms": round(k_ms, 4), "keys": n, "keyset_hbm_bytes": ks.hbm_bytes(),
                   "keyset_build_ms": round(build_ms, 2),
                   "table_bytes_read_per_verify": 64 * 160,
@@ -483,7 +483,7 @@ def main():
             gather = 32 * 160 * nl                      # bytes of the keys' tables read per launch
             cached["large_committee"] = {
                 "n_validators": Nv, "signatures": nl, "keyset_hbm_bytes": lks.hbm_bytes(),
-                "kernel": "k_verify_cached_lane2" if 16384 < nl <= 131072 else "k_verify_cached*", "avg_kernel_ms": round(lk_ms, 4),
+                "kernel": _lib.lib().hs_ed25519_cached_kernel_for(nl).decode(), "avg_kernel_ms": round(lk_ms, 4),
                 "value": round(nl * reps / l_el, 1), "unit": "verifies/s",
                 "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

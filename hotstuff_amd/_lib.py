@@ -49,6 +49,8 @@ def lib():
                 l.hs_ed25519_dominant_kernel.restype = ctypes.c_char_p
                 l.hs_ed25519_dominant_kernel_for.argtypes = [sz]
                 l.hs_ed25519_dominant_kernel_for.restype = ctypes.c_char_p
+                l.hs_ed25519_cached_kernel_for.argtypes = [sz]
+                l.hs_ed25519_cached_kernel_for.restype = ctypes.c_char_p
                 l.hs_ed25519_verify_shared.argtypes = [vp, vp, vp, sz, u32, vp]
                 l.hs_ed25519_verify_shared.restype = ctypes.c_int
                 l.hs_ed25519_verify_multi.argtypes = [vp, vp, vp, sz, u32, vp]
@@ -140,6 +142,7 @@ def ensure_init():
 
 KERNEL_AUTO, KERNEL_LANE, KERNEL_QUAD, KERNEL_FUSED = 0, 1, 2, 3
 KERNEL_CACHED_SINGLE_ROLE = 10    # key-cache path only: quad kernel finishing by inversion
+KERNEL_CACHED_LANE2_R = 12        # key-cache path only: two lanes per signature + R-decompression wavefront (cold path: as 2)
 
 
 def set_kernel(which):

@@ -305,6 +305,74 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
     }
 }
 
+// Two lanes per signature with the square root off the chains: a workgroup of THREE wavefronts
+// covers 64 signatures.  Wavefronts 0 and 1 run the paired addition chains (32 signatures each);
+// wavefront 2 meanwhile decompresses the 64 R's one lane each and hands (x_R, y_R, flags) over
+// through LDS; the chains then finish with a projective comparison instead of an inversion that both
+// lanes of a pair would execute.  Per 64 signatures: 2 x 52 K + 36 K instructions instead of 2 x 82 K.
+__global__ void __launch_bounds__(192)
+k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                       const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                       u32 *__restrict__ bitmap32, u32 *__restrict__ nreject) {
+    __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool strict = (mode & HS_MODE_STRICT) != 0;
+    ge_p3 acc;
+    bool ok = false, active = false;
+    if (wave == 2) {
+        const u32 i = blockIdx.x * 64 + lane;
+        const u32 j = i < n ? i : n - 1;
+        u32 enc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) enc[t] = sigs[(size_t)16 * j + t];
+        ge_p3 R;
+        u32 fl = ge_decompress(R, enc) ? HS_F_ONCURVE : 0;
+        if (strict) fl |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+#pragma unroll
+        for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
+        s_r[20][lane] = fl;
+    } else {
+        const u32 i = blockIdx.x * 64 + wave * 32 + (lane >> 1);
+        active = i < n;
+        const u32 j = active ? i : n - 1;
+        const u32 ki_raw = key_idx[j];
+        const bool known = ki_raw < nkeys;
+        const u32 ki = known ? ki_raw : 0;
+        const u32 *sig = sigs + (size_t)16 * j;
+        u32 kw[8], sw[8], msg[8];
+        load_msg(msg, msgs, j);
+        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+        const u32 fl = ks.flag[ki];
+        ok = ok && known && (fl & HS_F_ONCURVE);
+        if (strict) ok = ok && !(fl & HS_F_SMALL);
+        cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw);
+    }
+    __syncthreads();
+    if (wave == 2) return;
+    const u32 slot = wave * 32 + (lane >> 1);
+    fe rx, ry;
+#pragma unroll
+    for (int t = 0; t < 10; t++) { rx.v[t] = s_r[t][slot]; ry.v[t] = s_r[10 + t][slot]; }
+    const bool curve = cached_lane_match_point(acc, rx, ry, s_r[20][slot], strict);
+    unsigned long long m = __ballot(ok && curve && active);
+    m &= m >> 1;                         // both lanes of the pair
+    m &= 0x5555555555555555ull;          // gather bit 2q -> bit q
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0xffffffffull;
+    if (lane == 0) {
+        bitmap32[blockIdx.x * 2 + wave] = (u32)m;
+        if (nreject) {
+            const u32 first = blockIdx.x * 64 + wave * 32;
+            const u32 sigs_here = first < n ? min(32u, n - first) : 0u;
+            const u32 bad = sigs_here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
+
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches
 __global__ void __launch_bounds__(64)
 k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
@@ -376,8 +444,11 @@ static std::vector<hs_ed25519_ctx *> g_free;
 static int g_live = 0;
 static const int kMaxPool = 8;
 static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own window table
-static const size_t kCachedLaneMin = 16384;    // cached path: 4 lanes per signature up to here, 2 above ...
-static const size_t kCachedLane1Min = 131072;  // ... and 1 lane per signature above this
+// cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
+// one lane per signature above (profiles/r1_cached_threshold_sweep.md: the three-wavefront form wins or ties
+// from 1,024 to ~200,000 signatures; the one-lane form does the least total work once the chip is several
+// times over-subscribed)
+static const size_t kCachedLane1Min = 196608;
 static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
 static const size_t kZeroCopyMax = 16384;   // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
@@ -477,8 +548,10 @@ extern "C" int hs_ed25519_init(int device, size_t max_batch) {
     static fe tab4[HS_BTAB_ENTRIES][4];
     make_base_table_quad(tab4, HS_BTAB_ENTRIES);
     HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
-    if (const char *k = getenv("HS_ED25519_KERNEL"))
-        g_kernel.store(!strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : 0)));
+    if (const char *k = getenv("HS_ED25519_KERNEL")) {
+        const int sel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : atoi(k)));
+        if ((sel >= 0 && sel <= 3) || sel == 10 || sel == 12) g_kernel.store(sel);
+    }
     HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
     return 0;
@@ -494,15 +567,23 @@ extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
 // 3 = k_verify_fused.  For tests and A/B measurements; returns the previous setting.
 extern "C" int hs_ed25519_set_kernel(int which) {
     const int old = g_kernel.load();
-    if ((which >= 0 && which <= 3) || which == 10) g_kernel.store(which);
+    if ((which >= 0 && which <= 3) || which == 10 || which == 12) g_kernel.store(which);
     return old;
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const int forced = g_kernel.load();
-    const int k = forced == 10 ? 3 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1));
+    const int k = forced == 10 ? 3 : (forced == 12 ? 2 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1)));
     return k == 1 ? "k_verify" : (k == 2 ? "k_verify_quad" : "k_verify_fused");
 }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
+extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
+    const int forced = g_kernel.load();
+    if (forced == 1 || (!forced && n > kCachedLane1Min)) return "k_verify_cached_lane";
+    if (forced == 2) return "k_verify_cached_lane2";
+    if (forced == 3) return "k_verify_cached_5w";
+    if (forced == 10) return "k_verify_cached";
+    return "k_verify_cached_lane2r";
+}
 
 static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
@@ -542,7 +623,7 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     const int forced = g_kernel.load();
-    const int kern = forced == 10 ? 3 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1));
+    const int kern = forced == 10 ? 3 : (forced == 12 ? 2 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1)));
     if (ev) ctx->ev_mid[slot] = kern != 3;
     if (kern == 3) {
         HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
@@ -751,16 +832,19 @@ static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_
     const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
     hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
     if (ev) ctx->ev_mid[slot] = 0;
-    // four lanes per signature for latency, two in the middle, one once the chip is full anyway
     const int forced = g_kernel.load();
-    const int lanes = forced ? (forced == 1 ? 1 : (forced == 2 ? 2 : 4))      /* 3 and 10 -> 4 lanes */
-                             : (n > kCachedLane1Min ? 1 : (n > kCachedLaneMin ? 2 : 4));
+    const int lanes = forced ? (forced == 1 ? 1 : ((forced == 2 || forced == 12) ? 2 : 4))      /* 3 and 10 -> 4 lanes */
+                             : (n > kCachedLane1Min ? 1 : 2);
     if (lanes == 1)
         HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane");
-    else if (lanes == 2)
+    else if (lanes == 2 && forced == 2)     // selector 2: the single-role two-lane kernel (inversion finish), for A/B
         HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane2");
+    else if (lanes == 2)
+        HS_HIP(ev ? hipExtLaunchKernel((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, 0, st, ev[0], ev[2], 0)
+                  : hipLaunchKernel((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, 0, st),
+               "launch k_verify_cached_lane2r");
     else if (forced == 2 + 8)      // selector 10: the single-wavefront-role quad kernel (A/B measurements)
         HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached");

@@ -271,6 +271,25 @@ HS_Q bool verify_cached_lane2(const u32 *atab, const u32 *btab, u32 kw[8], u32 s
     ge_add_p3(acc, mine, other);          // both lanes of the pair now hold R' (addition commutes)
     return cached_finish(acc, renc, strict);
 }
+// The same chains, returning R' for a projective comparison against an R decompressed elsewhere.
+HS_Q void cached_lane2_chain(ge_p3 &acc, const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8]) {
+    const bool odd = threadIdx.x & 1u;
+    const u32 *tab = odd ? btab : atab;
+    u32 dw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) dw[i] = odd ? sw[i] : kw[i];
+    ge_p3 mine, other;
+    cached_chain(mine, tab, dw);
+    other.X = q_perm<1, 0, 3, 2>(mine.X); other.Y = q_perm<1, 0, 3, 2>(mine.Y);
+    other.Z = q_perm<1, 0, 3, 2>(mine.Z); other.T = q_perm<1, 0, 3, 2>(mine.T);
+    ge_add_p3(acc, mine, other);
+}
 #endif
+// finishing against a decompressed R (one-lane forms): flags of R as in cached_quad_match_point
+HS_HD bool cached_lane_match_point(const ge_p3 &acc, const fe &rx, const fe &ry, u32 r_flags, bool strict) {
+    bool ok = (r_flags & HS_F_ONCURVE) != 0;
+    if (strict) ok = ok && !(r_flags & HS_F_SMALL);
+    return ok && ge_match_point(acc, rx, ry);
+}
 
 }  // namespace hs

@@ -203,9 +203,10 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
 
 /* Cold-path kernel choice: 0 = by batch size (default: fused 4-lanes-per-signature kernel up to
  * 32,768 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
- * 2 = two kernels with the quad stage 2, 3 = fused.  (The key-cache path maps 1 / 2 / 3 to its
- * one- / two- / four-lanes-per-signature kernels; 10 = its four-lane kernel without the
- * concurrent R-decompression wavefront.)  All variants have the same accept set; this
+ * 2 = two kernels with the quad stage 2, 3 = fused.  (The key-cache path: 0 = two lanes per
+ * signature plus a concurrent R-decompression wavefront up to 196,608 signatures, one lane per
+ * signature above; 12 / 1 force those two; 3 = four lanes per signature plus the R wavefront;
+ * 2 and 10 = the two- and four-lane kernels finishing by inversion instead.)  All variants have the same accept set; this
  * exists for tests and A/B measurements (env HS_ED25519_KERNEL=lane|quad|fused sets it at init).
  * Returns the previous setting. */
 int hs_ed25519_set_kernel(int which);
@@ -213,6 +214,7 @@ int hs_ed25519_set_kernel(int which);
 /* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
+const char *hs_ed25519_cached_kernel_for(size_t n);        /* for an n-signature key-cache call */
 
 #ifdef __cplusplus
 }

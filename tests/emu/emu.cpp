@@ -174,6 +174,14 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
         bool curve;
         if (g_cached_lane_form == 1) {
             curve = verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
+        } else if (g_cached_lane_form == 3) {      // one-lane chains + R decompressed separately (k_verify_cached_lane2r)
+            ge_p3 R; u32 rf = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
+            if (strict) rf |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+            ge_p3 pa, pb, acc;
+            cached_chain(pa, tab + ki * (size_t)HS_KS_KEY_WORDS, kw);
+            cached_chain(pb, btab, sw);
+            ge_add_p3(acc, pa, pb);
+            curve = cached_lane_match_point(acc, R.X, R.Y, rf, strict);
         } else if (g_cached_lane_form == 2) {      // chain + R decompressed separately (the 5-wavefront kernel)
             ge_p3 R; u32 rf = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
             if (strict) rf |= ge_is_small_order(R) ? HS_F_SMALL : 0;

@@ -161,7 +161,7 @@ def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode, lane_form=0):
     return out.raw
 
 
-@pytest.mark.parametrize("lane_form", [0, 1, 2])
+@pytest.mark.parametrize("lane_form", [0, 1, 2, 3])
 def test_cached_path_on_edge_vectors(emu, edge_vectors, lane_form):
     """Committee key cache algorithm (verify_cached.h: per-key window tables, 64 table additions,
     R checked through one inversion instead of a decompression): the vector's key is
@@ -204,10 +204,11 @@ def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
     assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("lane_form", [0, 1, 2])
+@pytest.mark.parametrize("lane_form", [0, 1, 2, 3])
 def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz, lane_form):
     """lane_form 0 = quad core finishing by inversion, 1 = one lane per signature,
-    2 = quad chain + separately decompressed R compared as points (the 5-wavefront kernel)."""
+    2 = quad chain + separately decompressed R compared as points (the 5-wavefront kernel),
+    3 = one-lane chains + separately decompressed R (the default three-wavefront kernel)."""
     vec = torsion_fuzz[:40]
     n = len(vec)
     msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)

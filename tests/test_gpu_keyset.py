@@ -212,12 +212,14 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_CACHED_SINGLE_ROLE])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED, _lib.KERNEL_CACHED_SINGLE_ROLE,
+                                    _lib.KERNEL_CACHED_LANE2_R])
 def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
-    """The default cached kernel up to 16,384 signatures is the 5-wavefront one (chains +
-    concurrent R decompression).  Force the others - one / two lanes per signature (dispatched
-    above 131,072 / 16,384) and the single-role quad kernel finishing by inversion - on small
-    inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
+    """The default cached kernel up to 196,608 signatures is the three-wavefront one (two lanes per
+    signature + concurrent R decompression).  Force every form - one lane per signature (the
+    default above that), two lanes finishing by inversion, four lanes with the R wavefront or
+    finishing by inversion, and the default itself - on small inputs: edge vectors in both modes
+    and a corrupted QC vs the oracle."""
     old = _lib.set_kernel(kernel)
     try:
         n = len(edge_vectors)
