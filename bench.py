@@ -481,13 +481,22 @@ def main():
             assert int(l_nr.item()) == 0
             lk_ms = lctx.kernel_times()[1] / max(1, lctx.kernel_times()[2])
             gather = 32 * 160 * nl                      # bytes of the keys' tables read per launch
+            l_traffic = None
+            try:    # HBM bytes per launch from the committed rocprofv3 PMC pass (same kernel, same launch size)
+                lp = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json"))).get("large_committee", {})
+                if lp.get("signatures_per_launch") == nl and lp.get("kernel") == _lib.lib().hs_ed25519_cached_kernel_for(nl).decode():
+                    l_traffic = lp["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             cached["large_committee"] = {
                 "n_validators": Nv, "signatures": nl, "keyset_hbm_bytes": lks.hbm_bytes(),
                 "kernel": _lib.lib().hs_ed25519_cached_kernel_for(nl).decode(), "avg_kernel_ms": round(lk_ms, 4),
                 "value": round(nl * reps / l_el, 1), "unit": "verifies/s",
                 "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                             "algorithmic_bytes_per_launch": gather,
+                             "algorithmic_bytes_per_launch": gather, "traffic": l_traffic,
+                             "traffic_source": "profiles/r1_pmc_traffic.json large_committee (rocprofv3 --pmc FETCH_SIZE, "
+                                               "uncorrected)" if l_traffic else None,
                              "note": "32 table entries x 160 B per verification gathered from the key set"}}
             lctx.close(); lks.close()
         except Exception as e:        # never let the extra break the headline
