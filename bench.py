@@ -419,8 +419,7 @@ def main():
     # ---- extra (not the headline): the same workload with the signers' keys registered as a
     # committee key set (hs_ed25519_keyset_create) - the production path for QC / TC verification,
     # where every key is a committee member for the whole epoch.
-    cached = None
-    if world == 1 and not args.no_cached:
+    def run_cached():
         t0 = time.perf_counter()
         ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(n)])
         build_ms = (time.perf_counter() - t0) * 1e3
@@ -501,6 +500,14 @@ def main():
             lctx.close(); lks.close()
         except Exception as e:        # never let the extra break the headline
             cached["large_committee"] = {"error": str(e)}
+        return cached
+
+    cached = None
+    if world == 1 and not args.no_cached:
+        try:        # an extra must never cost the headline line
+            cached = run_cached()
+        except Exception as e:
+            cached = {"error": "%s: %s" % (type(e).__name__, e)}
 
     traffic = None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
@@ -513,7 +520,11 @@ def main():
     # ---- the workload that has an exchange step: one very large committee sharded over the ranks
     sharded = None
     if exchange and not args.no_sharded:
-        sharded = sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, validators=args.large_committee)
+        try:        # an extra must never cost the headline line (a rank that fails here leaves the others to the
+            # process group's 180 s timeout, after which they report the error too)
+            sharded = sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, validators=args.large_committee)
+        except Exception as e:
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         total = world * n * args.steps
@@ -563,11 +574,18 @@ def main():
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
-            out["qc_verify_latency"] = qc_latency(_lib, torch, synth, dev)
-            out["streamed_rounds"] = streamed_rounds(_lib, synth)
+            for key, fn in (("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
+                            ("streamed_rounds", lambda: streamed_rounds(_lib, synth))):
+                try:
+                    out[key] = fn()
+                except Exception as e:        # extras never cost the headline line
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
+                out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         line = json.dumps(out)
     else:
         line = None
