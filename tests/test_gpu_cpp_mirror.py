@@ -1,0 +1,74 @@
+"""The C++ host-side mirror of the reference's interface (include/hotstuff_crypto.hpp:
+Digest / PublicKey / Signature{verify, verify_batch}, Committee, QC::verify, TC::verify over the
+C ABI) run through the reference's own test cases (tests/cpp/mirror_tests.cpp restates
+crypto_tests.rs and messages_tests.rs).  The reference is compiled code, so its host side is
+mirrored in C++ as well as in Python; signing is off the path and done here with OpenSSL."""
+import hashlib
+import os
+import struct
+import subprocess
+
+import pytest
+import torch
+
+import synth
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "tests", "cpp", "mirror_tests.cpp")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "mirror_tests")
+    libdir = os.path.join(ROOT, "hotstuff_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unknown-pragmas", SRC, "-o", exe,
+                    "-L" + libdir, "-lhs_ed25519", "-Wl,-rpath," + libdir], check=True, capture_output=True)
+    return exe
+
+
+def _fixture(tmp_path):
+    seeds = [synth.key_seed(7000 + i) for i in range(4)]
+    digest = hashlib.sha512(b"Hello, world!").digest()[:32]
+    bad_digest = hashlib.sha512(b"Bad message!").digest()[:32]
+    pks, sigs = zip(*(synth.sign(s, digest) for s in seeds))
+    qc_hash, qc_round = hashlib.sha512(b"block").digest()[:32], 7
+    qc_digest = hashlib.sha512(qc_hash + struct.pack("<Q", qc_round)).digest()[:32]
+    qc_sigs = [synth.sign(s, qc_digest)[1] for s in seeds]
+    unknown = synth.sign(synth.key_seed(7999), digest)[0]
+    tc_round, tc_hq = 9, [3, 5, 5, 8]
+    tc_sigs = [synth.sign(s, hashlib.sha512(struct.pack("<QQ", tc_round, hq)).digest()[:32])[1] for s, hq in zip(seeds, tc_hq)]
+    blob = (b"".join(pks) + digest + bad_digest + b"".join(sigs) + qc_hash + struct.pack("<Q", qc_round) + qc_digest
+            + b"".join(qc_sigs) + unknown + struct.pack("<Q", tc_round) + struct.pack("<4Q", *tc_hq) + b"".join(tc_sigs))
+    path = str(tmp_path / "fixture.bin")
+    with open(path, "wb") as f:
+        f.write(blob)
+    return path
+
+
+def _run(tmp_path):
+    r = subprocess.run([_build(tmp_path), _fixture(tmp_path)], capture_output=True, text=True, timeout=120)
+    lines = [l for l in r.stdout.splitlines() if l[:4] in ("ok  ", "FAIL")]
+    return r.returncode, {l[5:]: l.startswith("ok") for l in lines}
+
+
+@pytest.mark.gpu
+def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
+    assert torch.cuda.is_available()
+    rc, cases = _run(tmp_path)
+    assert len(cases) == 17, cases
+    assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
+
+
+def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
+    """Compiles against include/ and links libhs_ed25519.so without a GPU.  Run here, the
+    structural checks (which precede the crypto, messages.rs:182-194) and QC::digest behave as in
+    the reference; with no device every signature check is Err - the mirror has no CPU fallback."""
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    rc, cases = _run(tmp_path)
+    for name in ("committee quorum_threshold is 3 of 4", "QC::digest is SHA-512(hash || round_le)[..32]",
+                 "verify_qc_authority_reuse", "verify_qc_unknown_authority", "verify_qc_insufficient_stake",
+                 "verify_tc_insufficient_stake", "verify_invalid_signature", "verify_invalid_batch"):
+        assert cases[name], name
+    for name in ("verify_valid_signature", "verify_valid_batch", "verify_valid_qc", "verify_valid_tc"):
+        assert not cases[name], name          # would need the GPU: must not be Ok
+    assert rc != 0
