@@ -127,6 +127,34 @@ struct Committee {                                         // config.rs:39-43 re
         for (const auto &a : authorities) total += a.second;
         return (Stake)(2 * total / 3 + 1);
     }
+
+    // The committee is static for an epoch: register its keys once (per-key tables in HBM,
+    // hs_ed25519_keyset_create) and every later QC / TC verification skips the doublings and the
+    // decompression of A.  Call after `authorities` is final; returns false on an engine error.
+    bool cache_keys() {
+        drop_key_cache();
+        if (authorities.empty() || !detail::ensure_init()) return false;
+        std::vector<uint8_t> pks;
+        uint32_t i = 0;
+        for (const auto &a : authorities) { pks.insert(pks.end(), a.first.b.begin(), a.first.b.end()); index_[a.first] = i++; }
+        if (hs_ed25519_keyset_create(&keyset_, pks.data(), authorities.size()) != 0) { keyset_ = nullptr; index_.clear(); return false; }
+        return true;
+    }
+    void drop_key_cache() { if (keyset_) hs_ed25519_keyset_destroy(keyset_); keyset_ = nullptr; index_.clear(); }
+    const hs_ed25519_keyset *keyset() const { return keyset_; }
+    // position of `name` in the key set, or an index outside it (the engine rejects that signature)
+    uint32_t key_index(const PublicKey &name) const {
+        const auto it = index_.find(name);
+        return it == index_.end() ? 0xffffffffu : it->second;
+    }
+    Committee() = default;
+    Committee(const Committee &) = delete;                 // owns a device resource
+    Committee &operator=(const Committee &) = delete;
+    ~Committee() { drop_key_cache(); }
+
+ private:
+    hs_ed25519_keyset *keyset_ = nullptr;
+    std::map<PublicKey, uint32_t> index_;
 };
 
 namespace detail {
@@ -180,6 +208,19 @@ struct QC {                                                // messages.rs:164-16
         const ConsensusResult s = detail::check_quorum(votes, [](const auto &v) -> const PublicKey & { return v.first; },
                                                        committee, ConsensusError::QCRequiresQuorum);
         if (s.is_err()) return s;
+        if (committee.keyset() && !votes.empty()) {        // every author passed the stake lookup, so every key is in the set
+            const Digest d = digest();
+            std::vector<uint32_t> idx(votes.size());
+            std::vector<uint8_t> sigs(64 * votes.size());
+            for (size_t i = 0; i < votes.size(); i++) {
+                idx[i] = committee.key_index(votes[i].first);
+                const auto f = votes[i].second.flatten();
+                std::memcpy(&sigs[64 * i], f.data(), 64);
+            }
+            const int rc = hs_ed25519_verify_shared_cached(committee.keyset(), d.b.data(), idx.data(), sigs.data(), votes.size(),
+                                                           HS_ED25519_BATCH, nullptr);
+            return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
+        }
         return Signature::verify_batch(digest(), votes).is_ok() ? ConsensusResult::Ok()
                                                                  : ConsensusResult::Err(ConsensusError::InvalidSignature);
     }
@@ -206,7 +247,14 @@ struct TC {                                                // messages.rs:283-28
             std::memcpy(&sigs[64 * i], f.data(), 64);
             hq[i] = std::get<2>(votes[i]);
         }
-        const int rc = hs_ed25519_verify_tc(round, hq.data(), pks.data(), sigs.data(), votes.size(), nullptr);
+        int rc;
+        if (committee.keyset()) {
+            std::vector<uint32_t> idx(votes.size());
+            for (size_t i = 0; i < votes.size(); i++) idx[i] = committee.key_index(std::get<0>(votes[i]));
+            rc = hs_ed25519_verify_tc_cached(committee.keyset(), round, hq.data(), idx.data(), sigs.data(), votes.size(), nullptr);
+        } else {
+            rc = hs_ed25519_verify_tc(round, hq.data(), pks.data(), sigs.data(), votes.size(), nullptr);
+        }
         return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
     }
 };

@@ -124,6 +124,31 @@ int main(int argc, char **argv) {
         const ConsensusResult r = t.verify(committee);
         CHECK("verify_tc_insufficient_stake", r.is_err() && r.err.kind == ConsensusError::TCRequiresQuorum);
     }
+    // ---- the same certificates with the committee's keys registered once (the key cache)
+    CHECK("committee.cache_keys()", committee.cache_keys() && committee.keyset() != nullptr);
+    CHECK("verify_valid_qc (key cache)", qc().verify(committee).is_ok());
+    {
+        QC q = qc();
+        q.votes[1].second = x.qc_sig[0];
+        const ConsensusResult r = q.verify(committee);
+        CHECK("misattributed signature is InvalidSignature (key cache)", r.is_err() && r.err.kind == ConsensusError::InvalidSignature);
+    }
+    {
+        QC q = qc();
+        const Signature sig = q.votes.back().second;
+        q.votes.pop_back();
+        q.votes.push_back({x.unknown, sig});
+        const ConsensusResult r = q.verify(committee);
+        CHECK("verify_qc_unknown_authority (key cache)", r.is_err() && r.err.kind == ConsensusError::UnknownAuthority);
+    }
+    CHECK("verify_valid_tc (key cache)", tc().verify(committee).is_ok());
+    {
+        TC t = tc();
+        std::get<2>(t.votes[0]) += 1;
+        const ConsensusResult r = t.verify(committee);
+        CHECK("tampered high_qc_round is InvalidSignature (key cache)", r.is_err() && r.err.kind == ConsensusError::InvalidSignature);
+    }
+    committee.drop_key_cache();
     hs_ed25519_shutdown();
     printf("%d failed\n", failures);
     return failures;

@@ -54,7 +54,7 @@ def _run(tmp_path):
 def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
     assert torch.cuda.is_available()
     rc, cases = _run(tmp_path)
-    assert len(cases) == 17, cases
+    assert len(cases) == 23, cases
     assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
 
 
@@ -69,6 +69,7 @@ def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
                  "verify_qc_authority_reuse", "verify_qc_unknown_authority", "verify_qc_insufficient_stake",
                  "verify_tc_insufficient_stake", "verify_invalid_signature", "verify_invalid_batch"):
         assert cases[name], name
-    for name in ("verify_valid_signature", "verify_valid_batch", "verify_valid_qc", "verify_valid_tc"):
+    for name in ("verify_valid_signature", "verify_valid_batch", "verify_valid_qc", "verify_valid_tc",
+                 "committee.cache_keys()", "verify_valid_qc (key cache)", "verify_valid_tc (key cache)"):
         assert not cases[name], name          # would need the GPU: must not be Ok
     assert rc != 0
