@@ -2,12 +2,18 @@
 // verification engine (include/hs_ed25519.h).  Replaces the ed25519-dalek calls at
 // /root/reference/crypto/src/lib.rs:203 (verify_strict) and :218 (verify_batch).
 //
-// Device side: two kernels per call, one wavefront (64 lanes) per workgroup so that
-// even a 1,024-signature batch spreads over 16-32 CUs; the workspace between them is
-// structure-of-arrays so every lane-strided access is a coalesced 256-byte row.
-//   k_prepare : 2n lanes  (decompress A / R, hram, scalar checks, recoding)
-//   k_verify  : n lanes   (joint double-scalar multiplication, compare, ballot -> bitmap)
-// Host side: a pool of stream contexts (pinned staging + device buffers), no CPU fallback.
+// Device side (one wavefront = 64 lanes per role; DESIGN.md section 5 has the table):
+//   cold path   k_verify_fused            n <= 32,768: four lanes per signature, one launch
+//               k_prepare + k_verify      above: one lane per point / signature, SoA workspace
+//               k_prepare + k_verify_quad kept for A/B
+//   key cache   k_keyset_decompress, k_keyset_build   registration (tables in HBM)
+//               k_verify_cached_lane2r    default up to 196,608: two lanes per signature + a
+//                                         wavefront decompressing the R's beside the chains
+//               k_verify_cached_lane      above: one lane per signature
+//               k_verify_cached_lane2 / _5w / k_verify_cached   other forms, selectable
+//   k_tc_digests                          timeout-certificate digests ahead of any of the above
+// Host side: a pool of stream contexts (pinned staging + device buffers), key sets, the round
+// ring (pinned slots; hipGraph / stream operations / zero-copy), no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>

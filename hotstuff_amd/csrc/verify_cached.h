@@ -7,14 +7,16 @@
 //      [k](-A) + [s]B == R
 // can be tabled per key once per epoch.  With signed 8-bit windows
 //      [k](-A) = sum_w T_A[w][k_w],   T_A[w][j] = j * 2^(8w) * (-A),   w < 32, j <= 128
-// a verification is 32 + 32 table additions: no doublings, no decompression of A; and R is
-// checked without decompressing it either - compute R' = sum, invert Z once, compare y' with
-// the encoded y and the parity of x' with the sign bit (equivalent to dalek's "decompress R,
-// compare points": if y' = y_R the encoding is on the curve and decodes to (+-x', y'); the
-// sign bit picks x' unless x' = 0, where dalek accepts either sign).
+// a verification is 32 + 32 table additions: no doublings, no decompression of A.  R' = sum is
+// then compared with R in one of two ways.  (a) Without decompressing R: invert Z once, compare
+// y' with the encoded y and the parity of x' with the sign bit (equivalent to dalek's "decompress
+// R, compare points": if y' = y_R the encoding is on the curve and decodes to (+-x', y'); the sign
+// bit picks x' unless x' = 0, where dalek accepts either sign).  (b) Against an R that another
+// wavefront of the workgroup decompressed meanwhile, as points: X == x_R Z, Y == y_R Z, Z != 0 -
+// the form the default kernels use, because it takes the 254-squaring chain off the addition chains.
 //
-// Cost: 64 additions + 1 inversion, against 252 doublings + 96 additions + 2 square roots
-// for the cold path.  Price: 129 * 32 cached points = 660,480 bytes of HBM per key
+// Cost: 64 additions + 1 inversion or square root, against 252 doublings + 96 additions + 2
+// square roots for the cold path.  Price: 129 * 32 cached points = 660,480 bytes of HBM per key
 // (6.6 GB for 10,000 validators, 66 GB for 100,000 - MI355X has 288 GB).
 //
 // Table entries use the quad kernel's cached layout, (Y-X, Y+X, 2dT, 2Z) one coordinate per
