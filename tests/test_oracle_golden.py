@@ -126,3 +126,40 @@ def test_torsion_fuzz_c_oracle_matches_bigint(oracle, torsion_fuzz):
     assert [bool(b) for b in strict] == [v["strict"] for v in torsion_fuzz]
     assert [bool(b) for b in cl] == [v["cofactorless"] for v in torsion_fuzz]
     assert sum(v["cofactored"] and not v["cofactorless"] for v in torsion_fuzz) > 30    # class iii is well covered
+
+
+def test_random_mutations_c_oracle_matches_bigint(oracle):
+    """Beyond the stored vectors: 240 fresh signatures with random single-byte and single-bit
+    mutations of the key, R, s or the message (seeded), both predicates, C restatement against the
+    big-int ground truth.  Mutated keys / R's are mostly off-curve or, when on it, unrelated points;
+    mutated s covers s >= L as well."""
+    import random
+    rng = random.Random(20260921)
+    n = 240
+    msgs, pks, sigs, kinds = [], [], [], []
+    for i in range(n):
+        seed = bytes(rng.randrange(256) for _ in range(32))
+        msg = bytes(rng.randrange(256) for _ in range(32))
+        pk = E.public_key(seed)
+        sig = E.sign(seed, msg)
+        kind = i % 6
+        pk, sig, msg = bytearray(pk), bytearray(sig), bytearray(msg)
+        if kind == 1:
+            pk[rng.randrange(32)] ^= 1 << rng.randrange(8)
+        elif kind == 2:
+            sig[rng.randrange(32)] ^= 1 << rng.randrange(8)            # R
+        elif kind == 3:
+            sig[32 + rng.randrange(32)] ^= 1 << rng.randrange(8)       # s
+        elif kind == 4:
+            msg[rng.randrange(32)] ^= 1 << rng.randrange(8)
+        elif kind == 5:
+            sig[63] |= 0x10 << rng.randrange(4)                        # push s above L
+        msgs.append(bytes(msg)); pks.append(bytes(pk)); sigs.append(bytes(sig)); kinds.append(kind)
+    strict = oracle_verify_many(oracle, b"".join(msgs), 32, b"".join(pks), b"".join(sigs), n, 1)
+    cl = oracle_verify_many(oracle, b"".join(msgs), 32, b"".join(pks), b"".join(sigs), n, 0)
+    accepted = 0
+    for i in range(n):
+        assert bool(strict[i]) == E.verify_strict(msgs[i], pks[i], sigs[i]), (i, kinds[i])
+        assert bool(cl[i]) == E.verify_cofactorless(msgs[i], pks[i], sigs[i]), (i, kinds[i])
+        accepted += strict[i]
+    assert accepted == n // 6          # exactly the untouched ones verify
