@@ -3,35 +3,40 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path (one hs_ed25519_verify_device call: the fused k_verify_fused
-kernel at this batch size) over one batch of synthetic input that is already resident in HBM.  Default workload = BASELINE.json
-configs[1]: 1,024 distinct (digest, pk, sig) tuples, one digest per tuple, strict semantics
-(the TC::verify / Signature::verify predicate, consensus/src/messages.rs:307-313).  Steps are
-enqueued round-robin on `--streams` HIP streams, each restricted to its own slice of the CUs
-(`--partitions`), so that independent batches overlap on the chip the way a node under load
-issues them; the timed region is bracketed by a barrier and a
-device synchronize on both sides and the maximum over ranks is taken.
+Workload = BASELINE.json configs[1]: batches of 1,024 distinct (digest, pk, sig) tuples, one digest per
+tuple, strict semantics (the TC::verify / Signature::verify predicate, consensus/src/messages.rs:307-313),
+inputs resident in HBM.  A "step" is one pass of the hot path over a synthetic input set of
+`--batches-per-step` (default 1,024) such batches = 1,048,576 verifications: 1,024 independent
+hs_ed25519_verify_device calls (k_verify_fused at this batch size) issued round-robin over 16 stream
+contexts, each context restricted to its own slice of the CUs and holding its own distinct batch -
+the way a node under load issues independent certificates.  With the driver's `--steps 20 --warmup 5`
+the timed region is 20,480 launches / ~0.6 s, i.e. steady state whatever `steps` is (round 1 timed
+single launches, so 20 steps were 1.2 ms and the number depended on steps mod streams).  The timed
+region is bracketed by a barrier and a device synchronize on both sides; the maximum over ranks is taken.
 
-With N > 1 every rank verifies its own independent 1,024-tuple batches (weak scaling; the units
-are independent, SURVEY.md 8e, so the headline has no data-path collective).  The one workload
-with a real exchange step - BASELINE configs[3], a 100,000-validator QC cut into one shard per
-GPU with an RCCL all-gather of the per-shard accept bitmaps (sharding.py) - is run by all ranks
-after the headline and reported as `sharded_committee` (latency and rate, all-gather and host
-verdict included).
+`value` is the HBM-resident rate the contract asks for.  `end_to_end` (same JSON line) is SURVEY.md
+8d's metric proper - host buffers in, host verdict out through the host-pointer C ABI
+(hs_ed25519_verify_multi from 16 host threads; pinned staging, PCIe both ways included).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+With N > 1 every rank verifies its own independent batches (weak scaling; the units are independent,
+SURVEY.md 8e, so the headline has no data-path collective).  The workload with a real exchange step -
+BASELINE configs[3], a 100,000-validator QC cut into one shard per GPU - is run after the headline two
+ways: `sharded_committee` (one process per GPU, torch.distributed RCCL all-gather of the bitmaps) and
+`sharded_c_abi` (ONE process - rank 0 - driving every GPU through hs_ed25519_verify_shared_sharded,
+which is what the reference's single-process node would call; host and RCCL exchange).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with:
   roofline      algorithmic bytes (128 B per verification) of the dominant kernel
-                divided by its average duration, measured live with HIP events attached to the
+                divided by its average duration, measured live with HIP events attached to sampled
                 dispatches on the launch streams inside the timed region, against the 8 TB/s HBM
                 peak.  This path is integer-VALU bound, so the fraction is tiny by construction;
-                `int_roofline` (extra) prices the same kernel against the measured
-                v_mad_u64_u32 issue rate.
-  extras        `committee_cached` (same workload with the keys registered as a key set, and the
-                100,000-validator QC on one GPU), `qc_verify_latency` (p50 at N = 10,000),
-                `streamed_rounds` (configs[4]: rounds from host memory through the pinned ring,
-                one hipGraph launch each).
-  cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"),
-                timed on the host's cores on a bounded sample of the same workload.
+                `int_roofline` prices the same kernel against the measured v_mad_u64_u32 issue rate.
+  cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"), timed on
+                the host cores this process may use, on a bounded sample of the same workload.
+  extras        `end_to_end`, `committee_cached`, `qc_verify_latency` (p50 at N = 10,000, with the
+                CPU batch verification timed beside it), `rlc_ab` (per-signature vs batch-RLC/MSM path
+                at 6,667 and 66,667 signatures), `streamed_rounds` (configs[4]),
+                `small_batch_crossover` (GPU vs one CPU core at n = 1 ... 32).
 """
 import argparse
 import ctypes
@@ -63,28 +68,45 @@ MAD_PER_VERIFY = {
 MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 
 
-def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=12.0):
-    """Time the oracle (the CPU port of the reference's verify loop) on all host cores."""
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def load_oracle():
     so = os.path.join(ROOT, "oracle", "libhs_oracle.so")
     native = "/tmp/hs_oracle_native.so"
     try:    # a -march=native build for a fair host number; falls back to the shipped build
-        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", native,
-                        os.path.join(ROOT, "oracle", "ed25519_oracle.c"), "-lpthread"],
-                       check=True, capture_output=True, timeout=120)
+        if not os.path.exists(native):
+            subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", native,
+                            os.path.join(ROOT, "oracle", "ed25519_oracle.c"), "-lpthread"],
+                           check=True, capture_output=True, timeout=120)
         so = native
     except Exception:
         pass
-    orc = ctypes.CDLL(so)
-    cores = os.cpu_count() or 1
+    return ctypes.CDLL(so)
+
+
+def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=14.0):
+    """Time the oracle (the CPU port of the reference's per-signature verify loop) on one core and on
+    every core this process may use.  Each thread gets >= 1,000 verifications per pass so that thread
+    start-up (the oracle spawns its workers per call) is noise."""
+    orc = load_oracle()
+    cores = host_cores()
     S = ctypes.c_size_t
-    # the same tuples, tiled so that every host thread gets >= 64 verifications per pass
-    # (thread spawn would otherwise dominate a 1,024-signature pass on a many-core host)
-    tile = max(1, (64 * cores + n - 1) // n)
+    tile = max(1, (1000 * cores + n - 1) // n)
     big_n = n * tile
     big_dg = dg * tile if stride else dg
     big_pk, big_sg = pk * tile, sg * tile
 
-    def run(threads, nn, a_dg, a_pk, a_sg):
+    def run(threads, nn, a_dg, a_pk, a_sg, budget):
         out = ctypes.create_string_buffer(nn)
         t0 = time.perf_counter()
         reps = 0
@@ -92,21 +114,44 @@ def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=12.0):
             orc.hs_oracle_verify_many(a_dg, S(32), S(stride), a_pk, a_sg, S(nn), mode, out, threads)
             reps += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s / 2:
+            if dt > budget:
                 break
         assert all(out.raw), "oracle rejected a valid synthetic signature"
         return reps * nn / dt, reps
 
-    one, r1 = run(1, n, dg, pk, sg)
-    allc, rn = run(cores, big_n, big_dg, big_pk, big_sg)
+    one, r1 = run(1, n, dg, pk, sg, budget_s * 0.3)
+    allc, rn = run(cores, big_n, big_dg, big_pk, big_sg, budget_s * 0.7)
     return {
         "value": round(allc, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
-        "one_core": round(one, 1),
+        "one_core": round(one, 1), "parallel_efficiency": round(allc / (cores * one), 3),
+        "os_cpu_count": os.cpu_count(),
         "sample": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1 verify_strict, 51-bit limbs, "
-                  "-O3 -march=native): the bench's own %d tuples tiled x%d = %d verifications per pass, %d passes "
-                  "on %d threads; 1-thread figure from %d passes over the untiled batch"
-                  % (n, tile, big_n, rn, cores, r1),
+                  "-O3 -march=native): the bench's own %d tuples tiled x%d = %d verifications per pass (>= 1,000 per "
+                  "thread), %d passes on %d threads (= sched_getaffinity capped by the cgroup quota); 1-thread figure "
+                  "from %d passes over the untiled batch" % (n, tile, big_n, rn, cores, r1),
     }
+
+
+def cpu_qc_latency(dg, pk, sg, n, calls=5):
+    """The CPU twin of `qc_verify_latency`: dalek's verify_batch (RLC + Pippenger, oracle restatement) on
+    one core, and split into one sub-batch per core (hs_oracle_verify_batch_mt)."""
+    orc = load_oracle()
+    S = ctypes.c_size_t
+    cores = host_cores()
+    one, many = [], []
+    for i in range(calls):
+        t0 = time.perf_counter()
+        ok = orc.hs_oracle_verify_batch(dg, S(32), S(0), pk, sg, S(n), ctypes.c_uint64(i))
+        one.append(time.perf_counter() - t0)
+        assert ok == 1
+    for i in range(calls * 4):
+        t0 = time.perf_counter()
+        ok = orc.hs_oracle_verify_batch_mt(dg, S(32), S(0), pk, sg, S(n), ctypes.c_uint64(i), cores)
+        many.append(time.perf_counter() - t0)
+        assert ok == 1
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"kind": "port", "algorithm": "dalek verify_batch restated: 128-bit RLC + Pippenger (w = 8)",
+            "p50_ms_one_core": round(med(one) * 1e3, 3), "p50_ms_all_cores": round(med(many) * 1e3, 3), "cores": cores}
 
 
 def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
@@ -186,7 +231,11 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     ctx.close()
     med = lambda v: sorted(v)[len(v) // 2]
     p99 = lambda v: sorted(v)[int(len(v) * 0.99)]
-    return {"n_validators": validators, "signatures": n, "calls": calls,
+    try:
+        cpu = cpu_qc_latency(dg, pk, sg, n)
+    except Exception as e:
+        cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"n_validators": validators, "signatures": n, "calls": calls, "cpu": cpu,
             "p50_ms_host_api": round(med(host) * 1e3, 4), "p99_ms_host_api": round(p99(host) * 1e3, 4),
             "p50_ms_device_resident": round(med(devt) * 1e3, 4),
             "verifies_per_s_at_p50_host_api": round(n / med(host), 1),
@@ -291,12 +340,192 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
     return out
 
 
+def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8):
+    """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI
+    (hs_ed25519_verify_multi / _shared).  `threads` host threads each verify their own 1,024-tuple batch in
+    a loop (ctypes releases the GIL for the call); every call stages into pinned memory, launches and waits
+    for its verdict.  PCIe-inclusive."""
+    import threading
+    lib = _lib.lib()
+    fn = lib.hs_ed25519_verify_multi if stride else lib.hs_ed25519_verify_shared
+    bufs = []
+    for t in range(threads):
+        dg, pk, sg = batches[t % len(batches)]
+        bufs.append(tuple(ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)))
+    for b in bufs[:4]:       # warm the context pool
+        assert fn(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, mode, None) == 1
+    counts, lats, stop, go = [0] * threads, [[] for _ in range(threads)], threading.Event(), threading.Event()
+
+    def work(t):
+        a = tuple(ctypes.addressof(x) for x in bufs[t])
+        go.wait()
+        while not stop.is_set():
+            t0 = time.perf_counter()
+            rc = fn(a[0], a[1], a[2], n, mode, None)
+            lats[t].append(time.perf_counter() - t0)
+            if rc != 1:
+                counts[t] = -1
+                return
+            counts[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    t0 = time.perf_counter()
+    go.set()
+    time.sleep(seconds)
+    stop.set()
+    for x in th:
+        x.join()
+    wall = time.perf_counter() - t0
+    assert all(c >= 0 for c in counts), "end-to-end call rejected a valid batch"
+    allv = sorted(v for l in lats for v in l)
+    return {"value": round(sum(counts) * n / wall, 1), "unit": "verifies/s", "host_threads": threads, "calls": sum(counts),
+            "signatures_per_call": n, "seconds": round(wall, 3), "call_p50_ms": round(allv[len(allv) // 2] * 1e3, 4),
+            "path": "host buffers -> pinned staging -> kernel reads over PCIe (zero-copy) -> pinned bitmap -> host verdict"}
+
+
+def small_batch_crossover(_lib, synth):
+    """where the GPU round trip starts to beat one CPU core.  p50 of the host-pointer
+    call at n = 1 ... 64 (strict, one digest per signature: the Vote / Timeout / TC shape), cold and with the
+    keys registered, against the oracle's per-signature strict verification on one core."""
+    lib = _lib.lib()
+    orc = load_oracle()
+    S = ctypes.c_size_t
+    sizes = [1, 2, 3, 4, 8, 16, 32, 64]
+    nmax = sizes[-1]
+    dg, pk, sg = synth.make_batch(nmax, shared=False, cache_dir="/tmp/hs_synth")
+    ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(nmax)])
+    import struct
+    idx = struct.pack("<%dI" % nmax, *range(nmax))
+    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg, idx)]
+    a = [ctypes.addressof(x) for x in b]
+    med = lambda v: sorted(v)[len(v) // 2]
+    rows, cross = [], {"cold": None, "key_cache": None}
+    for n in sizes:
+        cold, cached, cpu = [], [], []
+        for i in range(60):
+            t0 = time.perf_counter(); rc = lib.hs_ed25519_verify_multi(a[0], a[1], a[2], n, _lib.STRICT, None); cold.append(time.perf_counter() - t0)
+            assert rc == 1
+            t0 = time.perf_counter(); rc = lib.hs_ed25519_verify_multi_cached(ks.handle, a[0], a[3], a[2], n, _lib.STRICT, None); cached.append(time.perf_counter() - t0)
+            assert rc == 1
+        out = ctypes.create_string_buffer(n)
+        for i in range(20):
+            t0 = time.perf_counter(); orc.hs_oracle_verify_many(dg, S(32), S(32), pk, sg, S(n), 1, out, 1); cpu.append(time.perf_counter() - t0)
+        row = {"n": n, "gpu_cold_ms": round(med(cold[10:]) * 1e3, 4), "gpu_key_cache_ms": round(med(cached[10:]) * 1e3, 4),
+               "cpu_one_core_ms": round(med(cpu) * 1e3, 4)}
+        rows.append(row)
+        if cross["cold"] is None and row["gpu_cold_ms"] <= row["cpu_one_core_ms"]:
+            cross["cold"] = n
+        if cross["key_cache"] is None and row["gpu_key_cache_ms"] <= row["cpu_one_core_ms"]:
+            cross["key_cache"] = n
+    ks.close()
+    return {"rows": rows, "measured_crossover_n": cross,
+            "library_hint": {"cold": lib.hs_ed25519_min_gpu_batch(0), "key_cache": lib.hs_ed25519_min_gpu_batch(1)},
+            "cpu": "oracle per-signature strict verification, one core (dalek itself is ~1.5-2x faster per signature)"}
+
+
+def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
+    """A/B on the cold QC path: per-signature BATCH kernels vs HS_ED25519_BATCH_RLC (one
+    random linear combination = Pippenger MSM, per-signature fallback skipped when it accepts).  Device
+    resident; p50 of one call, and signatures/s with 4 contexts in flight."""
+    out = {}
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    for n in sizes:
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+        d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
+        nctx = 4
+        ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+        for c in ctxs:
+            c.set_rlc_min(1)
+        bms = [torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev) for _ in range(nctx)]
+        nrs = torch.zeros(nctx, dtype=torch.int32, device=dev)
+        sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        torch.cuda.synchronize(dev)
+        row = {}
+        for name, mode in (("per_signature", _lib.BATCH), ("rlc_msm", _lib.BATCH_RLC)):
+            def call(j):
+                ctxs[j].verify(d_dg.data_ptr(), 0, d_pk.data_ptr(), d_sg.data_ptr(), n, mode, bms[j].data_ptr(),
+                               nrs[j:].data_ptr(), 0)
+            lat = []
+            for i in range(calls + 5):
+                sts[0].synchronize()
+                t0 = time.perf_counter()
+                call(0)
+                sts[0].synchronize()
+                if i >= 5:
+                    lat.append(time.perf_counter() - t0)
+            assert bool((bms[0].view(torch.int64)[: n // 64] == -1).all()), "rejected a valid QC"
+            if mode == _lib.BATCH_RLC:
+                assert ctxs[0].rlc_last()[0] == 1, "the RLC stage did not accept a valid QC"
+            for j in range(nctx):
+                call(j)
+            torch.cuda.synchronize(dev)
+            for s_ in sts:
+                s_.synchronize()
+            t0 = time.perf_counter()
+            reps = 12
+            for i in range(reps):
+                for j in range(nctx):
+                    call(j)
+            for s_ in sts:
+                s_.synchronize()
+            wall = time.perf_counter() - t0
+            lat.sort()
+            row[name] = {"p50_ms": round(lat[len(lat) // 2] * 1e3, 4), "signatures_per_s_4_in_flight": round(reps * nctx * n / wall, 1)}
+        row["winner_latency"] = min(("per_signature", "rlc_msm"), key=lambda k: row[k]["p50_ms"])
+        row["winner_throughput"] = max(("per_signature", "rlc_msm"), key=lambda k: row[k]["signatures_per_s_4_in_flight"])
+        out[str(n)] = row
+        for c in ctxs:
+            c.close()
+    out["library_threshold"] = _lib.lib().hs_ed25519_rlc_min_batch()
+    return out
+
+
+def sharded_c_abi(_lib, synth, ngpus, validators=100000, iters=30):
+    """BASELINE configs[3] the way the reference's ONE-process node would run it: this process opens every
+    GPU (hs_ed25519_init_devices) and calls hs_ed25519_verify_shared_sharded - one contiguous shard per
+    GPU launched from one thread, bitmap slices exchanged through the host or an in-process RCCL all-gather."""
+    n = 2 * validators // 3 + 1
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    _lib.shutdown()
+    _lib.init_devices(list(range(ngpus)), 8192)
+    lib = _lib.lib()
+    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    a = [ctypes.addressof(x) for x in b]
+    out = {"n_validators": validators, "signatures": n, "gpus": ngpus, "process": "one (rank 0 drives every GPU)",
+           "signatures_per_shard": _lib.shard_plan(n, ngpus, 0)[1]}
+    for name, how in (("host_exchange", _lib.EXCHANGE_HOST), ("rccl_all_gather", _lib.EXCHANGE_RCCL)):
+        try:
+            lib.hs_ed25519_set_shard_exchange(how)
+            for mode_name, mode in (("per_signature", _lib.BATCH), ("rlc_msm", _lib.BATCH_RLC)):
+                times = []
+                for i in range(iters + 3):
+                    t0 = time.perf_counter()
+                    rc = lib.hs_ed25519_verify_shared_sharded(a[0], a[1], a[2], n, mode, None)
+                    dt = time.perf_counter() - t0
+                    if rc != 1:
+                        raise RuntimeError("sharded QC rejected / failed (%d): %s" % (rc, _lib.last_error()))
+                    if i >= 3:
+                        times.append(dt)
+                times.sort()
+                out.setdefault(name, {})[mode_name] = {"p50_ms": round(times[len(times) // 2] * 1e3, 4),
+                                                       "verifies_per_s": round(n / times[len(times) // 2], 1)}
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
+    _lib.shutdown()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=1024, help="signatures per step per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="signatures per batch (one verify call)")
+    ap.add_argument("--batches-per-step", type=int, default=1024,
+                    help="independent verify calls per step per GPU (a step = this many batches)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
     ap.add_argument("--no-cpu", action="store_true")
@@ -305,7 +534,8 @@ def main():
     ap.add_argument("--large-committee", type=int, default=100000, help="validators in the cached large-QC extra")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-committee extra (N > 1: RCCL all-gather)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
-    ap.add_argument("--event-stride", type=int, default=1, help="record HIP events on every k-th call per context")
+    ap.add_argument("--event-stride", type=int, default=16, help="record HIP events on every k-th call per context")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline + cpu_baseline only")
     ap.add_argument("--partitions", type=int, default=None,
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
                          "default 16 for batches up to 4,096 signatures, 0 above)")
@@ -344,11 +574,13 @@ def main():
     shared = args.shared
     mode = _lib.BATCH if shared else _lib.STRICT
     stride = 0 if shared else 32
-    dg, pk, sg = synth.make_batch(n, shared=shared, first=rank * n, cache_dir="/tmp/hs_synth")
+    B = max(1, args.batches_per_step)
+    ns = max(1, min(args.streams, B))
+    # one distinct synthetic batch per stream context (ns x 1,024 distinct tuples per GPU)
+    batches = [synth.make_batch(n, shared=shared, first=(rank * ns + j) * n, cache_dir="/tmp/hs_synth") for j in range(ns)]
+    dg, pk, sg = batches[0]
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
-
-    ns = max(1, min(args.streams, args.steps))
+    d_in = [tuple(t(x) for x in bt) for bt in batches]
     ctxs = None
     if args.partitions:
         try:
@@ -365,14 +597,19 @@ def main():
     nrej = torch.zeros(ns, dtype=torch.int32, device=dev)
 
     # raw addresses once, outside the timed loop (the step itself is one C-ABI call)
-    p_dg, p_pk, p_sg = d_dg.data_ptr(), d_pk.data_ptr(), d_sg.data_ptr()
+    p_in = [tuple(x.data_ptr() for x in d) for d in d_in]
+    p_dg, p_pk, p_sg = p_in[0]
     p_bm = [b.data_ptr() for b in bitmaps]
     p_nr = [nrej[j:].data_ptr() for j in range(ns)]
     p_st = [s.cuda_stream for s in streams]
+    fn = _lib.lib().hs_ed25519_verify_device
+    calls = [(ctxs[j]._h, p_in[j][0], stride, p_in[j][1], p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j]) for j in range(ns)]
 
     def step(i):
-        j = i % ns
-        ctxs[j].verify(p_dg, stride, p_pk, p_sg, n, mode, p_bm[j], p_nr[j], p_st[j])
+        """one pass over the step's input set: B independent 1,024-tuple verify calls, round-robin over the contexts"""
+        for b in range(B):
+            if fn(*calls[b % ns]) != 0:
+                raise RuntimeError("hs_ed25519_verify_device failed: " + _lib.last_error())
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -385,8 +622,9 @@ def main():
     fence()
     # HIP events attached to the kernel dispatches themselves (hipExtLaunchKernel start/stop), on the
     # launch streams, for every `--event-stride`-th call of each context (default: every call)
+    per_ctx = (args.steps * B + ns - 1) // ns
     for c in ctxs:
-        c.set_profiling(0 if args.no_events else (args.steps + ns - 1) // ns, every=args.event_stride)
+        c.set_profiling(0 if args.no_events else max(1, per_ctx // args.event_stride + 1), every=args.event_stride)
     nrej.zero_()
     fence()
     t0 = time.perf_counter()
@@ -402,9 +640,8 @@ def main():
 
     # correctness of what was timed: every synthetic signature is valid
     assert int(nrej.sum().item()) == 0, "engine rejected valid signatures during the timed region"
-    full = (1 << 64) - 1
-    words = bitmaps[0].view(torch.int64)
-    assert all((int(w) & full) == full for w in words[: n // 64].tolist())
+    for bmp in bitmaps:
+        assert bool((bmp.view(torch.int64)[: n // 64] == -1).all()), "bitmap of a timed batch is not all ones"
 
     prep_ms = ver_ms = 0.0
     launches = 0
@@ -421,17 +658,21 @@ def main():
     # where every key is a committee member for the whole epoch.
     def run_cached():
         t0 = time.perf_counter()
-        ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(n)])
+        # the committee = the signers of all ns batches; batch j's keys are entries [j n, (j+1) n)
+        ks = _lib.KeySet([bt[1][32 * i:32 * i + 32] for bt in batches for i in range(n)])
         build_ms = (time.perf_counter() - t0) * 1e3
-        d_ki = torch.arange(n, dtype=torch.int32, device=dev)
-        p_ki = d_ki.data_ptr()
+        d_ki = torch.arange(n * ns, dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
         for c in ctxs:
-            c.set_profiling((args.steps + ns - 1) // ns, every=args.event_stride)
+            c.set_profiling(max(1, per_ctx // args.event_stride + 1), every=args.event_stride)
+        cfn = _lib.lib().hs_ed25519_verify_device_cached
+        ccalls = [(ctxs[j]._h, ks.handle, p_in[j][0], stride, d_ki[j * n:].data_ptr(), p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j])
+                  for j in range(ns)]
 
         def cstep(i):
-            j = i % ns
-            ctxs[j].verify_cached(ks, p_dg, stride, p_ki, p_sg, n, mode, p_bm[j], p_nr[j], p_st[j])
+            for b in range(B):
+                if cfn(*ccalls[b % ns]) != 0:
+                    raise RuntimeError("hs_ed25519_verify_device_cached failed: " + _lib.last_error())
 
         for i in range(args.warmup):
             cstep(i)
@@ -444,9 +685,9 @@ def main():
         c_elapsed = time.perf_counter() - t0
         assert int(nrej.sum().item()) == 0, "cached path rejected valid signatures"
         k_ms = sum(c.kernel_times()[1] for c in ctxs) / max(1, sum(c.kernel_times()[2] for c in ctxs))
-        cached = {"value": round(n * args.steps / c_elapsed, 1), "unit": "verifies/s",
+        cached = {"value": round(n * B * args.steps / c_elapsed, 1), "unit": "verifies/s",
                   "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": _lib.lib().hs_ed25519_cached_kernel_for(n).decode(),
-                  "avg_kernel_ms": round(k_ms, 4), "keys": n, "keyset_hbm_bytes": ks.hbm_bytes(),
+                  "avg_kernel_ms": round(k_ms, 4), "keys": n * ns, "keyset_hbm_bytes": ks.hbm_bytes(),
                   "keyset_build_ms": round(build_ms, 2),
                   "table_bytes_read_per_verify": 64 * 160,
                   "note": "keys pre-registered (static committee); not comparable with `value`, which is the cold path"}
@@ -502,6 +743,8 @@ def main():
             cached["large_committee"] = {"error": str(e)}
         return cached
 
+    if args.no_extras:
+        args.no_cached = args.no_qc = args.no_sharded = True
     cached = None
     if world == 1 and not args.no_cached:
         try:        # an extra must never cost the headline line
@@ -509,15 +752,21 @@ def main():
         except Exception as e:
             cached = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    traffic = None
+    traffic = traffic_src = None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         kname = _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
-        if pmc.get("signatures_per_launch") == n and kname in pmc["kernels"]:
-            traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
+        for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            fp = os.path.join(ROOT, "profiles", f)
+            if not os.path.exists(fp):
+                continue
+            pmc = json.load(open(fp))
+            if pmc.get("signatures_per_launch") == n and kname in pmc["kernels"]:
+                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per launch)" % f
+                break
     except Exception:
         pass
-    # ---- the workload that has an exchange step: one very large committee sharded over the ranks
+    # ---- the workload that has an exchange step: one very large committee sharded over the GPUs
     sharded = None
     if exchange and not args.no_sharded:
         try:        # an extra must never cost the headline line (a rank that fails here leaves the others to the
@@ -525,9 +774,16 @@ def main():
             sharded = sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, validators=args.large_committee)
         except Exception as e:
             sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+    e2e = None
+    if world == 1 and not args.no_extras:
+        try:
+            e2e = end_to_end(_lib, batches, n, stride, mode)
+        except Exception as e:
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    out = None
     if rank == 0:
-        total = world * n * args.steps
+        total = world * n * B * args.steps
         value = total / elapsed
         algo = (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) * n
         achieved = algo / (avg_verify_ms * 1e-3) / 1e9 if avg_verify_ms > 0 else 0.0
@@ -540,22 +796,25 @@ def main():
             "dtype": "u32 limbs (radix 2^25.5), u64 accumulate",
             "data": "synthetic",
             "config": {
-                "workload": ("QC::verify shape: %d signatures over one digest, batch semantics" % n) if shared else
-                            ("BASELINE configs[1]: %d distinct (digest, pk, sig) tuples per step per GPU, "
-                             "strict semantics" % n),
-                "signatures_per_step_per_gpu": n, "streams": ns, "cu_partitions": args.partitions,
+                "workload": ("QC::verify shape: batches of %d signatures over one digest, batch semantics; " % n if shared else
+                             "BASELINE configs[1]: batches of %d distinct (digest, pk, sig) tuples, strict semantics, HBM-resident; " % n)
+                            + "one step = one pass over %d such batches per GPU (%d verifications), issued as %d independent "
+                              "hs_ed25519_verify_device calls round-robin over %d CU-partitioned stream contexts"
+                              % (B, B * n, B, ns),
+                "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
+                "distinct_tuples_per_gpu": ns * n, "streams": ns, "cu_partitions": args.partitions,
+                "timed_region_s": round(elapsed, 4), "launches_in_timed_region_per_gpu": B * args.steps,
                 "exchange": ("none on this workload: every rank verifies its own independent batches (SURVEY.md 8e); "
-                             "`sharded_committee` is the workload with the RCCL all-gather") if exchange else "none (1 GPU)",
+                             "`sharded_committee` / `sharded_c_abi` are the workloads with the exchange step") if exchange else "none (1 GPU)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
                 "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
-                "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
-                                  if traffic else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
-                "event_sampling": "every %d-th launch of each of the %d stream contexts" % (args.event_stride, ns),
+                "event_sampling": "dispatch timestamps (hipExtLaunchKernel start/stop events, on the launch stream) of every "
+                                  "%d-th launch of each of the %d stream contexts, inside the timed region" % (args.event_stride, ns),
                 "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
             },
             "int_roofline": None,
@@ -569,13 +828,17 @@ def main():
             out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,
                                    "unit": "v_mad_u64_u32 lane-ops/s (per GPU)", "frac": round(mad_s / MAD_PEAK_PER_S, 4),
                                    "mad_per_verify": MAD_PER_VERIFY[kname]}
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if sharded is not None:
             out["sharded_committee"] = sharded
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
             for key, fn in (("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
-                            ("streamed_rounds", lambda: streamed_rounds(_lib, synth))):
+                            ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
+                            ("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
+                            ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth))):
                 try:
                     out[key] = fn()
                 except Exception as e:        # extras never cost the headline line
@@ -586,9 +849,19 @@ def main():
                 out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
             except Exception as e:
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        line = json.dumps(out)
-    else:
-        line = None
+    # ---- the same sharded workload from ONE process through the C ABI (rank 0 drives every GPU; the other
+    # ranks have released their contexts and wait at the barrier)
+    if not args.no_sharded and (exchange or os.environ.get("HS_BENCH_SHARDED_C_ABI") == "1"):
+        for c in ctxs:
+            c.close()
+        if exchange:
+            dist.barrier()
+        if rank == 0:
+            try:
+                out["sharded_c_abi"] = sharded_c_abi(_lib, synth, world, validators=args.large_committee)
+            except Exception as e:
+                out["sharded_c_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    line = json.dumps(out) if rank == 0 else None
     if exchange:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get("HS_ED25519_LIB") or os.path.join(_HERE, "libhs_ed2551
 
 BATCH = 0
 STRICT = 1
+BATCH_RLC = 2          # dalek's verify_batch as computed: one random linear combination, per-signature fallback
+EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
+KEYS_REPLICATE, KEYS_BY_OWNER = 0, 1
 
 
 class EngineError(RuntimeError):
@@ -81,8 +84,48 @@ def lib():
                 l.hs_ed25519_verify_device_tc.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_tc_cached.argtypes = [vp, vp, u64, vp, vp, vp, sz, vp, vp, vp]
                 l.hs_ed25519_verify_device_tc_cached.restype = ctypes.c_int
-                l.hs_ed25519_set_kernel.argtypes = [ctypes.c_int]
-                l.hs_ed25519_set_kernel.restype = ctypes.c_int
+                l.hs_ed25519_ctx_set_kernel.argtypes = [vp, ctypes.c_int]
+                l.hs_ed25519_ctx_set_kernel.restype = ctypes.c_int
+                l.hs_ed25519_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), sz, sz]
+                l.hs_ed25519_init_devices.restype = ctypes.c_int
+                l.hs_ed25519_device_count.argtypes = []
+                l.hs_ed25519_device_count.restype = ctypes.c_int
+                l.hs_ed25519_min_gpu_batch.argtypes = [ctypes.c_int]
+                l.hs_ed25519_min_gpu_batch.restype = sz
+                l.hs_ed25519_set_rlc_key.argtypes = [vp]
+                l.hs_ed25519_set_rlc_key.restype = ctypes.c_int
+                l.hs_ed25519_rlc_min_batch.argtypes = []
+                l.hs_ed25519_rlc_min_batch.restype = sz
+                l.hs_ed25519_ctx_create_on.argtypes = [ctypes.POINTER(ctypes.c_void_p), sz, ctypes.c_int]
+                l.hs_ed25519_ctx_create_on.restype = ctypes.c_int
+                l.hs_ed25519_ctx_device.argtypes = [vp]
+                l.hs_ed25519_ctx_device.restype = ctypes.c_int
+                l.hs_ed25519_ctx_set_rlc_min.argtypes = [vp, sz]
+                l.hs_ed25519_ctx_set_rlc_min.restype = ctypes.c_int
+                l.hs_ed25519_ctx_rlc_last.argtypes = [vp, ctypes.POINTER(sz)]
+                l.hs_ed25519_ctx_rlc_last.restype = ctypes.c_int
+                l.hs_ed25519_keyset_create_on.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz, ctypes.c_int]
+                l.hs_ed25519_keyset_create_on.restype = ctypes.c_int
+                l.hs_ed25519_shard_plan.argtypes = [sz, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+                l.hs_ed25519_shard_plan.restype = ctypes.c_int
+                l.hs_ed25519_set_shard_exchange.argtypes = [ctypes.c_int]
+                l.hs_ed25519_set_shard_exchange.restype = ctypes.c_int
+                l.hs_ed25519_shard_reset.argtypes = []
+                l.hs_ed25519_shard_reset.restype = None
+                l.hs_ed25519_verify_shared_sharded.argtypes = [vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_shared_sharded.restype = ctypes.c_int
+                l.hs_ed25519_verify_multi_sharded.argtypes = [vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_multi_sharded.restype = ctypes.c_int
+                l.hs_ed25519_keyset_sharded_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz, ctypes.c_int]
+                l.hs_ed25519_keyset_sharded_create.restype = ctypes.c_int
+                l.hs_ed25519_keyset_sharded_destroy.argtypes = [vp]
+                l.hs_ed25519_keyset_sharded_destroy.restype = None
+                l.hs_ed25519_keyset_sharded_bytes_per_device.argtypes = [vp, ctypes.c_int]
+                l.hs_ed25519_keyset_sharded_bytes_per_device.restype = sz
+                l.hs_ed25519_verify_shared_sharded_cached.argtypes = [vp, vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_shared_sharded_cached.restype = ctypes.c_int
+                l.hs_ed25519_verify_multi_sharded_cached.argtypes = [vp, vp, vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_multi_sharded_cached.restype = ctypes.c_int
                 l.hs_ed25519_keyset_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, sz]
                 l.hs_ed25519_keyset_create.restype = ctypes.c_int
                 l.hs_ed25519_keyset_destroy.argtypes = [vp]
@@ -135,19 +178,113 @@ def init(device=None, max_batch=8192):
     _inited = True
 
 
+def init_devices(ordinals, max_batch=8192):
+    """hs_ed25519_init_devices: several GPUs behind this one process; entry s of `ordinals` becomes
+    device slot s (slot 0 = the primary device).  The same ordinal may repeat (virtual devices)."""
+    global _inited
+    arr = (ctypes.c_int * len(ordinals))(*[int(o) for o in ordinals])
+    check(lib().hs_ed25519_init_devices(arr, len(ordinals), int(max_batch)), "hs_ed25519_init_devices")
+    _inited = True
+
+
+def shutdown():
+    global _inited
+    lib().hs_ed25519_shard_reset()
+    lib().hs_ed25519_shutdown()
+    _inited = False
+
+
+def device_count():
+    return lib().hs_ed25519_device_count()
+
+
+def shard_plan(n, nshards, shard):
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().hs_ed25519_shard_plan(int(n), int(nshards), int(shard), ctypes.byref(lo), ctypes.byref(hi)), "hs_ed25519_shard_plan")
+    return lo.value, hi.value
+
+
+def set_rlc_key(key):
+    buf, keep = _buf(key)
+    check(lib().hs_ed25519_set_rlc_key(buf), "hs_ed25519_set_rlc_key")
+
+
+def verify_packed_sharded(digests, pks, sigs, n, mode, shared, want_bitmap=False):
+    """hs_ed25519_verify_shared_sharded / _multi_sharded: one call over every device slot."""
+    n = int(n)
+    if len(pks) != 32 * n or len(sigs) != 64 * n or len(digests) != (32 if shared else 32 * n):
+        raise ValueError("packed buffer sizes do not match n=%d" % n)
+    ensure_init()
+    if n == 0:
+        return True, (b"" if want_bitmap else None)
+    bm = (ctypes.c_ubyte * ((n + 7) // 8))() if want_bitmap else None
+    pd, k1 = _buf(digests)
+    pp, k2 = _buf(pks)
+    ps, k3 = _buf(sigs)
+    fn = lib().hs_ed25519_verify_shared_sharded if shared else lib().hs_ed25519_verify_multi_sharded
+    rc = check(fn(pd, pp, ps, n, mode, ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
+               "hs_ed25519_verify_sharded")
+    del k1, k2, k3
+    return rc == 1, (bytes(bm) if bm is not None else None)
+
+
+class ShardedKeySet:
+    """hs_ed25519_keyset_sharded: the committee key cache over every device slot, replicated or
+    partitioned by key owner (include/hs_ed25519.h)."""
+
+    UNKNOWN = 0xFFFFFFFF
+
+    def __init__(self, pks, placement=KEYS_REPLICATE):
+        ensure_init()
+        pks = [bytes(p) for p in pks]
+        self.index = {}
+        for i, p in enumerate(pks):
+            self.index.setdefault(p, i)
+        self.n = len(pks)
+        self._h = ctypes.c_void_p()
+        buf, keep = _buf(b"".join(pks))
+        check(lib().hs_ed25519_keyset_sharded_create(ctypes.byref(self._h), buf, self.n, int(placement)),
+              "hs_ed25519_keyset_sharded_create")
+        del keep
+
+    def bytes_per_device(self, slot):
+        return lib().hs_ed25519_keyset_sharded_bytes_per_device(self._h, int(slot))
+
+    def verify_packed(self, digests, key_idx_packed, sigs, n, mode, shared, want_bitmap=False):
+        n = int(n)
+        if n == 0:
+            return True, (b"" if want_bitmap else None)
+        bm = (ctypes.c_ubyte * ((n + 7) // 8))() if want_bitmap else None
+        pd, k1 = _buf(digests)
+        pi, k2 = _buf(key_idx_packed)
+        ps, k3 = _buf(sigs)
+        fn = lib().hs_ed25519_verify_shared_sharded_cached if shared else lib().hs_ed25519_verify_multi_sharded_cached
+        rc = check(fn(self._h, pd, pi, ps, n, mode, ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
+                   "hs_ed25519_verify_sharded_cached")
+        del k1, k2, k3
+        return rc == 1, (bytes(bm) if bm is not None else None)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hs_ed25519_keyset_sharded_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def ensure_init():
     if not _inited:
         init()
 
 
-KERNEL_AUTO, KERNEL_LANE, KERNEL_QUAD, KERNEL_FUSED = 0, 1, 2, 3
-KERNEL_CACHED_SINGLE_ROLE = 10    # key-cache path only: quad kernel finishing by inversion
-KERNEL_CACHED_LANE2_R = 12        # key-cache path only: two lanes per signature + R-decompression wavefront (cold path: as 2)
-
-
-def set_kernel(which):
-    """hs_ed25519_set_kernel: choose the cold-path kernel variant; returns the previous one."""
-    return lib().hs_ed25519_set_kernel(int(which))
+# DeviceContext.set_kernel: 0 = by batch size; 1 = one lane per signature (cold: k_prepare + k_verify,
+# key cache: k_verify_cached_lane); 3 = fused / two-lane kernels at any size.  Other variants exist
+# only in -DHS_AB_VARIANTS builds (2 quad stage 2 / two-lane inversion, 10, 13: four-lane cached forms).
+KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED = 0, 1, 3
 
 
 def _buf(b):
@@ -212,7 +349,7 @@ class KeySet:
 
     UNKNOWN = 0xFFFFFFFF
 
-    def __init__(self, pks):
+    def __init__(self, pks, slot=0):
         ensure_init()
         pks = [bytes(p) for p in pks]
         if not pks or any(len(p) != 32 for p in pks):
@@ -223,7 +360,7 @@ class KeySet:
         self.n = len(pks)
         self._h = ctypes.c_void_p()
         buf, keep = _buf(b"".join(pks))
-        check(lib().hs_ed25519_keyset_create(ctypes.byref(self._h), buf, self.n), "hs_ed25519_keyset_create")
+        check(lib().hs_ed25519_keyset_create_on(ctypes.byref(self._h), buf, self.n, int(slot)), "hs_ed25519_keyset_create")
         del keep
 
     @property
@@ -271,13 +408,13 @@ class DeviceContext:
     """hs_ed25519_ctx: workspace + stream for device-resident batches.  Pointers are raw
     HIP device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
 
-    def __init__(self, max_batch=1024, partition=None):
+    def __init__(self, max_batch=1024, partition=None, slot=0):
         """partition = (part, nparts): the context's own stream only runs on that slice of the
-        chip's CUs (pass stream=0 to verify() to use it)."""
+        chip's CUs (pass stream=0 to verify() to use it).  slot: device slot (hs_ed25519_init_devices)."""
         ensure_init()
         self._h = ctypes.c_void_p()
         if partition is None:
-            check(lib().hs_ed25519_ctx_create(ctypes.byref(self._h), int(max_batch)), "hs_ed25519_ctx_create")
+            check(lib().hs_ed25519_ctx_create_on(ctypes.byref(self._h), int(max_batch), int(slot)), "hs_ed25519_ctx_create")
         else:
             check(lib().hs_ed25519_ctx_create_partition(ctypes.byref(self._h), int(max_batch), int(partition[0]),
                                                         int(partition[1])), "hs_ed25519_ctx_create_partition")
@@ -295,6 +432,33 @@ class DeviceContext:
         check(lib().hs_ed25519_verify_device_cached(self._h, keyset.handle, d_digests, digest_stride, d_key_idx, d_sigs,
                                                     int(n), mode, d_bitmap, d_nreject or None, stream or None),
               "hs_ed25519_verify_device_cached")
+
+    def verify_tc(self, round_, d_hq_rounds, d_pks, d_sigs, n, d_bitmap, d_nreject=0, stream=0, keyset=None, d_key_idx=0):
+        """hs_ed25519_verify_device_tc[_cached]: TC::verify shape, per-vote digests built on the device."""
+        if keyset is None:
+            check(lib().hs_ed25519_verify_device_tc(self._h, int(round_), d_hq_rounds, d_pks, d_sigs, int(n), d_bitmap,
+                                                    d_nreject or None, stream or None), "hs_ed25519_verify_device_tc")
+        else:
+            check(lib().hs_ed25519_verify_device_tc_cached(self._h, keyset.handle, int(round_), d_hq_rounds, d_key_idx, d_sigs,
+                                                           int(n), d_bitmap, d_nreject or None, stream or None),
+                  "hs_ed25519_verify_device_tc_cached")
+
+    def set_kernel(self, which):
+        """hs_ed25519_ctx_set_kernel; returns the previous choice."""
+        return check(lib().hs_ed25519_ctx_set_kernel(self._h, int(which)), "hs_ed25519_ctx_set_kernel")
+
+    def set_rlc_min(self, n):
+        """Run the RLC stage of BATCH_RLC calls from n signatures up on this context (0 = default)."""
+        check(lib().hs_ed25519_ctx_set_rlc_min(self._h, int(n)), "hs_ed25519_ctx_set_rlc_min")
+
+    def rlc_last(self):
+        """(verdict of the RLC stage of the last BATCH_RLC call: 1 accepted outright, 0 fell through to the
+        per-signature kernels, -1 not run; calls that ran it).  Synchronises the context's stream."""
+        c = ctypes.c_size_t()
+        r = lib().hs_ed25519_ctx_rlc_last(self._h, ctypes.byref(c))
+        if r < -1:          # -1 = "not run"; below that an engine error code
+            check(r, "hs_ed25519_ctx_rlc_last")
+        return r, c.value
 
     def set_profiling(self, slots, every=1):
         check(lib().hs_ed25519_ctx_set_profiling(self._h, int(slots)), "hs_ed25519_ctx_set_profiling")

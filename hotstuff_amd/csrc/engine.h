@@ -1,0 +1,92 @@
+// engine.h - internal host-side declarations shared by the translation units of libhs_ed25519.so
+// (hs_ed25519.hip: kernels of the per-signature paths + contexts, key sets, host API, round ring;
+//  hs_rlc.hip: the batch random-linear-combination MSM path; hs_shard.hip: multi-GPU fan-out;
+//  hs_wire.hip: wire decode + batch signing).  Not installed; the public surface is include/hs_ed25519.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "verify.h"
+#include "../../include/hs_ed25519.h"
+
+namespace hs {
+
+// ---- errors -----------------------------------------------------------------------------------
+int hs_fail(int code, const char *what, hipError_t e = hipSuccess);
+#define HS_HIP(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hs::hs_fail(HS_ED25519_E_DEVICE, what, e_); } while (0)
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+inline size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }
+inline bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+bool bitmap_all_ones(const uint8_t *bm, size_t n);
+
+// ---- devices ----------------------------------------------------------------------------------
+// A "slot" is one entry of the device list given to hs_ed25519_init_devices; slot 0 is the primary
+// device (what hs_ed25519_init(device) selects).  The same HIP ordinal may appear in several slots
+// (tests shard one GPU into several virtual devices).
+int dev_slots();                    // 0 before init
+int dev_ordinal(int slot);          // HIP ordinal of a slot
+const u32 *dev_base_table(int slot);// the base point's window table on that device (built on first use), or nullptr on error
+size_t max_batch_hint();
+bool engine_ready();
+
+}  // namespace hs
+
+// kernel choices of a context (hs_ed25519_ctx_set_kernel)
+enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3 };
+
+struct hs_ed25519_ctx {
+    int slot = 0, device = 0;
+    hipStream_t stream = nullptr;
+    size_t cap = 0;               // signatures
+    hs::u32 *d_ws = nullptr;      // workspace of the two-kernel cold path
+    uint8_t *d_in = nullptr;      // digests | keys | sigs   (host API only)
+    uint8_t *d_out = nullptr;     // bitmap (8*ceil(cap/64)) | 16 spare bytes
+    uint8_t *h_in = nullptr;      // pinned mirror of d_in
+    uint8_t *h_out = nullptr;     // pinned mirror of d_out
+    hs::u32 *d_tc = nullptr;      // timeout-certificate digests built by k_tc_digests (tc_cap signatures)
+    size_t tc_cap = 0;
+    bool staging = false;
+    int kernel = HS_K_AUTO;       // per-context kernel choice (tests, A/B); HS_K_AUTO = by batch size
+    void *rlc = nullptr;          // hs_rlc.hip: this context's MSM workspace (rlc_ws *), freed by rlc_release
+    // optional profiling: a ring of (start, after-prepare, after-verify) HIP events attached to the
+    // kernel dispatches, read back by hs_ed25519_ctx_kernel_times after a synchronize
+    std::vector<hipEvent_t> ev;
+    std::vector<char> ev_mid;     // slot recorded the middle event (a two-kernel call)
+    size_t ev_slots = 0, ev_calls = 0;
+    size_t ev_every = 1, ev_seq = 0;   // record events on every ev_every-th call only
+};
+
+struct hs_ed25519_keyset {
+    int slot = 0;
+    size_t nkeys = 0;
+    hs::u32 *d_tab = nullptr, *d_pk = nullptr, *d_flag = nullptr;
+    hs::u32 *d_niels = nullptr;   // [key][32 words]: affine Niels form of +A (y+x, y-x, 2dxy, pad) for the RLC path
+};
+
+namespace hs {
+int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging);
+int pool_get(hs_ed25519_ctx **out, int slot);
+void pool_put(hs_ed25519_ctx *c);
+int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride);
+// per-signature cold path over n signatures, optionally skipped when *d_skip != 0 (then the bitmap is
+// written all-ones: the RLC fast-accept already vouched for every signature)
+int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n,
+                 uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream, const u32 *d_skip = nullptr);
+int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint32_t *d_key_idx,
+                   const uint8_t *d_sigs, size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream,
+                   const u32 *d_skip = nullptr);
+// one host-pointer verification on one device slot, split so that several devices can be in flight from one thread
+struct host_job { hs_ed25519_ctx *c = nullptr; size_t n = 0; bool zc = false; };
+int host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                const void *keys, const uint8_t *sigs, size_t n, uint32_t mode);
+int host_finish(host_job &job, uint8_t *bitmap);          // 1 / 0 / <0; returns the context to its pool
+void host_abandon(host_job &job);                          // after a failed submit
+const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap (valid until finish)
+// hs_rlc.hip
+void rlc_release(hs_ed25519_ctx *c);
+int rlc_reserve(hs_ed25519_ctx *ctx, size_t n);     // all allocation of an n-signature RLC call, ahead of time
+int enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
+                const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream);
+}  // namespace hs

@@ -1,19 +1,22 @@
-// hs_ed25519.hip - gfx950 kernels and the C-ABI host side of the batch Ed25519
-// verification engine (include/hs_ed25519.h).  Replaces the ed25519-dalek calls at
+// hs_ed25519.hip - gfx950 kernels of the per-signature paths and the C-ABI host side of the batch
+// Ed25519 verification engine (include/hs_ed25519.h).  Replaces the ed25519-dalek calls at
 // /root/reference/crypto/src/lib.rs:203 (verify_strict) and :218 (verify_batch).
 //
 // Device side (one wavefront = 64 lanes per role; DESIGN.md section 5 has the table):
 //   cold path   k_verify_fused            n <= 32,768: four lanes per signature, one launch
 //               k_prepare + k_verify      above: one lane per point / signature, SoA workspace
-//               k_prepare + k_verify_quad kept for A/B
 //   key cache   k_keyset_decompress, k_keyset_build   registration (tables in HBM)
 //               k_verify_cached_lane2r    default up to 196,608: two lanes per signature + a
 //                                         wavefront decompressing the R's beside the chains
 //               k_verify_cached_lane      above: one lane per signature
-//               k_verify_cached_lane2 / _5w / k_verify_cached   other forms, selectable
 //   k_tc_digests                          timeout-certificate digests ahead of any of the above
-// Host side: a pool of stream contexts (pinned staging + device buffers), key sets, the round
-// ring (pinned slots; hipGraph / stream operations / zero-copy), no CPU fallback.
+//   (-DHS_AB_VARIANTS additionally builds k_verify_quad, k_verify_cached, _5w, _lane2: measured
+//    and beaten forms kept for A/B runs, not part of the shipped library)
+// Every verify kernel takes an optional `skip` word: when the batch random-linear-combination
+// check (hs_rlc.hip) has already accepted the whole batch it writes an all-ones bitmap and leaves.
+// Host side: device slots (one or more GPUs), per-slot pools of stream contexts (pinned staging +
+// device buffers), key sets, the round ring (pinned slots; hipGraph / stream operations /
+// zero-copy), no CPU fallback.  hs_shard.hip fans one call out over the slots.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -27,7 +30,7 @@
 #include "verify.h"
 #include "verify_quad.h"
 #include "verify_cached.h"
-#include "../../include/hs_ed25519.h"
+#include "engine.h"
 
 using namespace hs;
 
@@ -38,7 +41,9 @@ __device__ ge_niels g_btab[HS_BTAB_ENTRIES];      // j*B, j = 0..128 (uploaded b
 
 // (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
 __global__ void __launch_bounds__(64, 3)
-k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode) {
+k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+          const u32 *__restrict__ skip) {
+    if (skip && *skip) return;          // the batch fast-accept already vouched for every signature (hs_rlc.hip)
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * n) return;
     const bool is_r = t >= n;
@@ -49,7 +54,13 @@ k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__
 }
 
 __global__ void __launch_bounds__(64)
-k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject) {
+k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject,
+         const u32 *__restrict__ skip) {
+    if (skip && *skip) {
+        const u32 lanes = min(64u, n - blockIdx.x * 64);
+        if (threadIdx.x == 0) bitmap[blockIdx.x] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
+        return;
+    }
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     const bool active = i < n;
     // inactive tail lanes run lane min(i, n-1)'s data so the wavefront stays convergent
@@ -82,6 +93,7 @@ k_tc_digests(unsigned long long round, const unsigned long long *__restrict__ hq
 // 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
 __device__ fe g_btab4[HS_BTAB_ENTRIES][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
 
+#ifdef HS_AB_VARIANTS
 __global__ void __launch_bounds__(64)
 k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
     __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
@@ -108,11 +120,19 @@ k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap
     }
 }
 
+#endif  // HS_AB_VARIANTS
+
 // Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
 __global__ void __launch_bounds__(64, 3)
 k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
-               unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
+               unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+    if (skip && *skip) {
+        const u32 first = blockIdx.x * 16;
+        const u32 here = first < n ? min(16u, n - first) : 0u;
+        if (threadIdx.x == 0) bitmap16[blockIdx.x] = (unsigned short)((1u << here) - 1);
+        return;
+    }
     qtab atab; atab.lds = s_atab;
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
@@ -141,7 +161,7 @@ k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict_
 // registration pass 1: one lane per key - decompress, flags, keep the key bytes
 __global__ void __launch_bounds__(64, 3)
 k_keyset_decompress(const u32 *__restrict__ pks, u32 nkeys, u32 *__restrict__ axy, u32 *__restrict__ pk_out,
-                    u32 *__restrict__ flag) {
+                    u32 *__restrict__ flag, u32 *__restrict__ niels) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
     if (k >= nkeys) return;
     u32 enc[8];
@@ -153,6 +173,15 @@ k_keyset_decompress(const u32 *__restrict__ pks, u32 nkeys, u32 *__restrict__ ax
     flag[k] = fl;
 #pragma unroll
     for (int j = 0; j < 10; j++) { axy[(size_t)20 * k + j] = p.X.v[j]; axy[(size_t)20 * k + 10 + j] = p.Y.v[j]; }
+    // affine Niels record of +A (y+x, y-x, 2dxy; 128 bytes) for the batch MSM path (rlc.h)
+    fe ypx, ymx, xy2d;
+    fe_add(ypx, p.Y, p.X); fe_carry(ypx);
+    fe_sub(ymx, p.Y, p.X); fe_carry(ymx);
+    fe_mul(xy2d, p.T, fe_d2());
+    u32 *rec = niels + (size_t)32 * k;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { rec[j] = ypx.v[j]; rec[10 + j] = ymx.v[j]; rec[20 + j] = xy2d.v[j]; }
+    rec[30] = fl; rec[31] = 0;
 }
 // registration pass 2: one quad per (window, key); the 16 quads of a wavefront share a window
 // so that their 8w doublings stay convergent
@@ -167,6 +196,7 @@ k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u3
     keyset_build_window(tab + (size_t)k * HS_KS_KEY_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
                         ax, ay, negate != 0, (int)w);
 }
+#ifdef HS_AB_VARIANTS
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
 __global__ void __launch_bounds__(64, 3)
 k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
@@ -311,6 +341,7 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
     }
 }
 
+#endif  // HS_AB_VARIANTS
 // Two lanes per signature with the square root off the chains: a workgroup of THREE wavefronts
 // covers 64 signatures.  Wavefronts 0 and 1 run the paired addition chains (32 signatures each);
 // wavefront 2 meanwhile decompresses the 64 R's one lane each and hands (x_R, y_R, flags) over
@@ -319,9 +350,15 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
 __global__ void __launch_bounds__(192)
 k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
                        const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                       u32 *__restrict__ bitmap32, u32 *__restrict__ nreject) {
+                       u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (skip && *skip) {
+        const u32 first = blockIdx.x * 64 + wave * 32;
+        const u32 here = first < n ? min(32u, n - first) : 0u;
+        if (wave < 2 && lane == 0) bitmap32[blockIdx.x * 2 + wave] = here == 32 ? 0xffffffffu : ((1u << here) - 1);
+        return;
+    }
     const bool strict = (mode & HS_MODE_STRICT) != 0;
     ge_p3 acc;
     bool ok = false, active = false;
@@ -383,7 +420,12 @@ k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, 
 __global__ void __launch_bounds__(64)
 k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
                      const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject) {
+                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    if (skip && *skip) {
+        const u32 lanes = min(64u, n - blockIdx.x * 64);
+        if (threadIdx.x == 0) bitmap[blockIdx.x] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
+        return;
+    }
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
@@ -415,52 +457,37 @@ k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, ms
 // host
 // ------------------------------------------------------------------------------------------
 static thread_local char t_err[256] = "";
-static int fail(int code, const char *what, hipError_t e = hipSuccess) {
+int hs::hs_fail(int code, const char *what, hipError_t e) {
     if (e != hipSuccess) snprintf(t_err, sizeof t_err, "%s: %s", what, hipGetErrorString(e));
     else snprintf(t_err, sizeof t_err, "%s", what);
     return code;
 }
-#define HS_HIP(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(HS_ED25519_E_DEVICE, what, e_); } while (0)
+#define fail hs::hs_fail
 
-struct hs_ed25519_ctx {
-    hipStream_t stream = nullptr;
-    size_t cap = 0;               // signatures
-    u32 *d_ws = nullptr;          // workspace
-    uint8_t *d_in = nullptr;      // digests | pks | sigs   (host API only)
-    uint8_t *d_out = nullptr;     // bitmap (8*ceil(cap/64)) | nreject (4) padded
-    uint8_t *h_in = nullptr;      // pinned mirror of d_in
-    uint8_t *h_out = nullptr;     // pinned mirror of d_out
-    u32 *d_tc = nullptr;          // timeout-certificate digests built by k_tc_digests (tc_cap signatures)
-    size_t tc_cap = 0;
-    bool staging = false;
-    // optional profiling: a ring of (start, after-prepare, after-verify) HIP events recorded
-    // on the launch stream, read back by hs_ed25519_ctx_kernel_times after a synchronize
-    std::vector<hipEvent_t> ev;
-    std::vector<char> ev_mid;     // slot recorded the middle event (a two-kernel call)
-    size_t ev_slots = 0, ev_calls = 0;
-    size_t ev_every = 1, ev_seq = 0;   // record events on every ev_every-th call only
+struct dev_state {
+    int ordinal = -1;
+    u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
+    std::vector<hs_ed25519_ctx *> free_ctx;  // the host API's pool of stream contexts on this device
+    int live = 0;
 };
-
 static std::mutex g_mu;
 static std::condition_variable g_cv;
-static bool g_init = false;
-static int g_device = 0;
-static size_t g_max_batch = 0;
-static std::vector<hs_ed25519_ctx *> g_free;
-static int g_live = 0;
-static const int kMaxPool = 8;
-static u32 *g_base_tab = nullptr;   // key-cache path: the base point's own window table
+static std::atomic<bool> g_init{false};
+static std::vector<dev_state> g_devs;        // written under g_mu by init / shutdown only
+static std::atomic<size_t> g_max_batch{0};
+static const int kMaxPool = 16;              // contexts per device slot (one HIP hardware queue each)
 // cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
 // one lane per signature above (profiles/r1_cached_threshold_sweep.md: the three-wavefront form wins or ties
 // from 1,024 to ~200,000 signatures; the one-lane form does the least total work once the chip is several
 // times over-subscribed)
 static const size_t kCachedLane1Min = 196608;
-static std::atomic<int> g_kernel{0};   // 0 = by batch size, 1 = prepare + lane, 2 = prepare + quad, 3 = fused quad
-static const size_t kZeroCopyMax = 16384;   // host-pointer calls up to this size let the kernels read pinned memory directly
+static const size_t kZeroCopyMax = 16384;    // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 
-static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
-static size_t bitmap_bytes(size_t n) { return 8 * ((n + 63) / 64); }
+int hs::dev_slots() { return g_init.load() ? (int)g_devs.size() : 0; }
+int hs::dev_ordinal(int slot) { return (slot >= 0 && slot < hs::dev_slots()) ? g_devs[slot].ordinal : -1; }
+size_t hs::max_batch_hint() { return g_max_batch.load(); }
+bool hs::engine_ready() { return g_init.load(); }
 
 static void ctx_release(hs_ed25519_ctx *c) {
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -470,45 +497,56 @@ static void ctx_release(hs_ed25519_ctx *c) {
     if (c->h_out) (void)hipHostFree(c->h_out);
     c->d_ws = nullptr; c->d_in = c->d_out = c->h_in = c->h_out = nullptr; c->cap = 0;
 }
-static int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging) {
+int hs::ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging) {
     if (n <= c->cap && (!staging || c->staging)) return 0;
     size_t cap = round_up(n < 64 ? 64 : n, 64);
     if (cap < c->cap) cap = c->cap;
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    if (c->stream && c->cap) HS_HIP(hipStreamSynchronize(c->stream), "stream sync");   // the old buffers may be in use
     ctx_release(c);
     HS_HIP(hipMalloc((void **)&c->d_ws, workspace_words(cap) * 4), "hipMalloc workspace");
-    if (staging) {
-        const size_t in_bytes = cap * 128, out_bytes = bitmap_bytes(cap) + 16;
+    if (staging || c->staging) {
+        const size_t in_bytes = cap * 128 + 64, out_bytes = bitmap_bytes(cap) + 16;
         HS_HIP(hipMalloc((void **)&c->d_in, in_bytes), "hipMalloc inputs");
         HS_HIP(hipMalloc((void **)&c->d_out, out_bytes), "hipMalloc outputs");
-        HS_HIP(hipHostMalloc((void **)&c->h_in, in_bytes, hipHostMallocDefault), "hipHostMalloc inputs");
-        HS_HIP(hipHostMalloc((void **)&c->h_out, out_bytes, hipHostMallocDefault), "hipHostMalloc outputs");
+        // Portable: the pinned staging is mapped on every device of the process (a sharded call reads it from several)
+        HS_HIP(hipHostMalloc((void **)&c->h_in, in_bytes, hipHostMallocPortable | hipHostMallocMapped), "hipHostMalloc inputs");
+        HS_HIP(hipHostMalloc((void **)&c->h_out, out_bytes, hipHostMallocPortable | hipHostMallocMapped), "hipHostMalloc outputs");
+        c->staging = true;
     }
-    c->cap = cap; c->staging = staging;
+    c->cap = cap;
     return 0;
 }
 
-extern "C" int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch) {
-    if (!out) return fail(HS_ED25519_E_ARG, "ctx_create: null out");
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+static int ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words) {
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "ctx_create: no such device slot");
+    const int device = g_devs[slot].ordinal;
+    HS_HIP(hipSetDevice(device), "hipSetDevice");
     hs_ed25519_ctx *c = new (std::nothrow) hs_ed25519_ctx();
     if (!c) return fail(HS_ED25519_E_NOMEM, "ctx_create: out of memory");
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, "hipStreamCreate", e); }
+    c->slot = slot; c->device = device;
+    hipError_t e = cu_mask ? hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask)
+                           : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, cu_mask ? "hipExtStreamCreateWithCUMask" : "hipStreamCreate", e); }
     int rc = ctx_reserve(c, max_batch ? max_batch : 64, false);
     if (rc) { (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
     *out = c;
     return 0;
 }
+extern "C" int hs_ed25519_ctx_create_on(hs_ed25519_ctx **out, size_t max_batch, int slot) {
+    if (!out) return fail(HS_ED25519_E_ARG, "ctx_create: null out");
+    return ctx_new(out, max_batch, slot, nullptr, 0);
+}
+extern "C" int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch) { return hs_ed25519_ctx_create_on(out, max_batch, 0); }
 // A context whose own stream may only run on a contiguous slice of the chip's CUs
 // (hipExtStreamCreateWithCUMask).  Concurrent small batches then occupy disjoint CUs instead
 // of being stacked on the same ones by the workgroup dispatcher.
 extern "C" int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_batch, unsigned part, unsigned nparts) {
     if (!out || nparts == 0 || part >= nparts) return fail(HS_ED25519_E_ARG, "ctx_create_partition: bad arguments");
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     hipDeviceProp_t prop;
-    HS_HIP(hipGetDeviceProperties(&prop, g_device), "hipGetDeviceProperties");
+    HS_HIP(hipGetDeviceProperties(&prop, g_devs[0].ordinal), "hipGetDeviceProperties");
     const unsigned cus = (unsigned)prop.multiProcessorCount;
     if (nparts > cus) return fail(HS_ED25519_E_ARG, "ctx_create_partition: more partitions than CUs");
     std::vector<uint32_t> mask((cus + 31) / 32, 0u);
@@ -516,102 +554,130 @@ extern "C" int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_
     // 20 / 24 / 28 slices, which are not aligned to the 32-CU XCDs: 8-12 M) - profiles/r1_stream_sweep.txt
     const unsigned lo = (unsigned)((uint64_t)cus * part / nparts), hi = (unsigned)((uint64_t)cus * (part + 1) / nparts);
     for (unsigned c = lo; c < hi; c++) mask[c / 32] |= 1u << (c % 32);
-    hs_ed25519_ctx *c = new (std::nothrow) hs_ed25519_ctx();
-    if (!c) return fail(HS_ED25519_E_NOMEM, "ctx_create_partition: out of memory");
-    hipError_t e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
-    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, "hipExtStreamCreateWithCUMask", e); }
-    int rc = ctx_reserve(c, max_batch ? max_batch : 64, false);
-    if (rc) { (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
-    *out = c;
-    return 0;
+    return ctx_new(out, max_batch, 0, mask.data(), (uint32_t)mask.size());
 }
 extern "C" void *hs_ed25519_ctx_stream(hs_ed25519_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int hs_ed25519_ctx_device(const hs_ed25519_ctx *c) { return c ? c->device : -1; }
 
 extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
+    (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
+    hs::rlc_release(c);
     ctx_release(c);
     delete c;
 }
+// Per-context kernel choice (tests and A/B measurements; the default is by batch size):
+// HS_K_AUTO 0, HS_K_LANE 1 (cold: k_prepare + k_verify; cached: k_verify_cached_lane),
+// HS_K_FUSED 3 (cold: k_verify_fused; cached: k_verify_cached_lane2r).  Returns the previous choice.
+extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
+    if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_kernel: null context");
+    const int old = c->kernel;
+    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED
+#ifdef HS_AB_VARIANTS
+        || which == 2 || which == 10 || which == 12 || which == 13
+#endif
+    ) c->kernel = which;
+    else return fail(HS_ED25519_E_ARG, "ctx_set_kernel: unknown kernel");
+    return old;
+}
 
-extern "C" int hs_ed25519_init(int device, size_t max_batch) {
+extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
+    if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_init) { if (max_batch > g_max_batch) g_max_batch = max_batch; return 0; }
+    if (g_init.load()) {
+        // idempotent for the same device list; a different one would silently run on the wrong GPUs
+        bool same = g_devs.size() == count;
+        for (size_t i = 0; same && i < count; i++) same = g_devs[i].ordinal == ordinals[i];
+        if (!same) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: already initialised with a different device list "
+                                                   "(hs_ed25519_shutdown first)");
+        if (max_batch > g_max_batch.load()) g_max_batch.store(max_batch);
+        return 0;
+    }
     // The pool, the ring slots and the CU-partitioned contexts each want a hardware queue of their
     // own; HIP's default of 4 multiplexes them (streamed rounds: 22 vs 34 M signatures/s).  The
     // runtime reads this when it initialises, so it only takes effect when this library is the
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    int count = 0;
-    HS_HIP(hipGetDeviceCount(&count), "hipGetDeviceCount");
-    if (device < 0 || device >= count) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
-    HS_HIP(hipSetDevice(device), "hipSetDevice");
+    int have = 0;
+    HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");
+    for (size_t i = 0; i < count; i++)
+        if (ordinals[i] < 0 || ordinals[i] >= have) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
     static ge_niels tab[HS_BTAB_ENTRIES];
     make_base_table(tab, HS_BTAB_ENTRIES);
-    HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
     static fe tab4[HS_BTAB_ENTRIES][4];
     make_base_table_quad(tab4, HS_BTAB_ENTRIES);
-    HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
-    if (const char *k = getenv("HS_ED25519_KERNEL")) {
-        const int sel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : (!strcmp(k, "fused") ? 3 : atoi(k)));
-        if ((sel >= 0 && sel <= 3) || sel == 10 || sel == 12) g_kernel.store(sel);
+    std::vector<dev_state> devs(count);
+    for (size_t i = 0; i < count; i++) {
+        devs[i].ordinal = ordinals[i];
+        HS_HIP(hipSetDevice(ordinals[i]), "hipSetDevice");
+        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
+        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
+        HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     }
-    HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    g_device = device; g_max_batch = max_batch ? max_batch : 1024; g_init = true;
+    HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
+    g_devs.swap(devs);
+    g_max_batch.store(max_batch ? max_batch : 1024);
+    g_init.store(true);
     return 0;
 }
+extern "C" int hs_ed25519_init(int device, size_t max_batch) { return hs_ed25519_init_devices(&device, 1, max_batch); }
+extern "C" int hs_ed25519_device_count(void) { return hs::dev_slots(); }
 extern "C" void hs_ed25519_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (hs_ed25519_ctx *c : g_free) hs_ed25519_ctx_destroy(c);
-    g_free.clear(); g_live = 0; g_init = false;
-    if (g_base_tab) { (void)hipFree(g_base_tab); g_base_tab = nullptr; }
+    if (!g_init.load()) return;
+    g_init.store(false);
+    for (dev_state &d : g_devs) {
+        for (hs_ed25519_ctx *c : d.free_ctx) hs_ed25519_ctx_destroy(c);
+        d.free_ctx.clear(); d.live = 0;
+        if (d.base_tab) { (void)hipSetDevice(d.ordinal); (void)hipFree(d.base_tab); d.base_tab = nullptr; }
+    }
+    g_devs.clear();
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
-// 0 = choose by batch size (default), 1 = k_prepare + k_verify, 2 = k_prepare + k_verify_quad,
-// 3 = k_verify_fused.  For tests and A/B measurements; returns the previous setting.
-extern "C" int hs_ed25519_set_kernel(int which) {
-    const int old = g_kernel.load();
-    if ((which >= 0 && which <= 3) || which == 10 || which == 12) g_kernel.store(which);
-    return old;
-}
-extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
-    const int forced = g_kernel.load();
-    const int k = forced == 10 ? 3 : (forced == 12 ? 2 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1)));
-    return k == 1 ? "k_verify" : (k == 2 ? "k_verify_quad" : "k_verify_fused");
-}
-extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
-extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
-    const int forced = g_kernel.load();
-    if (forced == 1 || (!forced && n > kCachedLane1Min)) return "k_verify_cached_lane";
-    if (forced == 2) return "k_verify_cached_lane2";
-    if (forced == 3) return "k_verify_cached_5w";
-    if (forced == 10) return "k_verify_cached";
-    return "k_verify_cached_lane2r";
+
+// Below this many signatures per call the GPU round trip (launch + one wavefront's serial chain,
+// ~0.40 ms cold / ~0.13 ms with the keys registered) costs more than verifying on one CPU core
+// (~40-50 us per ed25519-dalek strict verification): the Rust shim keeps such calls - the
+// reference's Block / Vote / Timeout::verify singles (consensus/src/messages.rs:64,144,258) and
+// 4-node committees - on dalek.  Crossover measured by bench.py `small_batch_crossover`;
+// env HS_ED25519_MIN_GPU_BATCH overrides.
+extern "C" size_t hs_ed25519_min_gpu_batch(int keys_registered) {
+    if (const char *e = getenv("HS_ED25519_MIN_GPU_BATCH")) { const long v = atol(e); if (v >= 0) return (size_t)v; }
+    return keys_registered ? 4 : 10;
 }
 
-static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
+    const int f = ctx ? ctx->kernel : HS_K_AUTO;
+    if (f == HS_K_AUTO) return n <= kQuadMaxBatch ? HS_K_FUSED : HS_K_LANE;
+    return f;
+}
+extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
+extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
+extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) { return n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r"; }
 
 // One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's
 // start/stop events) instead of bracketing it with marker packets: at 16 concurrent queues two
 // markers per step cost 14 % of small-batch throughput, dispatch timestamps ~3 %.
 // (hipExtAnyOrderLaunch was tried for back-to-back independent batches on one stream: no
 // effect on gfx950, as hip_ext.h warns for GFX9xx.)
-static hipError_t launch1(const void *fn, dim3 grid, void **args, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
-    if (start || stop) return hipExtLaunchKernel(fn, grid, dim3(64), args, 0, st, start, stop, 0);
-    return hipLaunchKernel(fn, grid, dim3(64), args, 0, st);
+static hipError_t launch1(const void *fn, dim3 grid, dim3 block, void **args, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+    if (start || stop) return hipExtLaunchKernel(fn, grid, block, args, 0, st, start, stop, 0);
+    return hipLaunchKernel(fn, grid, block, args, 0, st);
 }
 
 // enqueue the cold path over n signatures whose messages come from `msgs`
-static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n,
-                        uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n,
+                     uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream, const u32 *d_skip) {
     if (!d_pks || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
     if (misaligned(d_pks, 16) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) || misaligned(d_nreject, 4))
         return fail(HS_ED25519_E_ARG, "verify_device: misaligned pointer");
     if (mode > 1 || n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device: bad mode / n");
-    int rc = ctx_reserve(ctx, n, ctx->staging);
-    if (rc) return rc;
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const int kern = kernel_for(ctx, n);
+    if (kern != HS_K_FUSED) { int rc = ctx_reserve(ctx, n, ctx->staging); if (rc) return rc; }
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const u32 np = (u32)round_up(n, 64);
     workspace ws;
@@ -624,29 +690,29 @@ static int enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks,
     u32 nn_ = nn, mode_ = mode;
     unsigned long long *p_bm = (unsigned long long *)d_bitmap;
     u32 *p_nr = d_nreject;
-    void *a1[] = { &ws, &msgs, &p_pk, &p_sg, &nn_, &mode_ };
-    void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
-    void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr };
+    const u32 *p_skip = d_skip;
+    void *a1[] = { &ws, &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_skip };
+    void *a2[] = { &ws, &nn_, &mode_, &p_bm, &p_nr, &p_skip };
+    void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr, &p_skip };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
-    const int forced = g_kernel.load();
-    const int kern = forced == 10 ? 3 : (forced == 12 ? 2 : (forced ? forced : (n <= kQuadMaxBatch ? 3 : 1)));
-    if (ev) ctx->ev_mid[slot] = kern != 3;
-    if (kern == 3) {
-        HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+    if (ev) ctx->ev_mid[slot] = kern != HS_K_FUSED;
+    if (kern == HS_K_FUSED) {
+        HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused");
     } else {
-        HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
+        HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
                "launch k_prepare");
-        if (kern == 2)
-            HS_HIP(launch1((const void *)k_verify_quad, dim3(np / 16), a2, st, nullptr, ev ? ev[2] : nullptr),
-                   "launch k_verify_quad");
-        else
-            HS_HIP(launch1((const void *)k_verify, dim3(np / 64), a2, st, nullptr, ev ? ev[2] : nullptr),
-                   "launch k_verify");
+#ifdef HS_AB_VARIANTS
+        if (kern == 2 || kern == 12) {
+            void *aq[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
+            HS_HIP(launch1((const void *)k_verify_quad, dim3(np / 16), dim3(64), aq, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify_quad");
+        } else
+#endif
+        HS_HIP(launch1((const void *)k_verify, dim3(np / 64), dim3(64), a2, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify");
     }
     return 0;
 }
-static int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride) {
+int hs::make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride) {
     if (!d_digests) return fail(HS_ED25519_E_ARG, "verify_device: null digests");
     if (misaligned(d_digests, 16)) return fail(HS_ED25519_E_ARG, "verify_device: misaligned digests");
     if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "verify_device: bad digest_stride");
@@ -658,6 +724,7 @@ static int make_tc_src(hs_ed25519_ctx *ctx, msg_src &m, uint64_t round, const ui
     if (!d_hq) return fail(HS_ED25519_E_ARG, "verify_device_tc: null high_qc_rounds");
     if (misaligned(d_hq, 8)) return fail(HS_ED25519_E_ARG, "verify_device_tc: misaligned high_qc_rounds");
     if (n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device_tc: bad n");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     if (n > ctx->tc_cap) {
         const size_t cap = round_up(n < 1024 ? 1024 : n, 64);
         hipStream_t own = ctx->stream;
@@ -681,19 +748,26 @@ static int make_tc_src(hs_ed25519_ctx *ctx, msg_src &m, uint64_t round, const ui
 extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
                                         const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
                                         uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device: null context");
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify_device: bad mode");
     if (n == 0) return 0;
     msg_src m;
     int rc = make_digest_src(m, d_digests, digest_stride);
     if (rc) return rc;
+    if (mode == HS_ED25519_BATCH_RLC) {     // dalek's verify_batch: one random linear combination, per-signature fallback
+        u32 *d_ok = nullptr;
+        rc = enqueue_rlc(ctx, nullptr, m, d_pks, nullptr, d_sigs, n, &d_ok, stream);
+        if (rc) return rc;
+        return enqueue_cold(ctx, m, d_pks, d_sigs, n, HS_ED25519_BATCH, d_bitmap, d_nreject, stream, d_ok);
+    }
     return enqueue_cold(ctx, m, d_pks, d_sigs, n, mode, d_bitmap, d_nreject, stream);
 }
 // TC::verify shape with the per-vote digests built on the device (strict semantics)
 extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, const uint64_t *d_high_qc_rounds,
                                            const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap,
                                            uint32_t *d_nreject, void *stream) {
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx) return fail(HS_ED25519_E_ARG, "verify_device_tc: null context");
     if (n == 0) return 0;
     msg_src m;
@@ -704,6 +778,7 @@ extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, 
 
 extern "C" int hs_ed25519_ctx_set_profiling(hs_ed25519_ctx *ctx, size_t slots) {
     if (!ctx) return fail(HS_ED25519_E_ARG, "set_profiling: null context");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     ctx->ev.clear(); ctx->ev_slots = 0; ctx->ev_calls = 0; ctx->ev_seq = 0;
     ctx->ev_mid.assign(slots, 0);
@@ -742,11 +817,6 @@ extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_
 }
 
 // ---- key sets --------------------------------------------------------------------------------
-struct hs_ed25519_keyset {
-    size_t nkeys = 0;
-    u32 *d_tab = nullptr, *d_pk = nullptr, *d_flag = nullptr;
-};
-
 static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate, hipStream_t st) {
     const u32 nk = (u32)nkeys, pad = (u32)round_up(nkeys, 16), neg = negate ? 1u : 0u;
     void *args[] = { &d_tab, &d_axy, (void *)&nk, (void *)&pad, (void *)&neg };
@@ -754,9 +824,12 @@ static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate,
            "launch k_keyset_build");
     return 0;
 }
-static int ensure_base_table() {        // caller holds no lock; idempotent under g_mu
+static int ensure_base_table(int slot) {        // caller holds no lock; idempotent under g_mu
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_base_tab) return 0;
+    if (!g_init.load() || slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
+    dev_state &d = g_devs[slot];
+    if (d.base_tab) return 0;
+    HS_HIP(hipSetDevice(d.ordinal), "hipSetDevice");
     ge_p3 b; ge_basepoint(b);
     u32 h_axy[20];
     for (int j = 0; j < 10; j++) { h_axy[j] = b.X.v[j]; h_axy[10 + j] = b.Y.v[j]; }
@@ -768,31 +841,38 @@ static int ensure_base_table() {        // caller holds no lock; idempotent unde
     if (rc) return rc;
     HS_HIP(hipDeviceSynchronize(), "base table build");
     (void)hipFree(d_axy);
-    g_base_tab = d_tab;
+    d.base_tab = d_tab;
     return 0;
 }
+const u32 *hs::dev_base_table(int slot) {
+    if (ensure_base_table(slot)) return nullptr;
+    return g_devs[slot].base_tab;
+}
 
-extern "C" size_t hs_ed25519_keyset_bytes(size_t nkeys) { return nkeys * ((size_t)HS_KS_KEY_WORDS * 4 + 32 + 4); }
+extern "C" size_t hs_ed25519_keyset_bytes(size_t nkeys) { return nkeys * ((size_t)HS_KS_KEY_WORDS * 4 + 32 + 4 + 128); }
 
-extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t nkeys) {
+extern "C" int hs_ed25519_keyset_create_on(hs_ed25519_keyset **out, const uint8_t *pks, size_t nkeys, int slot) {
     if (!out || !pks || nkeys == 0 || nkeys > 0x0fffffffu) return fail(HS_ED25519_E_ARG, "keyset_create: bad arguments");
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
-    int rc = ensure_base_table();
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "keyset_create: no such device slot");
+    int rc = ensure_base_table(slot);
     if (rc) return rc;
+    HS_HIP(hipSetDevice(g_devs[slot].ordinal), "hipSetDevice");
     hs_ed25519_keyset *ks = new (std::nothrow) hs_ed25519_keyset();
     if (!ks) return fail(HS_ED25519_E_NOMEM, "keyset_create: out of memory");
+    ks->slot = slot;
     u32 *d_in = nullptr, *d_axy = nullptr;
     hipError_t e = hipSuccess;
     do {
         if ((e = hipMalloc((void **)&ks->d_tab, nkeys * (size_t)HS_KS_KEY_WORDS * 4)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&ks->d_pk, nkeys * 32)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&ks->d_flag, nkeys * 4)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&ks->d_niels, nkeys * 128)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&d_in, nkeys * 32)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&d_axy, nkeys * 80)) != hipSuccess) break;
         if ((e = hipMemcpy(d_in, pks, nkeys * 32, hipMemcpyHostToDevice)) != hipSuccess) break;
         const u32 nk = (u32)nkeys;
-        void *a[] = { &d_in, (void *)&nk, &d_axy, &ks->d_pk, &ks->d_flag };
+        void *a[] = { &d_in, (void *)&nk, &d_axy, &ks->d_pk, &ks->d_flag, &ks->d_niels };
         if ((e = hipLaunchKernel((const void *)k_keyset_decompress, dim3((nk + 63) / 64), dim3(64), a, 0, nullptr)) != hipSuccess) break;
         if (build_tables(ks->d_tab, d_axy, nkeys, true, nullptr)) { e = hipErrorUnknown; break; }
         e = hipDeviceSynchronize();
@@ -803,6 +883,7 @@ extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *
         if (ks->d_tab) (void)hipFree(ks->d_tab);
         if (ks->d_pk) (void)hipFree(ks->d_pk);
         if (ks->d_flag) (void)hipFree(ks->d_flag);
+        if (ks->d_niels) (void)hipFree(ks->d_niels);
         delete ks;
         return fail(e == hipErrorOutOfMemory ? HS_ED25519_E_NOMEM : HS_ED25519_E_DEVICE, "keyset_create", e);
     }
@@ -810,72 +891,79 @@ extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *
     *out = ks;
     return 0;
 }
+extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t nkeys) {
+    return hs_ed25519_keyset_create_on(out, pks, nkeys, 0);
+}
 extern "C" void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks) {
     if (!ks) return;
-    (void)hipDeviceSynchronize();
+    const int ord = hs::dev_ordinal(ks->slot);
+    if (ord >= 0) { (void)hipSetDevice(ord); (void)hipDeviceSynchronize(); }
     if (ks->d_tab) (void)hipFree(ks->d_tab);
     if (ks->d_pk) (void)hipFree(ks->d_pk);
     if (ks->d_flag) (void)hipFree(ks->d_flag);
+    if (ks->d_niels) (void)hipFree(ks->d_niels);
     delete ks;
 }
 extern "C" size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks) { return ks ? ks->nkeys : 0; }
 
-static int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint32_t *d_key_idx,
-                          const uint8_t *d_sigs, size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
+int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint32_t *d_key_idx,
+                       const uint8_t *d_sigs, size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream,
+                       const u32 *d_skip) {
     if (!d_key_idx || !d_sigs || !d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_cached: null pointer");
     if (misaligned(d_key_idx, 4) || misaligned(d_sigs, 16) || misaligned(d_bitmap, 8) || misaligned(d_nreject, 4))
         return fail(HS_ED25519_E_ARG, "verify_device_cached: misaligned pointer");
     if (mode > 1 || n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "verify_device_cached: bad mode / n");
+    if (ks->slot != ctx->slot) return fail(HS_ED25519_E_ARG, "verify_device_cached: the key set lives on another device slot than the context");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const u32 np = (u32)round_up(n, 64);
     keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
     u32 nkeys = (u32)ks->nkeys, nn = (u32)n, mode_ = mode;
-    const u32 *p_bt = g_base_tab, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
+    const u32 *p_bt = g_devs[ctx->slot].base_tab, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
     unsigned short *p_bm = (unsigned short *)d_bitmap;
     u32 *p_nr = d_nreject;
-    void *a[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr };
+    const u32 *p_skip = d_skip;
+    void *a[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &p_bm, &p_nr, &p_skip };
     const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
     const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
     hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
     if (ev) ctx->ev_mid[slot] = 0;
-    const int forced = g_kernel.load();
-    const int lanes = forced ? (forced == 1 ? 1 : ((forced == 2 || forced == 12) ? 2 : 4))      /* 3 and 10 -> 4 lanes */
-                             : (n > kCachedLane1Min ? 1 : 2);
-    if (lanes == 1)
-        HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-               "launch k_verify_cached_lane");
-    else if (lanes == 2 && forced == 2)     // selector 2: the single-role two-lane kernel (inversion finish), for A/B
-        HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-               "launch k_verify_cached_lane2");
-    else if (lanes == 2)
-        HS_HIP(ev ? hipExtLaunchKernel((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, 0, st, ev[0], ev[2], 0)
-                  : hipLaunchKernel((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, 0, st),
-               "launch k_verify_cached_lane2r");
-    else if (forced == 2 + 8)      // selector 10: the single-wavefront-role quad kernel (A/B measurements)
-        HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-               "launch k_verify_cached");
+    hipEvent_t e0 = ev ? ev[0] : nullptr, e2 = ev ? ev[2] : nullptr;
+    const int forced = ctx->kernel;
+#ifdef HS_AB_VARIANTS
+    if (forced == 2) { HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane2"); return 0; }
+    if (forced == 10) { HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, st, e0, e2), "launch k_verify_cached"); return 0; }
+    if (forced == 13) { HS_HIP(launch1((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, st, e0, e2), "launch k_verify_cached_5w"); return 0; }
+#endif
+    if (forced == HS_K_LANE || (forced == HS_K_AUTO && n > kCachedLane1Min))
+        HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane");
     else
-        HS_HIP(ev ? hipExtLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st, ev[0], ev[2], 0)
-                  : hipLaunchKernel((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, 0, st),
-               "launch k_verify_cached_5w");
+        HS_HIP(launch1((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, st, e0, e2), "launch k_verify_cached_lane2r");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
                                                size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs,
                                                size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream) {
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_cached: null context / key set");
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify_device_cached: bad mode");
     if (n == 0) return 0;
     msg_src m;
     int rc = make_digest_src(m, d_digests, digest_stride);
     if (rc) return rc;
+    if (mode == HS_ED25519_BATCH_RLC) {     // A served from the key set's Niels records; fallback = the cached per-signature kernels
+        u32 *d_ok = nullptr;
+        rc = enqueue_rlc(ctx, ks, m, nullptr, d_key_idx, d_sigs, n, &d_ok, stream);
+        if (rc) return rc;
+        return enqueue_cached(ctx, ks, m, d_key_idx, d_sigs, n, HS_ED25519_BATCH, d_bitmap, d_nreject, stream, d_ok);
+    }
     return enqueue_cached(ctx, ks, m, d_key_idx, d_sigs, n, mode, d_bitmap, d_nreject, stream);
 }
 extern "C" int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, uint64_t round,
                                                   const uint64_t *d_high_qc_rounds, const uint32_t *d_key_idx,
                                                   const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap, uint32_t *d_nreject,
                                                   void *stream) {
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || !ks) return fail(HS_ED25519_E_ARG, "verify_device_tc_cached: null context / key set");
     if (n == 0) return 0;
     msg_src m;
@@ -885,115 +973,124 @@ extern "C" int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_
 }
 
 // ---- host-pointer API ----------------------------------------------------------------------
-// the call's verdict from the accept bitmap (the host forms pass no reject counter to the kernels)
-static bool bitmap_all_ones(const uint8_t *bm, size_t n) {
+// the call's verdict from the accept bitmap (the host forms pass no reject counter to the kernels);
+// the bitmap words of [0, n) are zeroed before every submit, so a launch that did not write them
+// can never be read as "all accepted"
+bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     const size_t words = n / 64;
     for (size_t i = 0; i < words; i++) { uint64_t w; memcpy(&w, bm + 8 * i, 8); if (w != ~(uint64_t)0) return false; }
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
-// Up to kZeroCopyMax signatures the kernels read the pinned staging and write the pinned bitmap
-// directly over PCIe (hipHostMalloc memory is mapped on the device; every input byte is read
-// exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
-static int pool_get(hs_ed25519_ctx **out) {
+int hs::pool_get(hs_ed25519_ctx **out, int slot) {
     std::unique_lock<std::mutex> lk(g_mu);
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
     for (;;) {
-        if (!g_free.empty()) { *out = g_free.back(); g_free.pop_back(); return 0; }
-        if (g_live < kMaxPool) { g_live++; break; }
+        if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
+        dev_state &d = g_devs[slot];
+        if (!d.free_ctx.empty()) { *out = d.free_ctx.back(); d.free_ctx.pop_back(); return 0; }
+        if (d.live < kMaxPool) { d.live++; break; }
         g_cv.wait(lk);
     }
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
-    int rc = hs_ed25519_ctx_create(&c, 64);
-    if (rc) { lk.lock(); g_live--; g_cv.notify_one(); return rc; }
+    int rc = hs_ed25519_ctx_create_on(&c, 64, slot);
+    if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live--; g_cv.notify_one(); return rc; }
     *out = c;
     return 0;
 }
-static void pool_put(hs_ed25519_ctx *c) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_free.push_back(c);
-    g_cv.notify_one();
+void hs::pool_put(hs_ed25519_ctx *c) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
+    g_devs[c->slot].free_ctx.push_back(c);
+    g_cv.notify_all();
 }
 
-static int verify_host(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
-                       size_t n, uint32_t mode, uint8_t *bitmap) {
-    if (mode > 1) return fail(HS_ED25519_E_ARG, "verify: bad mode");
-    if (n == 0) return g_init ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
-    if (!digests || !pks || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
-    hs_ed25519_ctx *c = nullptr;
-    int rc = pool_get(&c);
+// One host-pointer verification on one device slot, split into submit (stage + enqueue, asynchronous)
+// and finish (wait + verdict) so that hs_shard.hip can have several devices in flight from one thread.
+// Up to kZeroCopyMax signatures the kernels read the pinned staging and write the pinned bitmap
+// directly over PCIe (hipHostMalloc memory is mapped on the device; every input byte is read
+// exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
+//   keys: n*32 key bytes (ks == NULL) or n uint32 indices into `ks`
+int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode) {
+    job.c = nullptr; job.n = n;
+    int rc = pool_get(&job.c, slot);
     if (rc) return rc;
-    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
-    size_t want = n > g_max_batch ? n : g_max_batch;
-    rc = ctx_reserve(c, want, true);
+    hs_ed25519_ctx *c = job.c;
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    const size_t hint = g_max_batch.load();
+    rc = ctx_reserve(c, n > hint ? n : hint, true);
     if (rc) return rc;
-    // staging layout: [digests: dg_bytes][pks: 32n][sigs: 64n], each section 16-byte aligned
-    const size_t dg_bytes = digest_stride ? 32 * n : 32;
-    const size_t off_pk = round_up(dg_bytes, 16), off_sig = off_pk + 32 * n, in_bytes = off_sig + 64 * n;
+    // staging layout: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n], each section 16-byte aligned
+    const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
     memcpy(c->h_in, digests, dg_bytes);
-    memcpy(c->h_in + off_pk, pks, 32 * n);
+    memcpy(c->h_in + off_k, keys, key_bytes);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
-    const bool zc = n <= kZeroCopyMax;
-    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
-    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_pk, in + off_sig, n, mode, outp, nullptr, c->stream);
+    job.zc = n <= kZeroCopyMax;
+    uint8_t *in = job.zc ? c->h_in : c->d_in, *outp = job.zc ? c->h_out : c->d_out;
+    if (job.zc) memset(c->h_out, 0, bitmap_bytes(n));
+    else {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
+    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, c->stream);
+    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, c->stream);
     if (rc) return rc;
-    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
+    return 0;
+}
+// returns 1 / 0 / <0; always gives the context back.  bitmap (optional): ceil(n/8) bytes.
+int hs::host_finish(host_job &job, uint8_t *bitmap) {
+    hs_ed25519_ctx *c = job.c;
+    if (!c) return fail(HS_ED25519_E_ARG, "host_finish: nothing submitted");
+    job.c = nullptr;
+    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
-    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
-    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
+    if (bitmap) memcpy(bitmap, c->h_out, (job.n + 7) / 8);
+    return bitmap_all_ones(c->h_out, job.n) ? 1 : 0;
+}
+void hs::host_abandon(host_job &job) {
+    if (!job.c) return;
+    (void)hipSetDevice(job.c->device);
+    (void)hipStreamSynchronize(job.c->stream);
+    pool_put(job.c);
+    job.c = nullptr;
+}
+const uint8_t *hs::host_job_bitmap(const host_job &job) { return job.c ? job.c->h_out : nullptr; }
+
+static int verify_host(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const void *keys,
+                       const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify: bad mode");
+    if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
+    host_job job;
+    int rc = host_submit(job, ks ? ks->slot : 0, ks, digests, digest_stride, keys, sigs, n, mode);
+    if (rc) { host_abandon(job); return rc; }
+    return host_finish(job, bitmap);
 }
 
 extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
                                         size_t n, uint32_t mode, uint8_t *bitmap) {
-    return verify_host(digest, 0, pks, sigs, n, mode, bitmap);
+    return verify_host(nullptr, digest, 0, pks, sigs, n, mode, bitmap);
 }
 extern "C" int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
                                        size_t n, uint32_t mode, uint8_t *bitmap) {
-    return verify_host(digests, 32, pks, sigs, n, mode, bitmap);
+    return verify_host(nullptr, digests, 32, pks, sigs, n, mode, bitmap);
 }
-
-// host-pointer form of the cached path: key_idx[i] indexes the key set
-static int verify_host_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
-                              const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
-    if (mode > 1) return fail(HS_ED25519_E_ARG, "verify: bad mode");
-    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
-    if (n == 0) return 1;
-    if (!digests || !key_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
-    hs_ed25519_ctx *c = nullptr;
-    int rc = pool_get(&c);
-    if (rc) return rc;
-    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
-    size_t want = n > g_max_batch ? n : g_max_batch;
-    rc = ctx_reserve(c, want, true);
-    if (rc) return rc;
-    // staging (capacity 128 B per signature): [digests][key_idx: 4n][sigs: 64n]
-    const size_t dg_bytes = digest_stride ? 32 * n : 32;
-    const size_t off_ki = round_up(dg_bytes, 16), off_sig = round_up(off_ki + 4 * n, 16), in_bytes = off_sig + 64 * n;
-    memcpy(c->h_in, digests, dg_bytes);
-    memcpy(c->h_in + off_ki, key_idx, 4 * n);
-    memcpy(c->h_in + off_sig, sigs, 64 * n);
-    const bool zc = n <= kZeroCopyMax;
-    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
-    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_ki), in + off_sig,
-                                         n, mode, outp, nullptr, c->stream);
-    if (rc) return rc;
-    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
-    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
-    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
-    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
-}
+// host-pointer forms of the cached path: key_idx[i] indexes the key set
 extern "C" int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
                                                const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
-    return verify_host_cached(ks, digest, 0, key_idx, sigs, n, mode, bitmap);
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
+    return verify_host(ks, digest, 0, key_idx, sigs, n, mode, bitmap);
 }
 extern "C" int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
                                               const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
-    return verify_host_cached(ks, digests, 32, key_idx, sigs, n, mode, bitmap);
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
+    return verify_host(ks, digests, 32, key_idx, sigs, n, mode, bitmap);
 }
 
 // TC::verify from host buffers: the per-vote digests SHA-512(round || high_qc_round)[..32]
@@ -1001,15 +1098,15 @@ extern "C" int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const
 // ks == NULL: keys by bytes (pks_or_idx = n*32 key bytes); else pks_or_idx = n uint32 indices.
 static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *hq_rounds, const void *pks_or_idx,
                           const uint8_t *sigs, size_t n, uint8_t *bitmap) {
-    if (n == 0) return g_init ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!hq_rounds || !pks_or_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_tc: null pointer");
     hs_ed25519_ctx *c = nullptr;
-    int rc = pool_get(&c);
+    int rc = pool_get(&c, ks ? ks->slot : 0);
     if (rc) return rc;
-    struct putter { hs_ed25519_ctx *c; ~putter() { pool_put(c); } } guard{c};
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
-    size_t want = n > g_max_batch ? n : g_max_batch;
-    rc = ctx_reserve(c, want, true);
+    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    const size_t hint = g_max_batch.load();
+    rc = ctx_reserve(c, n > hint ? n : hint, true);
     if (rc) return rc;
     // staging (128 B per signature available): [hq: 8n][keys: 32n or 4n][sigs: 64n]
     const size_t key_bytes = ks ? 4 * n : 32 * n;
@@ -1019,13 +1116,17 @@ static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uin
     memcpy(c->h_in + off_sig, sigs, 64 * n);
     const bool zc = n <= kZeroCopyMax;
     uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
-    if (!zc) HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    if (zc) memset(c->h_out, 0, bitmap_bytes(n));
+    else {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
     if (ks)
         rc = hs_ed25519_verify_device_tc_cached(c, ks, round, (const uint64_t *)in, (const uint32_t *)(in + off_k),
                                                 in + off_sig, n, outp, nullptr, c->stream);
     else
         rc = hs_ed25519_verify_device_tc(c, round, (const uint64_t *)in, in + off_k, in + off_sig, n, outp, nullptr, c->stream);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
     if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
@@ -1052,7 +1153,7 @@ extern "C" int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t
 struct ring_slot {
     hs_ed25519_ctx *ctx = nullptr;
     hipGraphExec_t exec = nullptr;
-    size_t g_n = 0, g_stride = 0; uint32_t g_mode = 0; int g_sel = -1;     // what `exec` was captured for
+    size_t g_n = 0, g_stride = 0; uint32_t g_mode = 0;                      // what `exec` was captured for
     size_t n = 0, stride = 0, off_key = 0, off_sig = 0, in_bytes = 0;       // the round begun in this slot
     bool begun = false, inflight = false;
 };
@@ -1068,7 +1169,7 @@ struct hs_ed25519_ring {
 extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
     if (!r) return;
     for (ring_slot &s : r->slots) {
-        if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
+        if (s.ctx) { (void)hipSetDevice(s.ctx->device); (void)hipStreamSynchronize(s.ctx->stream); }
         if (s.exec) (void)hipGraphExecDestroy(s.exec);
         if (s.ctx) hs_ed25519_ctx_destroy(s.ctx);
     }
@@ -1079,10 +1180,11 @@ extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, 
                                       const hs_ed25519_keyset *ks, uint32_t flags) {
     if (!out || slot_batch == 0 || slots == 0 || slots > 64 || slot_batch > 0x3fffffffu || flags > 3u)
         return fail(HS_ED25519_E_ARG, "ring_create: bad arguments");
-    if (!g_init) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     hs_ed25519_ring *r = new (std::nothrow) hs_ed25519_ring();
     if (!r) return fail(HS_ED25519_E_NOMEM, "ring_create: out of memory");
-    r->cap = round_up(slot_batch, 64); r->ks = ks; // AUTO follows the measurements (profiles/r1_ring_sweep.md): zero-copy wins or ties up to QC-sized rounds of a
+    r->cap = round_up(slot_batch, 64); r->ks = ks;
+    // AUTO follows the measurements (profiles/r1_ring_sweep.md): zero-copy wins or ties up to QC-sized rounds of a
     // 10,000-validator committee; above that the copy engines' bulk transfers are as good and plain stream
     // operations overlap best.  The graph form never won on gfx950 / ROCm 7 and is kept selectable.
     if (flags == HS_ED25519_RING_AUTO) flags = r->cap <= kZeroCopyMax ? HS_ED25519_RING_ZERO_COPY : HS_ED25519_RING_STREAM_OPS;
@@ -1090,7 +1192,7 @@ extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, 
     r->use_graph = flags == HS_ED25519_RING_GRAPH;
     r->slots.resize(slots);
     for (ring_slot &s : r->slots) {
-        int rc = hs_ed25519_ctx_create(&s.ctx, 64);
+        int rc = hs_ed25519_ctx_create_on(&s.ctx, 64, ks ? ks->slot : 0);
         if (!rc) rc = ctx_reserve(s.ctx, r->cap, true);      // all allocation happens here, none under capture
         if (rc) { hs_ed25519_ring_destroy(r); return rc; }
     }
@@ -1121,8 +1223,10 @@ static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
     // zero-copy: hipHostMalloc memory is mapped into the device's address space, so the kernels can
     // take the slot's pinned buffers as they are - every input byte is read exactly once anyway
     uint8_t *in = r->zero_copy ? c->h_in : c->d_in, *outp = r->zero_copy ? c->h_out : c->d_out;
-    if (!r->zero_copy)
+    if (!r->zero_copy) {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(s.n), c->stream), "ring clear bitmap");
         HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, s.in_bytes, hipMemcpyHostToDevice, c->stream), "ring H2D");
+    }
     int rc;
     if (r->ks)
         rc = hs_ed25519_verify_device_cached(c, r->ks, in, s.stride, (const uint32_t *)(in + s.off_key),
@@ -1140,14 +1244,16 @@ extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_
     if (!r || slot >= r->slots.size() || mode > 1) return fail(HS_ED25519_E_ARG, "ring_submit: bad arguments");
     ring_slot &s = r->slots[slot];
     if (!s.begun || s.inflight) return fail(HS_ED25519_E_ARG, "ring_submit: slot not begun / already in flight");
-    HS_HIP(hipSetDevice(g_device), "hipSetDevice");
+    HS_HIP(hipSetDevice(s.ctx->device), "hipSetDevice");
     hipStream_t st = s.ctx->stream;
+    // the verdict is read from the pinned bitmap: clear it so that a round whose kernels did not
+    // write it can never be read as accepted (the zero-copy kernels write this memory directly)
+    memset(s.ctx->h_out, 0, bitmap_bytes(s.n));
     if (!r->use_graph) {
         int rc = ring_enqueue(r, s, mode);
         if (rc) return rc;
     } else {
-        const int sel = g_kernel.load();
-        if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode || s.g_sel != sel) {
+        if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode) {
             hipGraph_t g = nullptr;
             HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
             int rc = ring_enqueue(r, s, mode);
@@ -1164,7 +1270,7 @@ extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_
                 if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
             }
             (void)hipGraphDestroy(g);
-            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode; s.g_sel = sel;
+            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
             r->captures++;
         }
         HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");

@@ -1,0 +1,355 @@
+// hs_shard.hip - one verification call fanned out over the GPUs of a node, behind the C ABI.
+//
+// The reference node is ONE process whose Core task calls QC::verify (consensus/src/messages.rs:197
+// -> crypto/src/lib.rs:206-219); it cannot run one process per GPU.  hs_ed25519_init_devices opens
+// several device slots and the *_sharded entry points cut a batch into one contiguous shard per
+// slot (signatures are independent units, no data-path collective), stage and launch
+// every shard from the calling thread - all devices run concurrently - and then bring the per-shard
+// accept bitmaps together.  Two exchanges, same result:
+//   HS_ED25519_EXCHANGE_HOST   every device writes / copies its <= 1 KB bitmap slice to pinned host
+//                              memory; the host concatenates and ANDs (default: at this size the
+//                              collective is pure latency)
+//   HS_ED25519_EXCHANGE_RCCL   in-process RCCL all-gather of the slices over xGMI (ncclCommInitAll,
+//                              one communicator per slot, grouped call), then one D2H from slot 0 -
+//                              what BASELINE.json's north_star names; librccl is dlopen'ed on first use.
+// Shard bounds are multiples of 64 signatures, so slices are whole 64-bit wavefront ballots and
+// concatenate bit-exactly.
+//
+// Committee key cache on several GPUs (hs_ed25519_keyset_sharded_*): a QC is an arbitrary 2f+1
+// subset of the committee, so votes do not line up with any slicing of the key table.  Two placements:
+//   REPLICATE  every slot holds the whole table (100,000 validators = 66 GB per GPU of 288 GB);
+//              shards stay contiguous, no host-side routing.
+//   BY_OWNER   slot s holds keys [k_lo(s), k_hi(s)); the host routes each vote to its key's owner
+//              (counting sort by owner), and scatters the per-slot verdict bits back.  1/k of the
+//              memory per GPU; shard sizes follow the vote distribution (binomial around n/k).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <string.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
+#include <rccl/rccl.h>
+#include "engine.h"
+
+using namespace hs;
+#define fail hs::hs_fail
+
+// ---- shard plan (pure host arithmetic; exported so that the shim and the tests use the same cut) ----
+extern "C" int hs_ed25519_shard_plan(size_t n, unsigned nshards, unsigned shard, size_t *lo, size_t *hi) {
+    if (!lo || !hi || nshards == 0 || shard >= nshards) return fail(HS_ED25519_E_ARG, "shard_plan: bad arguments");
+    const size_t per = (n + nshards - 1) / nshards;
+    const size_t S = n ? round_up(per, 64) : 64;
+    const size_t l = (size_t)shard * S < n ? (size_t)shard * S : n;
+    *lo = l; *hi = l + S < n ? l + S : n;
+    return 0;
+}
+
+// ---- RCCL, loaded on demand -----------------------------------------------------------------------
+namespace {
+struct rccl_api {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+std::mutex s_mu;
+rccl_api s_rccl;
+std::vector<ncclComm_t> s_comms;       // one per slot
+std::vector<uint8_t *> s_gather;       // per slot: device buffer for the gathered bitmaps
+size_t s_gather_bytes = 0;
+std::atomic<int> s_exchange{HS_ED25519_EXCHANGE_HOST};
+
+int rccl_load() {      // under s_mu
+    if (s_rccl.h) return 0;
+    const char *names[] = { "librccl.so.1", "librccl.so" };
+    void *h = nullptr;
+    for (const char *nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;     // the copy the process already has (PyTorch's)
+    if (!h) for (const char *nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(HS_ED25519_E_DEVICE, "RCCL exchange: librccl.so not found");
+    rccl_api a; a.h = h;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.AllGather || !a.GroupStart || !a.GroupEnd)
+        return fail(HS_ED25519_E_DEVICE, "RCCL exchange: librccl.so lacks a required symbol");
+    s_rccl = a;
+    return 0;
+}
+int rccl_fail(const char *what, ncclResult_t r) {
+    char buf[200];
+    snprintf(buf, sizeof buf, "%s: %s", what, s_rccl.GetErrorString ? s_rccl.GetErrorString(r) : "RCCL error");
+    return fail(HS_ED25519_E_DEVICE, buf);
+}
+int rccl_ensure(size_t slice_bytes) {      // under s_mu: communicators + gather buffers for the current device list
+    int rc = rccl_load();
+    if (rc) return rc;
+    const int k = dev_slots();
+    if ((int)s_comms.size() != k) {
+        std::vector<int> ords(k);
+        for (int s = 0; s < k; s++) ords[s] = dev_ordinal(s);
+        for (int a = 0; a < k; a++) for (int b = a + 1; b < k; b++)
+            if (ords[a] == ords[b]) return fail(HS_ED25519_E_ARG, "RCCL exchange: the same GPU appears in two device slots (use the host exchange)");
+        std::vector<ncclComm_t> comms(k);
+        ncclResult_t r = s_rccl.CommInitAll(comms.data(), k, ords.data());
+        if (r != ncclSuccess) return rccl_fail("ncclCommInitAll", r);
+        s_comms.swap(comms);
+    }
+    const size_t want = round_up((size_t)k * slice_bytes, 256);
+    if (want > s_gather_bytes || (int)s_gather.size() != k) {
+        for (size_t s = 0; s < s_gather.size(); s++) if (s_gather[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(s_gather[s]); }
+        s_gather.assign(k, nullptr); s_gather_bytes = 0;
+        for (int s = 0; s < k; s++) {
+            HS_HIP(hipSetDevice(dev_ordinal(s)), "hipSetDevice");
+            HS_HIP(hipMalloc((void **)&s_gather[s], want), "hipMalloc gather buffer");
+        }
+        s_gather_bytes = want;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" void hs_ed25519_shard_reset(void) {      // called by tests / before shutdown: drop communicators and buffers
+    std::lock_guard<std::mutex> lk(s_mu);
+    for (size_t s = 0; s < s_gather.size(); s++) if (s_gather[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(s_gather[s]); }
+    s_gather.clear(); s_gather_bytes = 0;
+    if (s_rccl.CommDestroy) for (ncclComm_t c : s_comms) if (c) (void)s_rccl.CommDestroy(c);
+    s_comms.clear();
+}
+extern "C" int hs_ed25519_set_shard_exchange(int how) {
+    if (how != HS_ED25519_EXCHANGE_HOST && how != HS_ED25519_EXCHANGE_RCCL) return fail(HS_ED25519_E_ARG, "set_shard_exchange: unknown exchange");
+    return s_exchange.exchange(how);
+}
+
+// ---- the fan-out ----------------------------------------------------------------------------------
+// items[s]: what slot s verifies.  keys: 32-byte keys or uint32 indices (with ks).  Returns per-slot bitmaps via finish.
+namespace {
+struct shard_item {
+    const hs_ed25519_keyset *ks = nullptr;
+    const uint8_t *digests = nullptr; const void *keys = nullptr; const uint8_t *sigs = nullptr;
+    size_t n = 0;
+};
+
+// run all items concurrently; out_bm[s] (optional per slot) receives ceil(n_s/8) bytes.  Verdict = AND.
+int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32_t mode, std::vector<std::vector<uint8_t>> *out_bm,
+              bool want_rccl, size_t slice_bytes, std::vector<uint8_t> *gathered) {
+    const int k = (int)items.size();
+    std::vector<host_job> jobs(k);
+    int rc = 0;
+    for (int s = 0; s < k && !rc; s++) {
+        if (!items[s].n) continue;
+        rc = host_submit(jobs[s], s, items[s].ks, items[s].digests, digest_stride, items[s].keys, items[s].sigs, items[s].n, mode);
+    }
+    if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
+    if (want_rccl) {
+        // all-gather of equal slice_bytes slices: slot s contributes its bitmap padded with zeros
+        std::lock_guard<std::mutex> lk(s_mu);
+        rc = rccl_ensure(slice_bytes);
+        if (!rc) {
+            std::vector<uint8_t *> send(k, nullptr);
+            for (int s = 0; s < k && !rc; s++) {
+                hs_ed25519_ctx *c = jobs[s].c;
+                if (!c) {      // an empty shard still takes part in the collective: borrow a context for its stream
+                    rc = pool_get(&jobs[s].c, s); c = jobs[s].c; jobs[s].n = 0;
+                    if (rc) break;
+                }
+                if (hipSetDevice(c->device) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
+                // slice = the first slice_bytes of the gather buffer's own slot region, filled on the stream
+                send[s] = s_gather[s] + (size_t)s * slice_bytes;
+                hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, c->stream);
+                if (e == hipSuccess && jobs[s].n) {
+                    const uint8_t *src = jobs[s].zc ? c->h_out : c->d_out;
+                    e = hipMemcpyAsync(send[s], src, bitmap_bytes(jobs[s].n) < slice_bytes ? bitmap_bytes(jobs[s].n) : slice_bytes,
+                                       jobs[s].zc ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream);
+                }
+                if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the slice", e);
+            }
+            if (!rc) {
+                ncclResult_t r = s_rccl.GroupStart();
+                for (int s = 0; s < k && r == ncclSuccess; s++)
+                    r = s_rccl.AllGather(send[s], s_gather[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].c->stream);   // in place
+                const ncclResult_t r2 = s_rccl.GroupEnd();
+                if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather", r != ncclSuccess ? r : r2);
+            }
+            if (!rc) {
+                gathered->assign((size_t)k * slice_bytes, 0);
+                hs_ed25519_ctx *c0 = jobs[0].c;
+                if (hipSetDevice(c0->device) != hipSuccess ||
+                    hipMemcpyAsync(gathered->data(), s_gather[0], gathered->size(), hipMemcpyDeviceToHost, c0->stream) != hipSuccess)
+                    rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: reading the gathered bitmap");
+            }
+        }
+        if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
+    }
+    int verdict = 1;
+    for (int s = 0; s < k; s++) {
+        if (!jobs[s].c) continue;
+        if (!jobs[s].n) { host_abandon(jobs[s]); continue; }
+        uint8_t *bm = nullptr;
+        if (out_bm) { (*out_bm)[s].assign((items[s].n + 7) / 8, 0); bm = (*out_bm)[s].data(); }
+        const int r = host_finish(jobs[s], bm);
+        if (r < 0) { rc = r; verdict = r; for (host_job &j : jobs) host_abandon(j); return rc; }
+        if (r == 0) verdict = 0;
+    }
+    return verdict;
+}
+
+int verify_sharded_contiguous(const hs_ed25519_keyset *const *ks_per_slot, const uint8_t *digests, size_t digest_stride,
+                              const void *keys, size_t key_bytes, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify_sharded: bad mode");
+    const int k = dev_slots();
+    if (k <= 0) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (n == 0) return 1;
+    if (!digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "verify_sharded: null pointer");
+    std::vector<shard_item> items(k);
+    size_t S = 0;
+    for (int s = 0; s < k; s++) {
+        size_t lo, hi;
+        hs_ed25519_shard_plan(n, (unsigned)k, (unsigned)s, &lo, &hi);
+        if (s == 0) S = hi - lo;
+        items[s].ks = ks_per_slot ? ks_per_slot[s] : nullptr;
+        items[s].digests = digest_stride ? digests + 32 * lo : digests;
+        items[s].keys = (const uint8_t *)keys + key_bytes * lo;
+        items[s].sigs = sigs + 64 * lo;
+        items[s].n = hi - lo;
+    }
+    const size_t slice = round_up(S, 64) / 8;
+    const bool rccl = s_exchange.load() == HS_ED25519_EXCHANGE_RCCL;
+    std::vector<std::vector<uint8_t>> bms(k);
+    std::vector<uint8_t> gathered;
+    const int verdict = run_items(items, digest_stride, mode, bitmap && !rccl ? &bms : nullptr, rccl, slice, &gathered);
+    if (verdict < 0) return verdict;
+    if (rccl) {
+        // slices are whole 64-bit words at offset s*slice bytes = s*S signatures: the concatenation IS the bitmap
+        if (bitmap) memcpy(bitmap, gathered.data(), (n + 7) / 8);
+        return bitmap_all_ones(gathered.data(), n) ? 1 : 0;
+    }
+    if (bitmap)
+        for (int s = 0; s < k; s++) {
+            size_t lo, hi;
+            hs_ed25519_shard_plan(n, (unsigned)k, (unsigned)s, &lo, &hi);
+            if (hi > lo) memcpy(bitmap + lo / 8, bms[s].data(), (hi - lo + 7) / 8);
+        }
+    return verdict;
+}
+}  // namespace
+
+extern "C" int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
+                                                uint32_t mode, uint8_t *bitmap) {
+    return verify_sharded_contiguous(nullptr, digest, 0, pks, 32, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                                               uint32_t mode, uint8_t *bitmap) {
+    return verify_sharded_contiguous(nullptr, digests, 32, pks, 32, sigs, n, mode, bitmap);
+}
+
+// ---- committee key cache over several GPUs ------------------------------------------------------
+struct hs_ed25519_keyset_sharded {
+    int placement = HS_ED25519_KEYS_REPLICATE;
+    size_t nkeys = 0;
+    std::vector<hs_ed25519_keyset *> per_slot;
+    std::vector<size_t> key_lo;          // BY_OWNER: first key of slot s (key_lo[k] = nkeys)
+};
+extern "C" void hs_ed25519_keyset_sharded_destroy(hs_ed25519_keyset_sharded *kss) {
+    if (!kss) return;
+    for (hs_ed25519_keyset *ks : kss->per_slot) hs_ed25519_keyset_destroy(ks);
+    delete kss;
+}
+extern "C" int hs_ed25519_keyset_sharded_create(hs_ed25519_keyset_sharded **out, const uint8_t *pks, size_t nkeys, int placement) {
+    if (!out || !pks || nkeys == 0) return fail(HS_ED25519_E_ARG, "keyset_sharded_create: bad arguments");
+    if (placement != HS_ED25519_KEYS_REPLICATE && placement != HS_ED25519_KEYS_BY_OWNER)
+        return fail(HS_ED25519_E_ARG, "keyset_sharded_create: unknown placement");
+    const int k = dev_slots();
+    if (k <= 0) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    hs_ed25519_keyset_sharded *kss = new (std::nothrow) hs_ed25519_keyset_sharded();
+    if (!kss) return fail(HS_ED25519_E_NOMEM, "keyset_sharded_create: out of memory");
+    kss->placement = placement; kss->nkeys = nkeys;
+    kss->per_slot.assign(k, nullptr); kss->key_lo.assign(k + 1, nkeys);
+    for (int s = 0; s < k; s++) {
+        size_t lo = 0, hi = nkeys;
+        if (placement == HS_ED25519_KEYS_BY_OWNER) hs_ed25519_shard_plan(nkeys, (unsigned)k, (unsigned)s, &lo, &hi);
+        kss->key_lo[s] = placement == HS_ED25519_KEYS_BY_OWNER ? lo : 0;
+        if (hi == lo) continue;              // more slots than 64-key slices: this slot owns no key
+        int rc = hs_ed25519_keyset_create_on(&kss->per_slot[s], pks + 32 * lo, hi - lo, s);
+        if (rc) { hs_ed25519_keyset_sharded_destroy(kss); return rc; }
+    }
+    *out = kss;
+    return 0;
+}
+extern "C" size_t hs_ed25519_keyset_sharded_bytes_per_device(const hs_ed25519_keyset_sharded *kss, int slot) {
+    if (!kss || slot < 0 || slot >= (int)kss->per_slot.size() || !kss->per_slot[slot]) return 0;
+    return hs_ed25519_keyset_bytes(kss->per_slot[slot]->nkeys);
+}
+
+static int verify_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uint8_t *digests, size_t digest_stride,
+                                 const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (!kss) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: null key set");
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: bad mode");
+    const int k = dev_slots();
+    if (k <= 0 || (int)kss->per_slot.size() != k) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: key set built for another device list");
+    if (n == 0) return 1;
+    if (!digests || !key_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: null pointer");
+    if (kss->placement == HS_ED25519_KEYS_REPLICATE)
+        return verify_sharded_contiguous(kss->per_slot.data(), digests, digest_stride, key_idx, 4, sigs, n, mode, bitmap);
+    // BY_OWNER: route every vote to the slot that holds its key (counting sort by owner, stable)
+    std::vector<uint32_t> owner(n);
+    std::vector<size_t> count(k + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t ki = key_idx[i];
+        int o = 0;
+        if (ki < kss->nkeys) { while (o + 1 < k && ki >= kss->key_lo[o + 1]) o++; }
+        else { while (o < k && !kss->per_slot[o]) o++; if (o == k) o = 0; }    // unknown key: any slot rejects it
+        owner[i] = (uint32_t)o; count[o + 1]++;
+    }
+    for (int s = 0; s < k; s++) count[s + 1] += count[s];
+    std::vector<size_t> pos(count.begin(), count.end() - 1);
+    std::vector<uint32_t> order(n), lidx(n);
+    std::vector<uint8_t> rsig(64 * n), rdg(digest_stride ? 32 * n : 0);
+    for (size_t i = 0; i < n; i++) {
+        const int o = (int)owner[i];
+        const size_t p = pos[o]++;
+        order[p] = (uint32_t)i;
+        const uint32_t ki = key_idx[i];
+        lidx[p] = ki < kss->nkeys ? (uint32_t)(ki - kss->key_lo[o]) : 0xffffffffu;
+        memcpy(&rsig[64 * p], sigs + 64 * i, 64);
+        if (digest_stride) memcpy(&rdg[32 * p], digests + 32 * i, 32);
+    }
+    std::vector<shard_item> items(k);
+    for (int s = 0; s < k; s++) {
+        items[s].ks = kss->per_slot[s];
+        items[s].n = count[s + 1] - count[s];
+        if (!items[s].n) continue;
+        if (!items[s].ks) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: vote routed to a slot without keys");
+        items[s].digests = digest_stride ? &rdg[32 * count[s]] : digests;
+        items[s].keys = &lidx[count[s]];
+        items[s].sigs = &rsig[64 * count[s]];
+    }
+    std::vector<std::vector<uint8_t>> bms(k);
+    std::vector<uint8_t> unused;
+    // routed shards are ragged (their sizes follow the votes), so the slices go through the host exchange
+    const int verdict = run_items(items, digest_stride, mode, bitmap ? &bms : nullptr, false, 0, &unused);
+    if (verdict < 0) return verdict;
+    if (bitmap) {
+        memset(bitmap, 0, (n + 7) / 8);
+        for (int s = 0; s < k; s++)
+            for (size_t j = 0; j < items[s].n; j++)
+                if ((bms[s][j >> 3] >> (j & 7)) & 1) { const uint32_t i = order[count[s] + j]; bitmap[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+    }
+    return verdict;
+}
+extern "C" int hs_ed25519_verify_shared_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uint8_t digest[32],
+                                                       const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
+                                                       uint8_t *bitmap) {
+    return verify_sharded_cached(kss, digest, 0, key_idx, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uint8_t *digests,
+                                                      const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
+                                                      uint8_t *bitmap) {
+    return verify_sharded_cached(kss, digests, 32, key_idx, sigs, n, mode, bitmap);
+}

@@ -53,14 +53,25 @@ class Vote:
 
 
 class VoteIngest:
-    """Aggregates votes for one (round, block hash) and verifies them in batches."""
+    """Aggregates votes for one (round, block hash) and verifies them in batches.
+
+    Authority bookkeeping follows the reference's ORDER: there a vote is verified first
+    (core.rs:210 Vote::verify) and only a vote that verified marks its author used
+    (aggregator.rs:79-82 QCMaker::append).  So here an author is `used` only once a signature
+    from it has verified.  Unverified candidates wait keyed by (author, signature): several may
+    wait for the same author (anyone can send a garbage-signature vote naming authority X; it
+    must neither block X's genuine vote while pending nor after it has been dropped), an exact
+    duplicate of a waiting candidate is ignored, and at most one candidate per author is
+    accepted.  AuthorityReuse is raised exactly where the reference raises it: for a vote
+    whose author already has an accepted vote."""
 
     def __init__(self, committee, verify_fn=None, max_pending=None):
         self.committee = committee
         self.verify_fn = verify_fn or _gpu_verify(committee)
         self.max_pending = max_pending
-        self.used = set()
+        self.used = set()          # authors with a VERIFIED vote (aggregator.rs `used`)
         self.pending = []          # votes whose signature has not been checked yet
+        self._pending_keys = set() # (author bytes, signature bytes) of the waiting candidates
         self.valid = []            # (author, signature) with a verified signature
         self.valid_weight = 0
         self.done = False
@@ -70,39 +81,46 @@ class VoteIngest:
         self.dropped = []
 
     def add_vote(self, vote):
-        """Structural checks now (aggregator.rs:79-82, messages.rs:138-142), signature later.
+        """Structural checks now (messages.rs:138-142, aggregator.rs:79-82), signature later.
         Returns a QC the first time the verified stake reaches the quorum, else None."""
         if self.hash is None:
             self.hash, self.round = vote.hash, vote.round
         elif (vote.hash, vote.round) != (self.hash, self.round):
             raise ValueError("VoteIngest handles one (hash, round); use one instance per aggregator entry")
-        if vote.author in self.used:
-            raise AuthorityReuse(vote.author)
         if self.committee.stake(vote.author) <= 0:
             raise UnknownAuthority(vote.author)
-        self.used.add(vote.author)
+        if vote.author in self.used:
+            raise AuthorityReuse(vote.author)      # a verified vote of this author is already in (aggregator.rs:79-82)
         if self.done:
             return None            # the certificate exists; late votes need no verification
+        key = (vote.author.b, vote.signature.flatten())
+        if key in self._pending_keys:
+            return None            # byte-identical to a candidate already waiting
+        self._pending_keys.add(key)
         self.pending.append(vote)
-        pend_weight = sum(self.committee.stake(v.author) for v in self.pending)
+        # stake that COULD verify: one candidate per author at most
+        pend_weight = sum(self.committee.stake(a) for a in {v.author for v in self.pending})
         if (self.valid_weight + pend_weight >= self.committee.quorum_threshold()
                 or (self.max_pending and len(self.pending) >= self.max_pending)):
             return self.flush()
         return None
 
     def flush(self):
-        """Verify everything pending in one call; keep the valid votes."""
+        """Verify everything pending in one call; keep the valid votes (first valid candidate per
+        author), drop the rest individually - the set the reference drops one by one."""
         if self.pending:
             votes = [(v.author, v.signature) for v in self.pending]
             oks = self.verify_fn(self.pending[0].digest(), votes)
             self.gpu_calls += 1
             for v, ok in zip(self.pending, oks):
-                if ok:
+                if ok and v.author not in self.used:
+                    self.used.add(v.author)
                     self.valid.append((v.author, v.signature))
                     self.valid_weight += self.committee.stake(v.author)
-                else:
+                elif not ok:
                     self.dropped.append(v.author)     # the reference warns and drops (core.rs:434-439)
             self.pending = []
+            self._pending_keys = set()
         if not self.done and self.valid_weight >= self.committee.quorum_threshold():
             self.done = True                          # QCMaker: "ensures QC is only made once"
             return QC(self.hash, self.round, list(self.valid))
@@ -162,7 +180,8 @@ class Timeout:
             self.signature.verify(self.digest(), self.author)
         except Exception as e:
             raise InvalidSignature() from e
-        if self.high_qc.votes or self.high_qc.round != 0 or self.high_qc.hash != Digest():   # != QC::genesis()
+        # `high_qc != QC::genesis()`: QC's PartialEq compares hash and round only (messages.rs:217-221)
+        if self.high_qc.round != 0 or self.high_qc.hash != Digest():
             if qc_cache is not None:
                 qc_cache.verify(self.high_qc, committee)
             else:

@@ -30,6 +30,18 @@
  *                          returns this per-signature verdict.  DESIGN.md section 3.)
  *   HS_ED25519_STRICT (1)  `PublicKey::verify_strict`: BATCH plus reject when
  *                          [8]R == O or [8]A == O.
+ *   HS_ED25519_BATCH_RLC (2)  ed25519-dalek 1.0.1 `verify_batch` as it computes it: ONE
+ *                          random linear combination  -[sum z_i s_i]B + sum [z_i]R_i +
+ *                          sum [z_i h_i mod L]A_i == O  over the whole call (128-bit z_i,
+ *                          Pippenger multi-scalar multiplication on the GPU).  If it holds the
+ *                          call accepts (bitmap all ones); if it does not, the per-signature
+ *                          BATCH kernels run in the same call and localise the rejects, so the
+ *                          verdict and bitmap are then exactly BATCH's.  Identical to BATCH on
+ *                          every input where dalek is deterministic (SURVEY.md 8a classes i / ii);
+ *                          on crafted torsion inputs (class iii) it can accept where BATCH
+ *                          rejects, with dalek's own probability.  z_i = SHA-512(process-secret
+ *                          key || h_i || s_i || i): unpredictable to whoever built the batch, as
+ *                          dalek's thread_rng is (hs_ed25519_set_rlc_key pins it for tests).
  *
  * Return value of every verify call:
  *    1  every signature accepted (n == 0 -> 1, as lib.rs:206-219 returns Ok)
@@ -55,6 +67,7 @@ extern "C" {
 
 #define HS_ED25519_BATCH 0u
 #define HS_ED25519_STRICT 1u
+#define HS_ED25519_BATCH_RLC 2u
 
 #define HS_ED25519_E_NOT_INIT (-1) /* hs_ed25519_init not called or failed        */
 #define HS_ED25519_E_DEVICE (-2)   /* HIP runtime error (see hs_ed25519_last_error) */
@@ -65,7 +78,26 @@ extern "C" {
  * context pool for batches of `max_batch` signatures (contexts grow on demand).
  * Idempotent and thread-safe.  Returns 0 or HS_ED25519_E_*. */
 int hs_ed25519_init(int device, size_t max_batch);
+/* Several GPUs behind one process (the reference node is one process: consensus/src/messages.rs:197
+ * is called from the single Core task).  `ordinals[0..count)` are HIP device ordinals; entry s becomes
+ * device slot s, slot 0 being the primary device every non-sharded call uses.  The same ordinal may
+ * appear more than once (virtual devices: tests shard one GPU).  Idempotent for the same list; a
+ * different list after a successful init is HS_ED25519_E_ARG (shutdown first). */
+int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch);
+int hs_ed25519_device_count(void);        /* device slots, 0 before init */
 void hs_ed25519_shutdown(void);
+/* The batch size below which a call should stay on the CPU path of the shim (dalek): the GPU round
+ * trip costs one wavefront's serial chain (~0.4 ms cold, ~0.13 ms with registered keys) whatever n
+ * is.  keys_registered != 0: the caller would use a *_cached entry point.  bench.py measures the
+ * crossover (`small_batch_crossover`); env HS_ED25519_MIN_GPU_BATCH overrides. */
+size_t hs_ed25519_min_gpu_batch(int keys_registered);
+/* HS_ED25519_BATCH_RLC draws its 128-bit coefficients from SHA-512 keyed with a 32-byte secret taken
+ * from the OS at first use; this pins it (tests, reproducible runs). */
+int hs_ed25519_set_rlc_key(const uint8_t key[32]);
+/* HS_ED25519_BATCH_RLC calls below this size run as plain HS_ED25519_BATCH (the five-stage MSM pipeline
+ * only pays from a few thousand signatures up; profiles/r2_rlc_ab.md).  A context can override the
+ * threshold (tests run the pipeline from n = 1); 0 restores the default. */
+size_t hs_ed25519_rlc_min_batch(void);
 /* Human-readable text of the last engine error seen by the calling thread. */
 const char *hs_ed25519_last_error(void);
 
@@ -94,7 +126,14 @@ int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const ui
  * work on other streams (including the null stream) that produces the inputs or consumes the
  * bitmap must be ordered against it explicitly (event / stream wait / synchronize). */
 typedef struct hs_ed25519_ctx hs_ed25519_ctx;
-int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch);
+int hs_ed25519_ctx_create(hs_ed25519_ctx **out, size_t max_batch);                 /* on device slot 0 */
+int hs_ed25519_ctx_create_on(hs_ed25519_ctx **out, size_t max_batch, int slot);
+int hs_ed25519_ctx_device(const hs_ed25519_ctx *ctx);                                /* HIP ordinal */
+int hs_ed25519_ctx_set_rlc_min(hs_ed25519_ctx *ctx, size_t min_batch);
+/* After the context's stream has drained: 1 = the last HS_ED25519_BATCH_RLC call on it accepted the
+ * batch by the combination alone, 0 = it fell through to the per-signature kernels, -1 = the RLC
+ * stage has not run; *calls (optional) = how many calls ran it. */
+int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls);
 void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);
 /* Like hs_ed25519_ctx_create, but the context's own stream is restricted to partition `part`
  * of `nparts` equal contiguous slices of the GPU's compute units (CU-masked stream), so that
@@ -118,7 +157,8 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
  * return values, bitmap format, modes and alignment rules are identical to the calls above.
  * A key set is immutable and may be used concurrently from any number of threads/streams. */
 typedef struct hs_ed25519_keyset hs_ed25519_keyset;
-int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys);
+int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys);   /* device slot 0 */
+int hs_ed25519_keyset_create_on(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys, int slot);
 void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks);
 size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks);
 size_t hs_ed25519_keyset_bytes(size_t n_keys);   /* HBM footprint of a key set of that size */
@@ -201,20 +241,60 @@ int hs_ed25519_ctx_set_profiling_stride(hs_ed25519_ctx *ctx, size_t every);
 int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, double *verify_ms_sum,
                                 size_t *launches);
 
-/* Cold-path kernel choice: 0 = by batch size (default: fused 4-lanes-per-signature kernel up to
- * 32,768 signatures, two one-lane-per-signature kernels above), 1 = one lane per signature,
- * 2 = two kernels with the quad stage 2, 3 = fused.  (The key-cache path: 0 = two lanes per
- * signature plus a concurrent R-decompression wavefront up to 196,608 signatures, one lane per
- * signature above; 12 / 1 force those two; 3 = four lanes per signature plus the R wavefront;
- * 2 and 10 = the two- and four-lane kernels finishing by inversion instead.)  All variants have the same accept set; this
- * exists for tests and A/B measurements (env HS_ED25519_KERNEL=lane|quad|fused sets it at init).
- * Returns the previous setting. */
-int hs_ed25519_set_kernel(int which);
+/* Per-context kernel choice, for tests and A/B measurements (the host-pointer calls always use
+ * the default): 0 = by batch size (cold: fused 4-lanes-per-signature kernel up to 32,768
+ * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 196,608, the
+ * one-lane kernel above), 1 = the one-lane-per-signature kernels, 3 = the fused / two-lane
+ * kernels at any size.  All have the same accept set.  Returns the previous choice or
+ * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
+ * with -DHS_AB_VARIANTS and are not part of the shipped library.) */
+int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
 
 /* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 const char *hs_ed25519_cached_kernel_for(size_t n);        /* for an n-signature key-cache call */
+
+/* ---- one call over several GPUs (BASELINE configs[3]: a 100,000-validator QC on 8 x MI355X) ----
+ * After hs_ed25519_init_devices with k slots these cut the batch into k contiguous shards of
+ * ceil(n/k) signatures rounded up to a multiple of 64 (hs_ed25519_shard_plan), stage and launch all
+ * shards from the calling thread - the devices run concurrently - and bring the per-shard accept
+ * bitmaps together.  Same arguments, verdicts and bitmap as hs_ed25519_verify_shared / _multi; with
+ * one slot they are equivalent to them.  The exchange of the bitmap slices is selectable:
+ *   HS_ED25519_EXCHANGE_HOST  each device's slice (<= ~1 KB) lands in pinned host memory, the host
+ *                             concatenates (default)
+ *   HS_ED25519_EXCHANGE_RCCL  in-process RCCL all-gather over xGMI (ncclCommInitAll; librccl is
+ *                             dlopen'ed on first use), then one device-to-host copy
+ * hs_ed25519_set_shard_exchange returns the previous setting. */
+#define HS_ED25519_EXCHANGE_HOST 0
+#define HS_ED25519_EXCHANGE_RCCL 1
+int hs_ed25519_shard_plan(size_t n, unsigned nshards, unsigned shard, size_t *lo, size_t *hi);
+int hs_ed25519_set_shard_exchange(int how);
+void hs_ed25519_shard_reset(void);        /* drop RCCL communicators / gather buffers (before shutdown) */
+int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
+                                     uint32_t mode, uint8_t *bitmap);
+int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                                    uint32_t mode, uint8_t *bitmap);
+/* Committee key cache over several GPUs.  A QC is an arbitrary 2f+1 subset of the committee, so the
+ * votes of a call do not line up with any slicing of the key table:
+ *   HS_ED25519_KEYS_REPLICATE  every slot holds the whole table (100,000 validators: 66 GB of 288 GB
+ *                              per GPU); shards stay contiguous
+ *   HS_ED25519_KEYS_BY_OWNER   slot s holds the keys of hs_ed25519_shard_plan(n_keys, k, s); the
+ *                              call routes each vote to its key's owner and scatters the verdict bits
+ *                              back (1/k of the memory; shard sizes follow the votes)
+ * key_idx[i] indexes the WHOLE committee in both placements. */
+#define HS_ED25519_KEYS_REPLICATE 0
+#define HS_ED25519_KEYS_BY_OWNER 1
+typedef struct hs_ed25519_keyset_sharded hs_ed25519_keyset_sharded;
+int hs_ed25519_keyset_sharded_create(hs_ed25519_keyset_sharded **out, const uint8_t *pks, size_t n_keys, int placement);
+void hs_ed25519_keyset_sharded_destroy(hs_ed25519_keyset_sharded *kss);
+size_t hs_ed25519_keyset_sharded_bytes_per_device(const hs_ed25519_keyset_sharded *kss, int slot);
+int hs_ed25519_verify_shared_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uint8_t digest[32],
+                                            const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
+                                            uint8_t *bitmap);
+int hs_ed25519_verify_multi_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uint8_t *digests,
+                                           const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
+                                           uint8_t *bitmap);
 
 #ifdef __cplusplus
 }

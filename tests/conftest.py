@@ -43,11 +43,7 @@ def oracle():
 def emu():
     """The product's device headers compiled for the CPU (tests/emu)."""
     so = os.path.join(ROOT, "tests", "emu", "libhs_emu.so")
-    try:
-        _make(os.path.join(ROOT, "tests", "emu"))
-    except Exception:
-        if not os.path.exists(so):
-            raise
+    _make(os.path.join(ROOT, "tests", "emu"))      # a failed rebuild fails the tests: never run against a stale emulation
     return ctypes.CDLL(so)
 
 
@@ -66,10 +62,17 @@ def torsion_fuzz():
     return json.load(open(os.path.join(GOLDEN, "torsion_fuzz.json")))["vectors"]
 
 
-def oracle_verify_many(orc, digests, stride, pks, sigs, n, mode):
+def oracle_verify_many(orc, digests, stride, pks, sigs, n, mode, threads=None):
     out = ctypes.create_string_buffer(max(1, n))
-    orc.hs_oracle_verify_many(digests, S(32), S(stride), pks, sigs, S(n), mode, out, 1)
+    if threads is None:         # big batches: use the host's cores (the oracle shards by index)
+        threads = 1 if n < 2000 else max(1, min(32, len(os.sched_getaffinity(0))))
+    orc.hs_oracle_verify_many(digests, S(32), S(stride), pks, sigs, S(n), mode, out, threads)
     return out.raw[:n]
+
+
+def oracle_verify_batch(orc, digests, stride, pks, sigs, n, entropy=7):
+    """dalek verify_batch through the oracle's RLC + Straus/Pippenger restatement (1 / 0)."""
+    return orc.hs_oracle_verify_batch(digests, S(32), S(stride), pks, sigs, S(n), ctypes.c_uint64(entropy))
 
 
 def bits(bitmap, n):

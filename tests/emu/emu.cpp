@@ -7,6 +7,7 @@
 #include "../../hotstuff_amd/csrc/verify.h"
 #include "../../hotstuff_amd/csrc/verify_quad.h"
 #include "../../hotstuff_amd/csrc/verify_cached.h"
+#include "../../hotstuff_amd/csrc/rlc.h"
 using namespace hs;
 
 static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
@@ -192,5 +193,66 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
         }
         out[i] = (ok && curve) ? 1 : 0;
     }
+}
+
+// ---- batch random-linear-combination check (rlc.h): every stage on the CPU -----------------------
+// Same functions the kernels of hs_rlc.hip call, with the counting sort and the bucket fold done
+// serially.  Returns 1 when the combination is the identity, 0 otherwise (incl. format failures).
+// segments: how many lanes share a bucket's run (exercises the partial-sum path).
+int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                   const uint8_t *key32, int segments) {
+    if (!n) return 1;
+    const u32 np = (u32)((n + 63) / 64 * 64), NP = 2 * np;
+    std::vector<u32> rec((size_t)(NP + 1) * HS_RLC_REC_WORDS, 0);
+    std::vector<uint8_t> dig((size_t)HS_RLC_WINDOWS * NP, 128);
+    unsigned long long csum[8] = {0};
+    u32 fail = 0;
+    rlc_view v; v.rec = rec.data(); v.dig = dig.data(); v.csum = csum; v.failed = &fail; v.np = np;
+    rlc_key key; memcpy(key.w, key32, 32);
+    for (size_t i = 0; i < n; i++) {
+        u32 pk[8], sig[16], msg[8];
+        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        if (!rlc_point(v, (u32)i, sig)) fail = 1;
+        if (!rlc_point(v, np + (u32)i, pk)) fail = 1;
+        if (!rlc_scalars(v, (u32)i, key, pk, sig, msg)) fail = 1;
+    }
+    rlc_store_identity_record(rec.data() + (size_t)NP * HS_RLC_REC_WORDS);
+    if (fail) return 0;
+    static std::vector<u32> btab;
+    if (btab.empty()) { btab.resize(HS_KS_KEY_WORDS); emu_keyset_build_base(btab.data()); }
+    std::vector<u32> wsum((size_t)HS_RLC_WINDOWS * 40);
+    for (int w = 0; w < HS_RLC_WINDOWS; w++) {
+        std::vector<u32> sorted; std::vector<u32> off(HS_RLC_BUCKETS + 1, 0);
+        std::vector<std::vector<u32>> lists(HS_RLC_BUCKETS);
+        for (u32 p = 0; p < NP; p++) {
+            const int d = (int)dig[(size_t)w * NP + p] - 128;
+            if (d) lists[(d < 0 ? -d : d) - 1].push_back(p | (d < 0 ? HS_RLC_ID_NEG : 0u));
+        }
+        for (int j = 0; j < HS_RLC_BUCKETS; j++) { off[j] = (u32)sorted.size(); sorted.insert(sorted.end(), lists[j].begin(), lists[j].end()); }
+        off[HS_RLC_BUCKETS] = (u32)sorted.size();
+        sorted.push_back(0);
+        ge_p3 bucket[HS_RLC_BUCKETS];
+        for (int j = 0; j < HS_RLC_BUCKETS; j++) {
+            ge_identity(bucket[j]);
+            const u32 lo = off[j], len = off[j + 1] - off[j];
+            for (int sgm = 0; sgm < segments; sgm++) {
+                const u32 a = lo + (u32)((u64)len * sgm / segments), b = lo + (u32)((u64)len * (sgm + 1) / segments);
+                ge_p3 part;
+                rlc_accum_lane(part, sorted.data(), a, b, (b - a) + (sgm & 1), rec.data(), nullptr, NP);   // odd segments run one idle step
+                ge_add_p3(bucket[j], bucket[j], part);
+            }
+        }
+        ge_p3 W;
+        rlc_bucket_fold(W, bucket);
+        for (int i = 0; i < 10; i++) { wsum[40 * w + i] = W.X.v[i]; wsum[40 * w + 10 + i] = W.Y.v[i]; wsum[40 * w + 20 + i] = W.Z.v[i]; wsum[40 * w + 30 + i] = W.T.v[i]; }
+    }
+    const qflags f = rlc_final_quad(wsum.data(), btab.data(), csum);
+    return f.f[0] && f.f[1] && f.f[2] && f.f[3];
+}
+void emu_rlc_coeff(const uint8_t *key32, const uint8_t *k32, const uint8_t *s32, uint32_t index, uint8_t *z16) {
+    rlc_key key; memcpy(key.w, key32, 32);
+    u32 k[8], s[8], z[8]; load_words(k, k32, 8); load_words(s, s32, 8);
+    rlc_coeff(z, key, k, s, index);
+    memcpy(z16, z, 16);
 }
 }

@@ -1,0 +1,74 @@
+"""Bit-exact GPU-vs-C-oracle parity AT BASELINE.json's sizes, ~3 % of the signatures corrupted
+(SURVEY.md 8d mix): n = 6,667 (config 3: N = 10,000), n = 66,667 (config 4: N = 100,000; cold
+two-kernel path and the cached three-wavefront kernel, by size), n = 8,384 (the shard one of 8 GPUs
+gets) and n > 196,608 (the one-lane cached kernel reached by size, not by a selector).  Cold and
+key-cache paths, both modes, through the host-pointer C ABI."""
+import os
+
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+
+pytestmark = pytest.mark.gpu
+CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.init(0, 8192)
+    yield
+
+
+def _mixed(n):
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=8)       # ~3 %
+    assert bad and len(bad) < n // 10
+    return dg, pk, sg, bad
+
+
+@pytest.mark.parametrize("n", [6667, 8384, 66667])
+def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
+    dg, pk, sg, bad = _mixed(n)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)                       # 66,667 keys: 44 GB of tables
+    packed, idx = ks.indices(keys)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+        assert 0 < sum(1 for b in expect if not b) <= len(bad)
+        ok, bm = _lib.verify_packed(dg, pk, sg, n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect, "cold path, mode %d" % mode
+        ok, bm = ks.verify_packed(dg, packed, sg, n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect, "key-cache path, mode %d" % mode
+    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() == ("k_verify_fused" if n <= 32768 else "k_verify")
+    assert _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane2r"
+    ks.close()
+
+
+def test_one_lane_cached_kernel_reached_by_size(oracle):
+    """n = 197,632 > 196,608: hs_ed25519_verify_shared_cached dispatches k_verify_cached_lane by size.
+    1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted individually."""
+    base = 1024
+    dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
+    reps = 193
+    n = base * reps
+    assert n > 196608 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane"
+    pk_t, sg_t = pk * reps, sg * reps
+    dg2, pk_t, sg_t, bad = synth.corrupt(dg, pk_t, sg_t, n, True, rate_byte=8)
+    keys = [pk[32 * i:32 * i + 32] for i in range(base)]
+    ks = _lib.KeySet(keys)
+    import struct
+    # a corrupted key byte makes the key unknown to the set: index outside it, rejected like the cold path rejects it
+    idx = [ks.index.get(pk_t[32 * i:32 * i + 32], _lib.KeySet.UNKNOWN) for i in range(n)]
+    packed = struct.pack("<%dI" % n, *idx)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        expect = bytearray(oracle_verify_many(oracle, dg2, 0, pk_t, sg_t, n, mode))
+        for i in range(n):
+            if idx[i] == _lib.KeySet.UNKNOWN:
+                expect[i] = 0                    # not a committee member (the oracle may accept a flipped key bit by chance: never here)
+        ok, bm = ks.verify_packed(dg2, packed, sg_t, n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == bytes(expect)
+    ks.close()

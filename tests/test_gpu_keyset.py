@@ -7,6 +7,7 @@ import torch
 
 import synth
 from conftest import bits, oracle_verify_many
+from gpu_helpers import DeviceRunner
 from hotstuff_amd import _lib
 from hotstuff_amd.crypto import Digest, PublicKey, Signature
 from hotstuff_amd.messages import QC, TC, Committee, InvalidSignature
@@ -175,71 +176,63 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     ks = _lib.KeySet([bytes(pks[32 * i:32 * i + 32]) for i in range(n)])
     ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs), keyset=ks)
     assert not ok and bits(bm, n) == expect
-    # the >16,384 two-kernel path hashes in k_prepare
-    old = _lib.set_kernel(_lib.KERNEL_LANE)
-    try:
-        ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs))
-        assert not ok and bits(bm, n) == expect
-    finally:
-        _lib.set_kernel(old)
+    # the two-kernel path (n > 32,768 by size) and the one-lane cached kernel (n > 196,608 by size), forced per context
+    r = DeviceRunner(n, kernel=_lib.KERNEL_LANE)
+    assert r.tc_bits(rnd, hq, bytes(pks), bytes(sigs)) == expect
+    keys = [bytes(pks[32 * i:32 * i + 32]) for i in range(n)]
+    assert r.tc_bits(rnd, hq, None, bytes(sigs), keyset=ks, keys=keys) == expect
+    r.close()
     ks.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED, "cached"])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, "cached-lane", "cached-lane2r"])
 def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
-    """160 randomized torsion-mix signatures labelled by the big-int oracle, through every
-    cold kernel variant and the key-cache path, both modes."""
+    """160 randomized torsion-mix signatures labelled by the big-int oracle, through both cold
+    kernels and both key-cache kernels (forced per context), both modes."""
     vec = torsion_fuzz
     n = len(vec)
     dg = b"".join(H(v["msg"]) for v in vec)
     keys = [H(v["pk"]) for v in vec]
     sg = b"".join(H(v["sig"]) for v in vec)
-    if kernel == "cached":
+    if isinstance(kernel, str):
         ks = _lib.KeySet(keys)
-        strict = cached_bits(ks, dg, keys, sg, n, _lib.STRICT, False)
-        batch = cached_bits(ks, dg, keys, sg, n, _lib.BATCH, False)
+        r = DeviceRunner(n, kernel=_lib.KERNEL_LANE if kernel == "cached-lane" else _lib.KERNEL_FUSED)
+        strict = r.bits(dg, None, sg, n, _lib.STRICT, False, keyset=ks, keys=keys)
+        batch = r.bits(dg, None, sg, n, _lib.BATCH, False, keyset=ks, keys=keys)
+        r.close()
         ks.close()
     else:
-        old = _lib.set_kernel(kernel)
-        try:
-            _, bm = _lib.verify_packed(dg, b"".join(keys), sg, n, _lib.STRICT, shared=False, want_bitmap=True)
-            strict = bits(bm, n)
-            _, bm = _lib.verify_packed(dg, b"".join(keys), sg, n, _lib.BATCH, shared=False, want_bitmap=True)
-            batch = bits(bm, n)
-        finally:
-            _lib.set_kernel(old)
+        r = DeviceRunner(n, kernel=kernel)
+        strict = r.bits(dg, b"".join(keys), sg, n, _lib.STRICT, False)
+        batch = r.bits(dg, b"".join(keys), sg, n, _lib.BATCH, False)
+        r.close()
     assert [bool(b) for b in strict] == [v["strict"] for v in vec]
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED, _lib.KERNEL_CACHED_SINGLE_ROLE,
-                                    _lib.KERNEL_CACHED_LANE2_R])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED])
 def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
     """The default cached kernel up to 196,608 signatures is the three-wavefront one (two lanes per
-    signature + concurrent R decompression).  Force every form - one lane per signature (the
-    default above that), two lanes finishing by inversion, four lanes with the R wavefront or
-    finishing by inversion, and the default itself - on small inputs: edge vectors in both modes
-    and a corrupted QC vs the oracle."""
-    old = _lib.set_kernel(kernel)
-    try:
-        n = len(edge_vectors)
-        keys = [H(v["pk"]) for v in edge_vectors]
-        ks = _lib.KeySet(keys)
-        dg = b"".join(H(v["msg"]) for v in edge_vectors)
-        sg = b"".join(H(v["sig"]) for v in edge_vectors)
-        assert [bool(b) for b in cached_bits(ks, dg, keys, sg, n, _lib.STRICT, False)] == [v["strict"] for v in edge_vectors]
-        assert [bool(b) for b in cached_bits(ks, dg, keys, sg, n, _lib.BATCH, False)] == [v["cofactorless"] for v in edge_vectors]
-        ks.close()
-        n = 700
-        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
-        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
-        keys = [pk[32 * i:32 * i + 32] for i in range(n)]
-        ks = _lib.KeySet(keys)
-        for mode in (_lib.BATCH, _lib.STRICT):
-            assert cached_bits(ks, dg, keys, sg, n, mode, True) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
-        ks.close()
-    finally:
-        _lib.set_kernel(old)
+    signature + concurrent R decompression); above, one lane per signature.  Force each on small
+    inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
+    r = DeviceRunner(1024, kernel=kernel)
+    n = len(edge_vectors)
+    keys = [H(v["pk"]) for v in edge_vectors]
+    ks = _lib.KeySet(keys)
+    dg = b"".join(H(v["msg"]) for v in edge_vectors)
+    sg = b"".join(H(v["sig"]) for v in edge_vectors)
+    assert [bool(b) for b in r.bits(dg, None, sg, n, _lib.STRICT, False, keyset=ks, keys=keys)] == [v["strict"] for v in edge_vectors]
+    assert [bool(b) for b in r.bits(dg, None, sg, n, _lib.BATCH, False, keyset=ks, keys=keys)] == [v["cofactorless"] for v in edge_vectors]
+    ks.close()
+    n = 700
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        assert r.bits(dg, None, sg, n, mode, True, keyset=ks, keys=keys) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+    ks.close()
+    r.close()
 
 
 def test_cached_large_qc_takes_the_two_lane_form():

@@ -11,6 +11,7 @@ import torch
 
 import synth
 from conftest import bits, oracle_verify_many
+from gpu_helpers import DeviceRunner
 from hotstuff_amd import _lib
 from hotstuff_amd.crypto import CryptoError, Digest, PublicKey, Signature
 from hotstuff_amd.messages import QC, TC, Committee, InvalidSignature
@@ -249,26 +250,24 @@ def test_single_gpu_sharded_path_over_rccl():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_QUAD, _lib.KERNEL_FUSED])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED])
 def test_every_kernel_variant_has_the_same_accept_set(oracle, edge_vectors, kernel):
-    """The three cold-path variants (one lane per signature; quad stage 2; fused quad) are
-    selected by batch size in production; force each one over the edge vectors and a corrupted
-    batch so the default test run covers all of them."""
-    old = _lib.set_kernel(kernel)
-    try:
-        n = len(edge_vectors)
-        dg = b"".join(H(v["msg"]) for v in edge_vectors)
-        pk = b"".join(H(v["pk"]) for v in edge_vectors)
-        sg = b"".join(H(v["sig"]) for v in edge_vectors)
-        assert [bool(b) for b in gpu_bits(dg, pk, sg, n, _lib.STRICT, False)] == [v["strict"] for v in edge_vectors]
-        assert [bool(b) for b in gpu_bits(dg, pk, sg, n, _lib.BATCH, False)] == [v["cofactorless"] for v in edge_vectors]
-        n = 333
-        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
-        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
-        for mode in (_lib.BATCH, _lib.STRICT):
-            assert gpu_bits(dg, pk, sg, n, mode, True) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
-    finally:
-        _lib.set_kernel(old)
+    """The two cold-path forms (fused four-lanes-per-signature kernel; k_prepare + one lane per
+    signature) are selected by batch size in production; force each one (per context) over the
+    edge vectors and a corrupted batch so the default test run covers both at small sizes too."""
+    r = DeviceRunner(1024, kernel=kernel)
+    n = len(edge_vectors)
+    dg = b"".join(H(v["msg"]) for v in edge_vectors)
+    pk = b"".join(H(v["pk"]) for v in edge_vectors)
+    sg = b"".join(H(v["sig"]) for v in edge_vectors)
+    assert [bool(b) for b in r.bits(dg, pk, sg, n, _lib.STRICT, False)] == [v["strict"] for v in edge_vectors]
+    assert [bool(b) for b in r.bits(dg, pk, sg, n, _lib.BATCH, False)] == [v["cofactorless"] for v in edge_vectors]
+    n = 333
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        assert r.bits(dg, pk, sg, n, mode, True) == oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+    r.close()
 
 
 def test_large_batch_takes_the_two_kernel_path(oracle):

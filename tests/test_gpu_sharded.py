@@ -1,0 +1,103 @@
+"""One call fanned out over several device slots behind the C ABI (hs_shard.hip).  The GPU boxes have
+one GPU, so the slots are virtual devices on it (hs_ed25519_init_devices([0, 0, 0])): every shard
+still has its own contexts, streams, staging and key sets, and the fan-out / bitmap merge / key
+routing run exactly as they would over three GPUs.  The RCCL exchange is exercised with one slot
+(RCCL refuses the same GPU twice in a communicator)."""
+import os
+import struct
+
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+
+pytestmark = pytest.mark.gpu
+CACHE = os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")
+
+
+@pytest.fixture()
+def three_slots():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.shutdown()
+    _lib.init_devices([0, 0, 0], 8192)
+    assert _lib.device_count() == 3
+    yield
+    _lib.shutdown()
+    _lib.init(0, 8192)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 200, 6667])
+def test_sharded_cold_equals_oracle(oracle, three_slots, n):
+    """ragged shards (n = 200 -> 128 + 72 + 0), an empty tail shard, single-word shards"""
+    for shared in (True, False):
+        dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.STRICT, shared, want_bitmap=True)
+        assert ok and all(bits(bm, n))
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)
+        for mode in (_lib.BATCH, _lib.STRICT):
+            expect = oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, mode)
+            ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, mode, shared, want_bitmap=True)
+            assert ok == all(expect) and bits(bm, n) == expect
+            ok2, _ = _lib.verify_packed_sharded(dg, pk, sg, n, mode, shared)      # verdict without a bitmap
+            assert ok2 == ok
+
+
+@pytest.mark.parametrize("placement", [_lib.KEYS_REPLICATE, _lib.KEYS_BY_OWNER])
+def test_sharded_key_cache_arbitrary_vote_subset(oracle, three_slots, placement):
+    """A QC is an arbitrary 2f+1 subset of the committee: votes in a scrambled order that lines up
+    with no slicing of the key table, some keys unknown, some signatures bad."""
+    committee = 600
+    dg, pk, sg = synth.make_batch(committee, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(committee)]
+    kss = _lib.ShardedKeySet(keys, placement)
+    per_dev = [kss.bytes_per_device(s) for s in range(3)]
+    if placement == _lib.KEYS_REPLICATE:
+        assert per_dev == [_lib.lib().hs_ed25519_keyset_bytes(committee)] * 3
+    else:
+        assert sum(per_dev) == _lib.lib().hs_ed25519_keyset_bytes(committee) and all(per_dev)
+    order = sorted(range(committee), key=lambda i: (i * 7919) % committee)[:401]     # 2f+1 of 600, scrambled
+    vsg = bytearray(b"".join(sg[64 * i:64 * i + 64] for i in order))
+    vpk = b"".join(keys[i] for i in order)
+    idx = list(order)
+    vsg[64 * 5 + 40] ^= 2
+    vsg[64 * 400 + 3] ^= 1
+    idx[17] = 0xFFFFFFFF                           # not a committee member
+    idx[250] = committee + 5
+    packed = struct.pack("<%dI" % len(idx), *idx)
+    n = len(idx)
+    for mode in (_lib.BATCH, _lib.STRICT, _lib.BATCH_RLC):
+        expect = bytearray(oracle_verify_many(oracle, dg, 0, vpk, bytes(vsg), n, 1 if mode == _lib.STRICT else 0))
+        expect[17] = expect[250] = 0
+        ok, bm = kss.verify_packed(dg, packed, bytes(vsg), n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == bytes(expect)
+    good = [i for i in range(n) if expect[i]]
+    ok, bm = kss.verify_packed(dg, struct.pack("<%dI" % len(good), *[idx[i] for i in good]),
+                               b"".join(bytes(vsg[64 * i:64 * i + 64]) for i in good), len(good), _lib.BATCH, shared=True,
+                               want_bitmap=True)
+    assert ok and all(bits(bm, len(good)))
+    kss.close()
+
+
+def test_rccl_exchange_one_slot(oracle):
+    """In-process RCCL all-gather (ncclCommInitAll over the slots' GPUs) - with the one GPU here a
+    one-rank communicator: the collective, the gather buffer and the read-back are all on the path."""
+    _lib.shutdown()
+    _lib.init(0, 8192)
+    old = _lib.lib().hs_ed25519_set_shard_exchange(_lib.EXCHANGE_RCCL)
+    try:
+        n = 700
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=20)
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH, True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect
+    finally:
+        _lib.lib().hs_ed25519_set_shard_exchange(old)
+        _lib.lib().hs_ed25519_shard_reset()
+
+
+def test_reinit_with_another_device_list_is_refused(three_slots):
+    rc = _lib.lib().hs_ed25519_init(0, 1024)
+    assert rc == -3 and "different device list" in _lib.last_error()

@@ -88,3 +88,46 @@ def test_verified_qc_cache_collapses_a_timeout_storm():
     cache.verify(_StubQC(4), None)          # evicts the oldest fingerprint
     cache.verify(qc, None)
     assert qc.calls == 2
+
+
+def test_forged_votes_cannot_lock_out_an_authority(oracle):
+    """anyone can send a garbage-signature vote naming authority X.  The reference
+    verifies first and only then marks X used (core.rs:210, aggregator.rs:79-82), so the forgery is
+    dropped and X's genuine vote still counts - while the forgery is pending AND after it was dropped."""
+    votes = make_votes(4)
+    committee = Committee({v.author: 1 for v in votes})          # N = 4 -> quorum 3
+    ing = VoteIngest(committee, verify_fn=oracle_fn(oracle))
+    forged = [Vote(v.hash, v.round, v.author, Signature(bytes([7]) * 32, bytes(32))) for v in votes]
+    # forgeries for three authorities arrive first: together they "could" form a quorum -> one flush drops all three
+    out = [ing.add_vote(f) for f in forged[:3]]
+    assert out == [None] * 3 and ing.gpu_calls == 1 and len(ing.dropped) == 3 and not ing.used
+    # the genuine votes of the same authorities are still welcome (no AuthorityReuse) ...
+    assert ing.add_vote(votes[0]) is None
+    # ... also while another forgery for that authority is waiting
+    assert ing.add_vote(Vote(votes[0].hash, votes[0].round, votes[1].author, Signature(bytes([9]) * 32, bytes(32)))) is None
+    assert ing.add_vote(votes[1]) is None
+    assert ing.add_vote(votes[1]) is None                         # byte-identical duplicate of a waiting candidate: ignored
+    qc = ing.add_vote(votes[2])
+    assert qc is not None and sorted(a.b for a, _ in qc.votes) == sorted(v.author.b for v in votes[:3])
+    assert len(qc.votes) == 3 and len({a.b for a, _ in qc.votes}) == 3
+    # only now - after a signature from it verified - is the author "used"
+    with pytest.raises(AuthorityReuse):
+        ing.add_vote(forged[0])
+
+
+def test_timeout_genesis_check_compares_hash_and_round_only():
+    """`high_qc != QC::genesis()` uses QC's PartialEq = (hash, round) (messages.rs:217-221): a timeout whose
+    high_qc has hash 0 / round 0 skips the QC verification even when it carries votes."""
+    from hotstuff_amd.ingest import Timeout
+    from hotstuff_amd.messages import QC
+
+    class _Sig:
+        def verify(self, d, a):
+            return None
+    k = PublicKey(bytes([1]) * 32)
+    committee = Committee({k: 1})
+    qc = QC(Digest(), 0, [(k, Signature())])          # would fail verification if it were looked at
+    Timeout(qc, 3, k, _Sig()).verify(committee)        # must not raise
+    qc2 = QC(Digest(bytes([1]) * 32), 0, [])
+    with pytest.raises(Exception):
+        Timeout(qc2, 3, k, _Sig()).verify(committee)   # not genesis: verified (and rejected: no quorum)
