@@ -189,7 +189,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
                        nr.data_ptr(), ctx.stream)
             bad = int(nr.item())        # D2H of the verdict word on the same stream = end of the call
             dt = time.perf_counter() - t0
-            assert bad == 0
+            assert bad == 0, "device-resident QC (cold): %d rejects at call %d" % (bad, i)
             if i >= 20:
                 devt.append(dt)
     full = bm.view(torch.int64)[: n // 64].tolist()
@@ -223,7 +223,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
                               nr.data_ptr(), ctx.stream)
             bad = int(nr.item())
             dt = time.perf_counter() - t0
-            assert bad == 0
+            assert bad == 0, "device-resident QC (key cache): %d rejects at call %d" % (bad, i)
             if i >= 20:
                 devc.append(dt)
     ks_bytes = ks.hbm_bytes()
@@ -525,7 +525,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="signatures per batch (one verify call)")
     ap.add_argument("--batches-per-step", type=int, default=1024,
-                    help="independent verify calls per step per GPU (a step = this many batches)")
+                    help="independent 1,024-tuple batches per step per GPU")
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "4")),
+                    help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
     ap.add_argument("--no-cpu", action="store_true")
@@ -593,23 +595,34 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
     bm_bytes = 8 * ((n + 63) // 64)
-    bitmaps = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)]
-    nrej = torch.zeros(ns, dtype=torch.int32, device=dev)
+    K = max(1, min(16, args.batches_per_launch))
+    B = (B + K - 1) // K * K               # whole launches
+    bitmaps = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns * K)]
+    nrej = torch.zeros(ns * K, dtype=torch.int32, device=dev)
 
     # raw addresses once, outside the timed loop (the step itself is one C-ABI call)
     p_in = [tuple(x.data_ptr() for x in d) for d in d_in]
     p_dg, p_pk, p_sg = p_in[0]
     p_bm = [b.data_ptr() for b in bitmaps]
-    p_nr = [nrej[j:].data_ptr() for j in range(ns)]
+    p_nr = [nrej[j:].data_ptr() for j in range(ns * K)]
     p_st = [s.cuda_stream for s in streams]
-    fn = _lib.lib().hs_ed25519_verify_device
-    calls = [(ctxs[j]._h, p_in[j][0], stride, p_in[j][1], p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j]) for j in range(ns)]
+    # context j verifies K independent batches per launch: its own tuples and its neighbours' (K distinct batches,
+    # each with its own bitmap and reject counter)
+    lists = [_lib.batch_array([(p_in[(j + k) % ns][0], stride, p_in[(j + k) % ns][1], p_in[(j + k) % ns][2], n, mode,
+                                p_bm[j * K + k], p_nr[j * K + k]) for k in range(K)]) for j in range(ns)]
+    if K == 1:
+        fn = _lib.lib().hs_ed25519_verify_device
+        calls = [(ctxs[j]._h, p_in[j][0], stride, p_in[j][1], p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j]) for j in range(ns)]
+    else:
+        fn = _lib.lib().hs_ed25519_verify_device_batches
+        calls = [(ctxs[j]._h, ctypes.cast(lists[j], ctypes.c_void_p), K, p_st[j]) for j in range(ns)]
+    launches_per_step = B // K
 
     def step(i):
-        """one pass over the step's input set: B independent 1,024-tuple verify calls, round-robin over the contexts"""
-        for b in range(B):
+        """one pass over the step's input set: B independent 1,024-tuple batches, K per launch, round-robin over the contexts"""
+        for b in range(launches_per_step):
             if fn(*calls[b % ns]) != 0:
-                raise RuntimeError("hs_ed25519_verify_device failed: " + _lib.last_error())
+                raise RuntimeError("verify launch failed: " + _lib.last_error())
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -622,7 +635,7 @@ def main():
     fence()
     # HIP events attached to the kernel dispatches themselves (hipExtLaunchKernel start/stop), on the
     # launch streams, for every `--event-stride`-th call of each context (default: every call)
-    per_ctx = (args.steps * B + ns - 1) // ns
+    per_ctx = (args.steps * launches_per_step + ns - 1) // ns
     for c in ctxs:
         c.set_profiling(0 if args.no_events else max(1, per_ctx // args.event_stride + 1), every=args.event_stride)
     nrej.zero_()
@@ -668,6 +681,8 @@ def main():
         cfn = _lib.lib().hs_ed25519_verify_device_cached
         ccalls = [(ctxs[j]._h, ks.handle, p_in[j][0], stride, d_ki[j * n:].data_ptr(), p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j])
                   for j in range(ns)]
+        for c in ctxs:
+            c.set_profiling(max(1, (args.steps * B + ns - 1) // ns // args.event_stride + 1), every=args.event_stride)
 
         def cstep(i):
             for b in range(B):
@@ -753,14 +768,15 @@ def main():
             cached = {"error": "%s: %s" % (type(e).__name__, e)}
 
     traffic = traffic_src = None
+    kernel_name = "k_verify_fused_batches" if (K > 1 and n <= 32768) else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
-        kname = _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
+        kname = kernel_name
         for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
             fp = os.path.join(ROOT, "profiles", f)
             if not os.path.exists(fp):
                 continue
             pmc = json.load(open(fp))
-            if pmc.get("signatures_per_launch") == n and kname in pmc["kernels"]:
+            if pmc.get("signatures_per_launch") == n * K and kname in pmc["kernels"]:
                 traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per launch)" % f
                 break
@@ -785,7 +801,7 @@ def main():
     if rank == 0:
         total = world * n * B * args.steps
         value = total / elapsed
-        algo = (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) * n
+        algo = (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) * n * K       # one launch of the dominant kernel covers K batches
         achieved = algo / (avg_verify_ms * 1e-3) / 1e9 if avg_verify_ms > 0 else 0.0
         out = {
             "metric": "Ed25519 verifies/sec (whole node)",
@@ -798,17 +814,17 @@ def main():
             "config": {
                 "workload": ("QC::verify shape: batches of %d signatures over one digest, batch semantics; " % n if shared else
                              "BASELINE configs[1]: batches of %d distinct (digest, pk, sig) tuples, strict semantics, HBM-resident; " % n)
-                            + "one step = one pass over %d such batches per GPU (%d verifications), issued as %d independent "
-                              "hs_ed25519_verify_device calls round-robin over %d CU-partitioned stream contexts"
-                              % (B, B * n, B, ns),
+                            + "one step = one pass over %d such batches per GPU (%d verifications), %d independent batches per "
+                              "launch (%s), launches round-robin over %d CU-partitioned stream contexts"
+                              % (B, B * n, K, "hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device", ns),
                 "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
                 "distinct_tuples_per_gpu": ns * n, "streams": ns, "cu_partitions": args.partitions,
-                "timed_region_s": round(elapsed, 4), "launches_in_timed_region_per_gpu": B * args.steps,
+                "timed_region_s": round(elapsed, 4), "batches_per_launch": K, "launches_in_timed_region_per_gpu": launches_per_step * args.steps,
                 "exchange": ("none on this workload: every rank verifies its own independent batches (SURVEY.md 8e); "
                              "`sharded_committee` / `sharded_c_abi` are the workloads with the exchange step") if exchange else "none (1 GPU)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
+                "bound": "hbm", "kernel": kernel_name,
                 "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo,
@@ -822,7 +838,7 @@ def main():
                            "k_verify": round(avg_verify_ms, 4)},
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
-        kname = out["roofline"]["kernel"]
+        kname = "k_verify_fused" if kernel_name == "k_verify_fused_batches" else kernel_name
         if kname in MAD_PER_VERIFY:
             mad_s = value / world * MAD_PER_VERIFY[kname]
             out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,

@@ -84,6 +84,8 @@ def lib():
                 l.hs_ed25519_verify_device_tc.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_tc_cached.argtypes = [vp, vp, u64, vp, vp, vp, sz, vp, vp, vp]
                 l.hs_ed25519_verify_device_tc_cached.restype = ctypes.c_int
+                l.hs_ed25519_verify_device_batches.argtypes = [vp, vp, sz, vp]
+                l.hs_ed25519_verify_device_batches.restype = ctypes.c_int
                 l.hs_ed25519_ctx_set_kernel.argtypes = [vp, ctypes.c_int]
                 l.hs_ed25519_ctx_set_kernel.restype = ctypes.c_int
                 l.hs_ed25519_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), sz, sz]
@@ -341,6 +343,21 @@ def verify_tc_packed(round_, hq_rounds, pks, sigs, keyset=None):
     return rc == 1, bytes(bm)
 
 
+class Batch(ctypes.Structure):
+    """hs_ed25519_batch: one entry of hs_ed25519_verify_device_batches (device pointers)."""
+    _fields_ = [("d_digests", ctypes.c_void_p), ("digest_stride", ctypes.c_size_t), ("d_pks", ctypes.c_void_p),
+                ("d_sigs", ctypes.c_void_p), ("n", ctypes.c_size_t), ("mode", ctypes.c_uint32),
+                ("d_bitmap", ctypes.c_void_p), ("d_nreject", ctypes.c_void_p)]
+
+
+def batch_array(entries):
+    """[(d_digests, stride, d_pks, d_sigs, n, mode, d_bitmap, d_nreject), ...] -> ctypes array of Batch"""
+    arr = (Batch * len(entries))()
+    for a, e in zip(arr, entries):
+        a.d_digests, a.digest_stride, a.d_pks, a.d_sigs, a.n, a.mode, a.d_bitmap, a.d_nreject = e
+    return arr
+
+
 class KeySet:
     """hs_ed25519_keyset: the committee key cache.  Built once per epoch from the committee's
     public keys (consensus/src/config.rs:39-43); per-key window tables live in HBM and every
@@ -427,6 +444,11 @@ class DeviceContext:
         check(lib().hs_ed25519_verify_device(self._h, d_digests, digest_stride, d_pks, d_sigs, int(n), mode,
                                              d_bitmap, d_nreject or None, stream or None),
               "hs_ed25519_verify_device")
+
+    def verify_batches(self, batches, stream=0):
+        """hs_ed25519_verify_device_batches: `batches` = a ctypes array from batch_array()."""
+        check(lib().hs_ed25519_verify_device_batches(self._h, ctypes.cast(batches, ctypes.c_void_p), len(batches), stream or None),
+              "hs_ed25519_verify_device_batches")
 
     def verify_cached(self, keyset, d_digests, digest_stride, d_key_idx, d_sigs, n, mode, d_bitmap, d_nreject=0, stream=0):
         check(lib().hs_ed25519_verify_device_cached(self._h, keyset.handle, d_digests, digest_stride, d_key_idx, d_sigs,

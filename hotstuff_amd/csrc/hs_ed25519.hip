@@ -4,6 +4,7 @@
 //
 // Device side (one wavefront = 64 lanes per role; DESIGN.md section 5 has the table):
 //   cold path   k_verify_fused            n <= 32,768: four lanes per signature, one launch
+//               k_verify_fused_batches    the same for up to 16 independent small batches per grid
 //               k_prepare + k_verify      above: one lane per point / signature, SoA workspace
 //   key cache   k_keyset_decompress, k_keyset_build   registration (tables in HBM)
 //               k_verify_cached_lane2r    default up to 196,608: two lanes per signature + a
@@ -123,18 +124,18 @@ k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap
 #endif  // HS_AB_VARIANTS
 
 // Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
-__global__ void __launch_bounds__(64, 3)
-k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
-               unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+// `block` = this wavefront's index within its batch (16 signatures per wavefront).
+__device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
+                                            const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
+                                            u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     if (skip && *skip) {
-        const u32 first = blockIdx.x * 16;
+        const u32 first = block * 16;
         const u32 here = first < n ? min(16u, n - first) : 0u;
-        if (threadIdx.x == 0) bitmap16[blockIdx.x] = (unsigned short)((1u << here) - 1);
+        if (threadIdx.x == 0) bitmap16[block] = (unsigned short)((1u << here) - 1);
         return;
     }
     qtab atab; atab.lds = s_atab;
-    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const u32 i = block * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
     u32 msg[8];
@@ -147,14 +148,37 @@ k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict_
     m = (m | (m >> 12)) & 0x000000ff000000ffull;
     m = (m | (m >> 24)) & 0xffffull;
     if (threadIdx.x == 0) {
-        bitmap16[blockIdx.x] = (unsigned short)m;
+        bitmap16[block] = (unsigned short)m;
         if (nreject) {
-            const u32 first = blockIdx.x * 16;
+            const u32 first = block * 16;
             const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
             const u32 bad = sigs_here - (u32)__popcll(m);
             if (bad) atomicAdd(nreject, bad);
         }
     }
+}
+__global__ void __launch_bounds__(64, 2)
+k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+               unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+    fused_block(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
+}
+// Several independent small batches in ONE grid (hs_ed25519_verify_device_batches): a 1,024-signature
+// batch is only 64 wavefronts - one per SIMD of the 16 CUs its stream is confined to - and a lone
+// wavefront issues at about half the rate two co-resident ones reach (profiles/r1_ubench_valu.txt).
+// Back-to-back launches of one stream do not overlap and more than 16 streams collapse
+// (profiles/r1_stream_sweep.txt), so the way to more wavefronts per SIMD is more batches per launch.
+#define HS_MAX_BATCHES_PER_LAUNCH 16
+struct fused_batch { msg_src msgs; const u32 *pks, *sigs; unsigned short *bitmap16; u32 *nreject; u32 n, mode, first_block, pad; };
+struct fused_batch_list { fused_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+__global__ void __launch_bounds__(64, 2)
+k_verify_fused_batches(fused_batch_list L) {
+    __shared__ u32 s_atab[HS_QTAB_WORDS];
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const fused_batch &B = L.b[k];
+    fused_block(s_atab, blockIdx.x - B.first_block, B.msgs, B.pks, B.sigs, B.n, B.mode, B.bitmap16, B.nreject, nullptr);
 }
 
 // ---- committee key cache (verify_cached.h) -------------------------------------------------
@@ -469,6 +493,7 @@ struct dev_state {
     u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
     std::vector<hs_ed25519_ctx *> free_ctx;  // the host API's pool of stream contexts on this device
     int live = 0;
+    unsigned cus = 0;                        // compute units (for the pool's CU-partitioned streams)
 };
 static std::mutex g_mu;
 static std::condition_variable g_cv;
@@ -483,6 +508,12 @@ static const int kMaxPool = 16;              // contexts per device slot (one HI
 static const size_t kCachedLane1Min = 196608;
 static const size_t kZeroCopyMax = 16384;    // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
+// Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel = one per SIMD of 16 CUs) run
+// on their pool context's CU-partitioned stream: concurrent callers then occupy disjoint sixteenths of the chip
+// instead of being stacked onto the same CUs by the dispatcher (13.5 -> M verifies/s end to end from 16 host
+// threads, bench.py `end_to_end`); one caller alone loses nothing, its batch is one wavefront per SIMD either way.
+static const size_t kPartitionMaxBatch = 1024;
+static const unsigned kPoolPartitions = 16;
 
 int hs::dev_slots() { return g_init.load() ? (int)g_devs.size() : 0; }
 int hs::dev_ordinal(int slot) { return (slot >= 0 && slot < hs::dev_slots()) ? g_devs[slot].ordinal : -1; }
@@ -562,6 +593,7 @@ extern "C" int hs_ed25519_ctx_device(const hs_ed25519_ctx *c) { return c ? c->de
 extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream_part) { (void)hipStreamSynchronize(c->stream_part); (void)hipStreamDestroy(c->stream_part); }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
@@ -616,6 +648,9 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
         HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
         HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hipDeviceProp_t prop;
+        HS_HIP(hipGetDeviceProperties(&prop, ordinals[i]), "hipGetDeviceProperties");
+        devs[i].cus = (unsigned)prop.multiProcessorCount;
     }
     HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
     g_devs.swap(devs);
@@ -762,6 +797,42 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
         return enqueue_cold(ctx, m, d_pks, d_sigs, n, HS_ED25519_BATCH, d_bitmap, d_nreject, stream, d_ok);
     }
     return enqueue_cold(ctx, m, d_pks, d_sigs, n, mode, d_bitmap, d_nreject, stream);
+}
+// Several independent small batches (each <= 32,768 signatures, BATCH or STRICT) in one launch per 16 of them.
+extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, void *stream) {
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches: null context / list");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    size_t done = 0;
+    while (done < count) {
+        fused_batch_list L;
+        L.count = 0;
+        u32 blocks = 0;
+        for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
+            const hs_ed25519_batch &b = batches[done];
+            if (b.n == 0) continue;
+            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches: mode must be BATCH / STRICT and n <= 32,768");
+            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches: null pointer");
+            if (misaligned(b.d_pks, 16) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
+                return fail(HS_ED25519_E_ARG, "verify_device_batches: misaligned pointer");
+            fused_batch &f = L.b[L.count++];
+            int rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
+            if (rc) return rc;
+            f.pks = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap16 = (unsigned short *)b.d_bitmap;
+            f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode; f.first_block = blocks; f.pad = 0;
+            blocks += (u32)(round_up(b.n, 64) / 16);
+        }
+        if (!L.count) continue;
+        const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+        const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+        hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
+        if (ev) ctx->ev_mid[slot] = 0;
+        void *a[] = { &L };
+        HS_HIP(launch1((const void *)k_verify_fused_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_fused_batches");
+    }
+    return 0;
 }
 // TC::verify shape with the per-vote digests built on the device (strict semantics)
 extern "C" int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, const uint64_t *d_high_qc_rounds,
@@ -993,10 +1064,20 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot) {
         if (d.live < kMaxPool) { d.live++; break; }
         g_cv.wait(lk);
     }
+    const unsigned part = (unsigned)(g_devs[slot].live - 1) % kPoolPartitions, cus = g_devs[slot].cus;
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
     int rc = hs_ed25519_ctx_create_on(&c, 64, slot);
     if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live--; g_cv.notify_one(); return rc; }
+    if (cus >= kPoolPartitions) {      // the partitioned twin of the context's stream; without it small calls just use the full one
+        std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+        const unsigned lo = cus * part / kPoolPartitions, hi = cus * (part + 1) / kPoolPartitions;
+        for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
+        if (hipExtStreamCreateWithCUMask(&c->stream_part, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            c->stream_part = nullptr;
+        }
+    }
     *out = c;
     return 0;
 }
@@ -1030,16 +1111,17 @@ int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const 
     memcpy(c->h_in + off_k, keys, key_bytes);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
     job.zc = n <= kZeroCopyMax;
+    job.st = (n <= kPartitionMaxBatch && c->stream_part) ? c->stream_part : c->stream;
     uint8_t *in = job.zc ? c->h_in : c->d_in, *outp = job.zc ? c->h_out : c->d_out;
     if (job.zc) memset(c->h_out, 0, bitmap_bytes(n));
     else {
-        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
-        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), job.st), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, job.st), "H2D");
     }
-    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, c->stream);
-    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, c->stream);
+    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, job.st);
+    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, job.st);
     if (rc) return rc;
-    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, job.st), "D2H");
     return 0;
 }
 // returns 1 / 0 / <0; always gives the context back.  bitmap (optional): ceil(n/8) bytes.
@@ -1049,13 +1131,14 @@ int hs::host_finish(host_job &job, uint8_t *bitmap) {
     job.c = nullptr;
     struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
-    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    HS_HIP(hipStreamSynchronize(job.st ? job.st : c->stream), "stream sync");
     if (bitmap) memcpy(bitmap, c->h_out, (job.n + 7) / 8);
     return bitmap_all_ones(c->h_out, job.n) ? 1 : 0;
 }
 void hs::host_abandon(host_job &job) {
     if (!job.c) return;
     (void)hipSetDevice(job.c->device);
+    if (job.st) (void)hipStreamSynchronize(job.st);
     (void)hipStreamSynchronize(job.c->stream);
     pool_put(job.c);
     job.c = nullptr;
@@ -1263,7 +1346,10 @@ extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_
             if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
                 hipGraphNode_t bad = nullptr;
                 hipGraphExecUpdateResult res;
-                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
+                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
+                    (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
+                    (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
+                }
             }
             if (!s.exec) {
                 e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);

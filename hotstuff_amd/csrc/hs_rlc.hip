@@ -9,19 +9,23 @@
 //                   decompress -> 128-byte affine Niels record (one cache line, dwordx4 stores);
 //                   the R lane hashes, draws z_i, z_i h_i and z_i s_i mod L, writes 2 x 32 digit bytes
 //                   [window][point] and adds z_i s_i into eight 64-bit limb sums (atomics, carry-free).
-//   k_rlc_sort      one 1,024-lane workgroup per window: counting sort of the window's points by
-//                   |digit| in LDS (histogram -> offsets -> scatter of (record id | sign)).
-//   k_rlc_accum     one lane per (window, bucket, segment): a wavefront covers 64 consecutive buckets of
-//                   one window and one segment, so its lanes walk runs of similar length; each step gathers
-//                   one whole 128-byte record and does one mixed addition.  Partials go out
-//                   structure-of-arrays so that k_rlc_reduce reads them coalesced.
-//   k_rlc_reduce    two wavefronts per window, one lane per bucket: fold the segments, then
+//   k_rlc_hist / k_rlc_offsets / k_rlc_scatter   counting sort of every window's points by |digit|:
+//                   LDS histograms per (slice, window) workgroup, one lane per window turns them into
+//                   bucket offsets and chunk offsets, then each workgroup reserves its share of every
+//                   bucket's run with one global atomic and scatters (record id | sign) through LDS cursors.
+//   k_rlc_accum     one lane per chunk of <= C consecutive points of ONE bucket (a bucket of length len
+//                   gets ceil(len / C) lanes: the 5-bit top window of the 253-bit scalars puts n / 16
+//                   points into each of 16 buckets - that costs lanes, not time).  Each step gathers one
+//                   whole 128-byte record and does one mixed addition; the wavefront then folds the
+//                   chunks of equal buckets with a segmented suffix scan (shuffles) and stores one
+//                   partial per bucket stretch.
+//   k_rlc_reduce    two wavefronts per window, one lane per bucket: fold the stretch partials, then
 //                   sum_j j * bucket_j WITHOUT the 256-step running sum: a suffix scan across the
 //                   wavefront (6 shuffle + add steps), a butterfly reduction of the suffix sums (6 more)
 //                   and 64 x the upper wavefront's total (6 doublings) - 12 point additions deep.
+//                   A 33rd workgroup computes [-(sum z_i s_i)]B from the base point's window table.
 //   k_rlc_final     one quad: Horner over the 32 window sums (248 doublings, one coordinate per lane,
-//                   DPP glue of verify_quad.h), + [-(sum z_i s_i)]B from the base point's window table,
-//                   identity test -> one flag word.
+//                   DPP glue of verify_quad.h), + the [b]B point, identity test -> one flag word.
 // The per-signature kernels of hs_ed25519.hip then run with that flag as their `skip` word: they leave
 // at once with an all-ones bitmap when the combination held and localise the rejects when it did not.
 #include <hip/hip_runtime.h>
@@ -72,16 +76,22 @@ k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u3
     if (!ok) atomicOr(v.failed, 1u);
 }
 
-// counting sort of one window's points by |digit|
+// ---- counting sort of every window's points by |digit|, in three small launches -------------------
+// grid (G, 32): block (g, w) handles slice g of window w's NP digit bytes
+__device__ __forceinline__ void rlc_slice(u32 &q0, u32 &q1, u32 NP, u32 G) {
+    const u32 words = NP / 4, per = (words + G - 1) / G;
+    q0 = blockIdx.x * per; q1 = min(words, q0 + per);
+}
 __global__ void __launch_bounds__(1024)
-k_rlc_sort(const uint8_t *__restrict__ dig, u32 NP, u32 np, const u32 *__restrict__ key_idx, u32 *__restrict__ sorted,
-           u32 *__restrict__ boff) {
-    __shared__ u32 hist[HS_RLC_BUCKETS + 1], cur[HS_RLC_BUCKETS + 1];
-    const u32 w = blockIdx.x;
+k_rlc_hist(const uint8_t *__restrict__ dig, u32 NP, u32 *__restrict__ ghist) {
+    __shared__ u32 hist[HS_RLC_BUCKETS + 1];
+    const u32 w = blockIdx.y;
     const u32 *d4 = reinterpret_cast<const u32 *>(dig + (size_t)w * NP);
     for (u32 j = threadIdx.x; j <= HS_RLC_BUCKETS; j += 1024) hist[j] = 0;
     __syncthreads();
-    for (u32 q = threadIdx.x; q < NP / 4; q += 1024) {
+    u32 q0, q1;
+    rlc_slice(q0, q1, NP, gridDim.x);
+    for (u32 q = q0 + threadIdx.x; q < q1; q += 1024) {
         const u32 four = d4[q];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -91,14 +101,50 @@ k_rlc_sort(const uint8_t *__restrict__ dig, u32 NP, u32 np, const u32 *__restric
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 acc = 0;
-        for (u32 j = 1; j <= HS_RLC_BUCKETS; j++) { cur[j] = acc; boff[w * (HS_RLC_BUCKETS + 1) + j - 1] = acc; acc += hist[j]; }
-        boff[w * (HS_RLC_BUCKETS + 1) + HS_RLC_BUCKETS] = acc;
+    for (u32 j = 1 + threadIdx.x; j <= HS_RLC_BUCKETS; j += 1024)
+        if (hist[j]) atomicAdd(&ghist[w * (HS_RLC_BUCKETS + 1) + j], hist[j]);
+}
+// one lane per window: bucket offsets, the scatter cursors, and the chunk (lane) offsets of stage 3:
+// bucket j gets ceil(len_j / C) lanes
+__global__ void __launch_bounds__(64)
+k_rlc_offsets(const u32 *__restrict__ ghist, u32 C, u32 *__restrict__ boff, u32 *__restrict__ segoff, u32 *__restrict__ gcur) {
+    const u32 w = threadIdx.x;
+    if (w >= HS_RLC_WINDOWS) return;
+    const u32 base = w * (HS_RLC_BUCKETS + 1);
+    u32 acc = 0, lanes = 0;
+    for (u32 j = 0; j < HS_RLC_BUCKETS; j++) {
+        const u32 len = ghist[base + j + 1];
+        boff[base + j] = acc; gcur[base + j] = acc; segoff[base + j] = lanes;
+        acc += len; lanes += (len + C - 1) / C;
+    }
+    boff[base + HS_RLC_BUCKETS] = acc; segoff[base + HS_RLC_BUCKETS] = lanes;
+}
+__global__ void __launch_bounds__(1024)
+k_rlc_scatter(const uint8_t *__restrict__ dig, u32 NP, u32 np, const u32 *__restrict__ key_idx, u32 nkeys,
+              u32 *__restrict__ gcur, u32 *__restrict__ sorted) {
+    __shared__ u32 hist[HS_RLC_BUCKETS + 1], cur[HS_RLC_BUCKETS + 1];
+    const u32 w = blockIdx.y;
+    const u32 *d4 = reinterpret_cast<const u32 *>(dig + (size_t)w * NP);
+    for (u32 j = threadIdx.x; j <= HS_RLC_BUCKETS; j += 1024) hist[j] = 0;
+    __syncthreads();
+    u32 q0, q1;
+    rlc_slice(q0, q1, NP, gridDim.x);
+    for (u32 q = q0 + threadIdx.x; q < q1; q += 1024) {
+        const u32 four = d4[q];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int dd = (int)((four >> (8 * b)) & 0xff) - 128;
+            const u32 m = (u32)(dd < 0 ? -dd : dd);
+            if (m) atomicAdd(&hist[m], 1u);
+        }
     }
     __syncthreads();
+    // reserve this block's share of every bucket's run with one global atomic per bucket
+    for (u32 j = 1 + threadIdx.x; j <= HS_RLC_BUCKETS; j += 1024)
+        cur[j] = hist[j] ? atomicAdd(&gcur[w * (HS_RLC_BUCKETS + 1) + j - 1], hist[j]) : 0u;
+    __syncthreads();
     u32 *out = sorted + (size_t)w * NP;
-    for (u32 q = threadIdx.x; q < NP / 4; q += 1024) {
+    for (u32 q = q0 + threadIdx.x; q < q1; q += 1024) {
         const u32 four = d4[q];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -106,32 +152,14 @@ k_rlc_sort(const uint8_t *__restrict__ dig, u32 NP, u32 np, const u32 *__restric
             const u32 m = (u32)(dd < 0 ? -dd : dd);
             if (m) {
                 const u32 p = 4 * q + b;
-                const u32 id = (key_idx && p >= np) ? (HS_RLC_ID_CACHED | key_idx[p - np]) : p;
+                u32 id = p;
+                if (key_idx && p >= np) {       // A served from the key set; an unknown key already failed the batch
+                    const u32 ki = key_idx[p - np];
+                    id = ki < nkeys ? (HS_RLC_ID_CACHED | ki) : NP;
+                }
                 out[atomicAdd(&cur[m], 1u)] = id | (dd < 0 ? HS_RLC_ID_NEG : 0u);
             }
         }
-    }
-}
-
-// one lane per (window, bucket, segment); block b -> window b / (2 S), segment, bucket half
-__global__ void __launch_bounds__(64)
-k_rlc_accum(const u32 *__restrict__ sorted, const u32 *__restrict__ boff, const u32 *__restrict__ rec,
-            const u32 *__restrict__ ksn, u32 NP, u32 S, u32 *__restrict__ part) {
-    const u32 w = blockIdx.x / (2 * S), rem = blockIdx.x % (2 * S), s = rem >> 1, half = rem & 1;
-    const u32 j = half * 64 + threadIdx.x;                       // bucket j holds |digit| = j + 1
-    const u32 lo0 = boff[w * (HS_RLC_BUCKETS + 1) + j], hi0 = boff[w * (HS_RLC_BUCKETS + 1) + j + 1];
-    const u32 len = hi0 - lo0;
-    const u32 a = lo0 + (u32)((u64)len * s / S), b = lo0 + (u32)((u64)len * (s + 1) / S);
-    u32 trip = b - a;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) trip = max(trip, (u32)__shfl_xor((int)trip, off, 64));
-    ge_p3 acc;
-    rlc_accum_lane(acc, sorted + (size_t)w * NP, a, b, trip, rec, ksn, NP);
-    u32 *o = part + ((size_t)(w * S + s) * 40) * HS_RLC_BUCKETS + j;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        o[(size_t)i * HS_RLC_BUCKETS] = acc.X.v[i]; o[(size_t)(10 + i) * HS_RLC_BUCKETS] = acc.Y.v[i];
-        o[(size_t)(20 + i) * HS_RLC_BUCKETS] = acc.Z.v[i]; o[(size_t)(30 + i) * HS_RLC_BUCKETS] = acc.T.v[i];
     }
 }
 
@@ -156,44 +184,99 @@ __device__ __forceinline__ void pt_shfl_lane0(ge_p3 &r, const ge_p3 &p) {
         r.Z.v[i] = (u32)__shfl((int)p.Z.v[i], 0, 64); r.T.v[i] = (u32)__shfl((int)p.T.v[i], 0, 64);
     }
 }
+__device__ __forceinline__ void pt_add_if(ge_p3 &v, const ge_p3 &q, bool take) {     // v += take ? q : O, lane-uniform control flow
+    ge_p3 ident, a;
+    ge_identity(ident);
+    fe_select(a.X, ident.X, q.X, take); fe_select(a.Y, ident.Y, q.Y, take);
+    fe_select(a.Z, ident.Z, q.Z, take); fe_select(a.T, ident.T, q.T, take);
+    ge_add_p3(v, v, a);
+}
+__device__ __forceinline__ void pt_load40(ge_p3 &p, const u32 *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+}
+__device__ __forceinline__ void pt_store40(u32 *dst, const ge_p3 &p) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
 
-// segment partials -> bucket sums -> window sum, by wavefront shuffles (rlc_bucket_fold is the
-// serial definition): with V_l = sum_{m >= l} B_m (suffix scan), sum_l (l + 1) B_l = sum_l V_l.
+// Stage 3.  grid (ceil(Lcap / 64), 32): lane l of window w owns chunk l of the window's chunk list (bucket j
+// owns chunks segoff[j] .. segoff[j + 1]); chunks of one bucket sit in consecutive lanes, so the wavefront then
+// folds them with a SEGMENTED suffix scan (6 shuffle + add steps keyed by the bucket) and only the first lane of
+// each bucket's stretch writes a partial: a bucket ends up with one partial per wavefront it spans.
+__global__ void __launch_bounds__(64)
+k_rlc_accum(const u32 *__restrict__ sorted, const u32 *__restrict__ boff, const u32 *__restrict__ segoff,
+            const u32 *__restrict__ rec, const u32 *__restrict__ ksn, u32 NP, u32 C, u32 Lcap, u32 *__restrict__ part) {
+    __shared__ u32 s_seg[HS_RLC_BUCKETS + 1], s_off[HS_RLC_BUCKETS + 1];
+    const u32 w = blockIdx.y, lane = threadIdx.x, l = blockIdx.x * 64 + lane;
+    const u32 base = w * (HS_RLC_BUCKETS + 1);
+    for (u32 j = lane; j <= HS_RLC_BUCKETS; j += 64) { s_seg[j] = segoff[base + j]; s_off[j] = boff[base + j]; }
+    __syncthreads();
+    const u32 total = s_seg[HS_RLC_BUCKETS];
+    if (blockIdx.x * 64 >= total) return;                   // the whole wavefront is past the window's last chunk
+    const bool live = l < total;
+    u32 j = 0;                                               // largest j with s_seg[j] <= l  (binary search, 7 steps)
+#pragma unroll
+    for (u32 step = 64; step >= 1; step >>= 1) { const u32 t = j + step; if (t < HS_RLC_BUCKETS && s_seg[t] <= l) j = t; }
+    u32 a = 0, b = 0;
+    if (live) {
+        a = s_off[j] + (l - s_seg[j]) * C;
+        b = min(a + C, s_off[j + 1]);
+    }
+    ge_p3 V;
+    rlc_accum_lane(V, sorted + (size_t)w * NP, a, b, C, rec, ksn, NP);
+    // segmented suffix scan; idle lanes carry a key of their own
+    const int key = live ? (int)j : -1 - (int)lane;
+#pragma nounroll
+    for (int off = 1; off < 64; off <<= 1) {
+        ge_p3 q;
+        pt_shfl_down(q, V, off);
+        const int kq = __shfl_down(key, off, 64);
+        pt_add_if(V, q, lane + (u32)off < 64 && kq == key);
+    }
+    const int kprev = __shfl_up(key, 1, 64);
+    if (live && (lane == 0 || kprev != key)) pt_store40(part + ((size_t)w * Lcap + l) * 40, V);
+}
+
+// Stage 4.  blocks 0..31: two wavefronts per window, one lane per bucket: fold the bucket's partials (one per
+// wavefront of stage 3 that it spans), then sum_j j * bucket_j WITHOUT the 256-step running sum: with
+// V_l = sum_{m >= l} B_m (suffix scan), sum_l (l + 1) B_l = sum_l V_l (rlc_bucket_fold is the serial definition).
+// block 32: [b]B beside it.
 __global__ void __launch_bounds__(128)
-k_rlc_reduce(const u32 *__restrict__ part, u32 S, u32 *__restrict__ wsum) {
+k_rlc_reduce(const u32 *__restrict__ part, const u32 *__restrict__ segoff, u32 Lcap, const u32 *__restrict__ btab,
+             const unsigned long long *__restrict__ csum, u32 *__restrict__ wsum) {
     __shared__ u32 s_up[40];
     const u32 w = blockIdx.x, j = threadIdx.x, wave = j >> 6, lane = j & 63u;
+    if (w == HS_RLC_WINDOWS) {         // [b]B on one quad: 32 table additions of two vector multiplications each
+        if (j >= 4) return;
+        const qv bb = rlc_b_point_quad(btab, csum);
+        rlc_store_wsum_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS, bb);
+        return;
+    }
     ge_p3 V;
+    ge_identity(V);
     {
-        const u32 *p = part + ((size_t)(w * S) * 40) * HS_RLC_BUCKETS + j;
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            V.X.v[i] = p[(size_t)i * HS_RLC_BUCKETS]; V.Y.v[i] = p[(size_t)(10 + i) * HS_RLC_BUCKETS];
-            V.Z.v[i] = p[(size_t)(20 + i) * HS_RLC_BUCKETS]; V.T.v[i] = p[(size_t)(30 + i) * HS_RLC_BUCKETS];
+        const u32 p0 = segoff[w * (HS_RLC_BUCKETS + 1) + j], end = segoff[w * (HS_RLC_BUCKETS + 1) + j + 1];
+        const u32 *pw = part + (size_t)w * Lcap * 40;
+        if (p0 < end) {
+            pt_load40(V, pw + (size_t)p0 * 40);
+            for (u32 p = (p0 & ~63u) + 64; p < end; p += 64) { ge_p3 q; pt_load40(q, pw + (size_t)p * 40); ge_add_p3(V, V, q); }
         }
     }
-#pragma nounroll
-    for (u32 s = 1; s < S; s++) {
-        const u32 *p = part + ((size_t)(w * S + s) * 40) * HS_RLC_BUCKETS + j;
-        ge_p3 q;
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            q.X.v[i] = p[(size_t)i * HS_RLC_BUCKETS]; q.Y.v[i] = p[(size_t)(10 + i) * HS_RLC_BUCKETS];
-            q.Z.v[i] = p[(size_t)(20 + i) * HS_RLC_BUCKETS]; q.T.v[i] = p[(size_t)(30 + i) * HS_RLC_BUCKETS];
-        }
-        ge_add_p3(V, V, q);
-    }
-    ge_p3 ident;
-    ge_identity(ident);
     // suffix scan over the wavefront's 64 buckets
 #pragma nounroll
     for (int off = 1; off < 64; off <<= 1) {
         ge_p3 q;
         pt_shfl_down(q, V, off);
-        const bool in = lane + (u32)off < 64;
-        fe_select(q.X, ident.X, q.X, in); fe_select(q.Y, ident.Y, q.Y, in);
-        fe_select(q.Z, ident.Z, q.Z, in); fe_select(q.T, ident.T, q.T, in);
-        ge_add_p3(V, V, q);
+        pt_add_if(V, q, lane + (u32)off < 64);
     }
     ge_p3 T;                           // this wavefront's plain total = V of lane 0
     pt_shfl_lane0(T, V);
@@ -219,19 +302,14 @@ k_rlc_reduce(const u32 *__restrict__ part, u32 S, u32 *__restrict__ wsum) {
 #pragma unroll
         for (int i = 0; i < 10; i++) { q.X.v[i] = s_up[i]; q.Y.v[i] = s_up[10 + i]; q.Z.v[i] = s_up[20 + i]; q.T.v[i] = s_up[30 + i]; }
         ge_add_p3(V, V, q);
-        if (lane == 0) {
-            u32 *o = wsum + (size_t)40 * w;
-#pragma unroll
-            for (int i = 0; i < 10; i++) { o[i] = V.X.v[i]; o[10 + i] = V.Y.v[i]; o[20 + i] = V.Z.v[i]; o[30 + i] = V.T.v[i]; }
-        }
+        if (lane == 0) rlc_store_wsum(wsum + (size_t)HS_RLC_WSUM_WORDS * w, V);
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ btab, const unsigned long long *__restrict__ csum,
-            const u32 *__restrict__ failed, u32 *__restrict__ ok_flag) {
+k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ failed, u32 *__restrict__ ok_flag) {
     if (threadIdx.x >= 4) return;      // one quad
-    const qflags f = rlc_final_quad(wsum, btab, csum);
+    const qflags f = rlc_final_quad(wsum);
     const bool all = q_quad_all(f);
     if (threadIdx.x == 0) *ok_flag = (all && *failed == 0) ? 1u : 0u;
 }
@@ -239,9 +317,10 @@ k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ btab, const un
 // ------------------------------------------------------------------------------------------ host
 namespace {
 struct rlc_ws {
-    size_t np = 0; u32 S = 0;
-    u32 *rec = nullptr; uint8_t *dig = nullptr; u32 *sorted = nullptr, *boff = nullptr, *part = nullptr, *wsum = nullptr;
-    uint8_t *small = nullptr;      // csum[8] (64 B) | fail (4) | ok (4) | pad
+    size_t np = 0;                 // capacity in (padded) signatures
+    u32 *rec = nullptr; uint8_t *dig = nullptr; u32 *sorted = nullptr, *part = nullptr, *wsum = nullptr;
+    u32 *tabs = nullptr;           // ghist | boff | segoff | gcur, each [32][129]
+    uint8_t *small = nullptr;      // csum[8] (64 B) | failed (4) | ok (4) | pad
     size_t min_batch = 0;          // 0 = the library default
     size_t calls = 0;
 };
@@ -249,26 +328,26 @@ std::mutex k_mu;
 rlc_key g_key;
 bool g_key_set = false;
 
-// Below this many signatures the five-stage pipeline costs more than the per-signature kernels
-// (one wavefront's serial chain either way; profiles/r2_rlc_ab.md): the call then runs plain BATCH.
-const size_t kRlcMinBatch = 2048;
+// Below this many signatures the pipeline (five stages, the last a 248-doubling chain on one quad) costs
+// more than the per-signature kernels (profiles/r2_rlc_ab.md): the call then runs plain BATCH.
+const size_t kRlcMinBatch = 16384;
+const u32 kTabWords = HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1);
+const u32 kMinChunk = 8;
 
 void ws_free(rlc_ws *w) {
     if (w->rec) (void)hipFree(w->rec);
     if (w->dig) (void)hipFree(w->dig);
     if (w->sorted) (void)hipFree(w->sorted);
-    if (w->boff) (void)hipFree(w->boff);
     if (w->part) (void)hipFree(w->part);
     if (w->wsum) (void)hipFree(w->wsum);
+    if (w->tabs) (void)hipFree(w->tabs);
     if (w->small) (void)hipFree(w->small);
-    w->rec = w->sorted = w->boff = w->part = w->wsum = nullptr; w->dig = w->small = nullptr; w->np = 0; w->S = 0;
+    w->rec = w->sorted = w->part = w->wsum = w->tabs = nullptr; w->dig = w->small = nullptr; w->np = 0;
 }
-u32 segments_for(size_t n) {       // lanes per bucket: runs of ~16 points per lane, at most 64 segments
-    const size_t per_bucket = 2 * n / HS_RLC_BUCKETS;
-    u32 s = 1;
-    while (s < 64 && (size_t)s * 16 < per_bucket) s <<= 1;
-    return s;
+u32 chunk_for(size_t n) {          // points per lane of stage 3: enough lanes to fill the chip, runs long enough to amortise the scan
+    return n <= 16384 ? 8u : (n <= 131072 ? 16u : 32u);
 }
+u32 lane_cap(size_t np, u32 C) { return (u32)round_up(2 * np / C + HS_RLC_BUCKETS, 64); }   // chunks per window, upper bound
 rlc_ws *ws_of(hs_ed25519_ctx *ctx) {
     if (!ctx->rlc) ctx->rlc = new (std::nothrow) rlc_ws();
     return (rlc_ws *)ctx->rlc;
@@ -288,22 +367,19 @@ int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n) {
     rlc_ws *w = ws_of(ctx);
     if (!w) return fail(HS_ED25519_E_NOMEM, "rlc: out of memory");
     const size_t np = round_up(n, 64);
-    const u32 S = segments_for(n);
-    if (np <= w->np && S <= w->S) return 0;
+    if (np <= w->np) return 0;
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(ctx->stream), "stream sync");       // the old buffers may be in use
-    const size_t cap = np > w->np ? np : w->np;
-    const u32 Scap = S > w->S ? S : w->S;
     ws_free(w);
-    const size_t NP = 2 * cap;
+    const size_t NP = 2 * np;
     HS_HIP(hipMalloc((void **)&w->rec, (NP + 1) * 128), "hipMalloc rlc records");
     HS_HIP(hipMalloc((void **)&w->dig, (size_t)HS_RLC_WINDOWS * NP), "hipMalloc rlc digits");
     HS_HIP(hipMalloc((void **)&w->sorted, (size_t)HS_RLC_WINDOWS * NP * 4), "hipMalloc rlc sorted");
-    HS_HIP(hipMalloc((void **)&w->boff, (size_t)HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1) * 4), "hipMalloc rlc offsets");
-    HS_HIP(hipMalloc((void **)&w->part, (size_t)HS_RLC_WINDOWS * Scap * 40 * HS_RLC_BUCKETS * 4), "hipMalloc rlc partials");
-    HS_HIP(hipMalloc((void **)&w->wsum, (size_t)HS_RLC_WINDOWS * 40 * 4), "hipMalloc rlc window sums");
+    HS_HIP(hipMalloc((void **)&w->part, (size_t)HS_RLC_WINDOWS * lane_cap(np, kMinChunk) * 160), "hipMalloc rlc partials");
+    HS_HIP(hipMalloc((void **)&w->wsum, (size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS * 4), "hipMalloc rlc window sums");
+    HS_HIP(hipMalloc((void **)&w->tabs, (size_t)4 * kTabWords * 4), "hipMalloc rlc offsets");
     HS_HIP(hipMalloc((void **)&w->small, 128), "hipMalloc rlc flags");
-    w->np = cap; w->S = Scap;
+    w->np = np;
     return 0;
 }
 
@@ -354,12 +430,11 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     *d_ok_flag = nullptr;
     if (!d_sigs || (!ks && !d_pks) || (ks && !d_key_idx)) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
     if (misaligned(d_sigs, 16) || misaligned(d_pks, 16) || misaligned(d_key_idx, 4)) return fail(HS_ED25519_E_ARG, "verify_device: misaligned pointer");
-    if (n > 0x1fffffffu) return fail(HS_ED25519_E_ARG, "verify_device: bad n");
     if (ks && ks->slot != ctx->slot) return fail(HS_ED25519_E_ARG, "verify_device_cached: the key set lives on another device slot than the context");
     rlc_ws *w = ws_of(ctx);
     if (!w) return fail(HS_ED25519_E_NOMEM, "rlc: out of memory");
     const size_t min_batch = w->min_batch ? w->min_batch : kRlcMinBatch;
-    if (n < min_batch) return 0;           // too small to pay for the pipeline: plain per-signature BATCH
+    if (n < min_batch || n > 0x0fffffffu) return 0;      // too small to pay for the pipeline (or absurdly large): plain per-signature BATCH
     const u32 *btab = dev_base_table(ctx->slot);
     if (!btab) return HS_ED25519_E_DEVICE;
     int rc = rlc_reserve(ctx, n);
@@ -369,40 +444,53 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     if (rc) return rc;
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    const u32 np = (u32)round_up(n, 64), NP = 2 * np, S = segments_for(n), nn = (u32)n;
+    const u32 np = (u32)round_up(n, 64), NP = 2 * np, nn = (u32)n, C = chunk_for(n), Lcap = lane_cap(np, C);
+    u32 G = NP / 16384; G = G < 1 ? 1 : (G > 16 ? 16 : G);
     rlc_view v;
     v.rec = w->rec; v.dig = w->dig; v.csum = (unsigned long long *)w->small; v.failed = (u32 *)(w->small + 64); v.np = np;
     u32 *ok_flag = (u32 *)(w->small + 68);
+    u32 *ghist = w->tabs, *boff = w->tabs + kTabWords, *segoff = w->tabs + 2 * kTabWords, *gcur = w->tabs + 3 * kTabWords;
     HS_HIP(hipMemsetAsync(w->small, 0, 128, st), "rlc clear flags");
+    HS_HIP(hipMemsetAsync(ghist, 0, (size_t)kTabWords * 4, st), "rlc clear histograms");
     HS_HIP(hipMemsetAsync(w->dig, 0x80, (size_t)HS_RLC_WINDOWS * NP, st), "rlc clear digits");
     rlc_keys_src keys;
     keys.pks = ks ? nullptr : (const u32 *)d_pks; keys.key_idx = ks ? d_key_idx : nullptr;
     keys.ks_pk = ks ? ks->d_pk : nullptr; keys.ks_flag = ks ? ks->d_flag : nullptr; keys.nkeys = ks ? (u32)ks->nkeys : 0;
     const u32 *p_sg = (const u32 *)d_sigs;
     const u32 tasks = ks ? nn : 2 * nn;
+    const uint8_t *p_dig = w->dig;
     {
         void *a[] = { &v, &key, &msgs, &keys, &p_sg, (void *)&nn };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_prepare, dim3((tasks + 63) / 64), dim3(64), a, 0, st), "launch k_rlc_prepare");
     }
     {
-        const uint8_t *p_dig = w->dig; const u32 *p_ki = keys.key_idx; u32 *p_sorted = w->sorted, *p_boff = w->boff;
-        void *a[] = { &p_dig, (void *)&NP, (void *)&np, &p_ki, &p_sorted, &p_boff };
-        HS_HIP(hipLaunchKernel((const void *)k_rlc_sort, dim3(HS_RLC_WINDOWS), dim3(1024), a, 0, st), "launch k_rlc_sort");
+        void *a[] = { &p_dig, (void *)&NP, &ghist };
+        HS_HIP(hipLaunchKernel((const void *)k_rlc_hist, dim3(G, HS_RLC_WINDOWS), dim3(1024), a, 0, st), "launch k_rlc_hist");
     }
     {
-        const u32 *p_sorted = w->sorted, *p_boff = w->boff, *p_rec = w->rec, *p_ksn = ks ? ks->d_niels : nullptr;
+        const u32 *p_hist = ghist;
+        void *a[] = { &p_hist, (void *)&C, &boff, &segoff, &gcur };
+        HS_HIP(hipLaunchKernel((const void *)k_rlc_offsets, dim3(1), dim3(64), a, 0, st), "launch k_rlc_offsets");
+    }
+    {
+        const u32 *p_ki = keys.key_idx; u32 *p_sorted = w->sorted;
+        void *a[] = { &p_dig, (void *)&NP, (void *)&np, &p_ki, &keys.nkeys, &gcur, &p_sorted };
+        HS_HIP(hipLaunchKernel((const void *)k_rlc_scatter, dim3(G, HS_RLC_WINDOWS), dim3(1024), a, 0, st), "launch k_rlc_scatter");
+    }
+    {
+        const u32 *p_sorted = w->sorted, *p_boff = boff, *p_seg = segoff, *p_rec = w->rec, *p_ksn = ks ? ks->d_niels : nullptr;
         u32 *p_part = w->part;
-        void *a[] = { &p_sorted, &p_boff, &p_rec, &p_ksn, (void *)&NP, (void *)&S, &p_part };
-        HS_HIP(hipLaunchKernel((const void *)k_rlc_accum, dim3(HS_RLC_WINDOWS * 2 * S), dim3(64), a, 0, st), "launch k_rlc_accum");
+        void *a[] = { &p_sorted, &p_boff, &p_seg, &p_rec, &p_ksn, (void *)&NP, (void *)&C, (void *)&Lcap, &p_part };
+        HS_HIP(hipLaunchKernel((const void *)k_rlc_accum, dim3(Lcap / 64, HS_RLC_WINDOWS), dim3(64), a, 0, st), "launch k_rlc_accum");
     }
     {
-        const u32 *p_part = w->part; u32 *p_wsum = w->wsum;
-        void *a[] = { &p_part, (void *)&S, &p_wsum };
-        HS_HIP(hipLaunchKernel((const void *)k_rlc_reduce, dim3(HS_RLC_WINDOWS), dim3(128), a, 0, st), "launch k_rlc_reduce");
+        const u32 *p_part = w->part, *p_seg = segoff; const unsigned long long *p_csum = v.csum; u32 *p_wsum = w->wsum;
+        void *a[] = { &p_part, &p_seg, (void *)&Lcap, &btab, &p_csum, &p_wsum };
+        HS_HIP(hipLaunchKernel((const void *)k_rlc_reduce, dim3(HS_RLC_WINDOWS + 1), dim3(128), a, 0, st), "launch k_rlc_reduce");
     }
     {
-        const u32 *p_wsum = w->wsum; const unsigned long long *p_csum = v.csum; const u32 *p_fail = v.failed;
-        void *a[] = { &p_wsum, &btab, &p_csum, &p_fail, &ok_flag };
+        const u32 *p_wsum = w->wsum; const u32 *p_fail = v.failed;
+        void *a[] = { &p_wsum, &p_fail, &ok_flag };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_final, dim3(1), dim3(64), a, 0, st), "launch k_rlc_final");
     }
     w->calls++;

@@ -4,7 +4,7 @@
 //
 //      -[sum z_i s_i mod L] B  +  sum [z_i] R_i  +  sum [z_i h_i mod L] A_i   ==   O
 //
-// with 128-bit z_i, h_i = SHA-512(R_i || A_i || M) mod L, evaluated as ONE multi-scalar
+// with 127-bit z_i (dalek: 128-bit), h_i = SHA-512(R_i || A_i || M) mod L, evaluated as ONE multi-scalar
 // multiplication over 2n + 1 points (dalek: Straus below 190 points, Pippenger above; here
 // Pippenger with signed 8-bit windows throughout, shaped for the GPU):
 //
@@ -13,16 +13,19 @@
 //            mod L, recodes both scalars into 32 signed radix-256 digits (one byte each) and adds
 //            z_i s_i into eight lazy 64-bit limb sums.
 //   stage 2  (kernel only) counting sort of the points of every window by |digit| -> per-bucket runs
-//   stage 3  rlc_accum_lane            one lane per (window, bucket, segment): mixed additions of its run
-//   stage 4  rlc_bucket_fold / the wavefront-shuffle form in hs_rlc.hip: segment partials -> bucket sums
-//            -> sum_j j * bucket_j  (suffix scan + reduction across the 64 lanes of a wavefront)
+//   stage 3  rlc_accum_lane            one lane per chunk of at most C consecutive points of one bucket's run
+//            (a bucket gets ceil(len / C) lanes, so skewed buckets - the 5-bit top window of the 253-bit
+//            scalars - cost lanes, not time): mixed additions
+//   stage 4  rlc_bucket_fold / the wavefront-shuffle form in hs_rlc.hip: chunk partials -> bucket sums
+//            -> sum_j j * bucket_j  (suffix scan + reduction across the 64 lanes of a wavefront);
+//            rlc_b_point: [-(sum z_i s_i)]B from the base point's window table, beside it
 //   stage 5  rlc_final_quad            Horner over the 32 window sums (248 doublings, four lanes per
-//            point), + [b]B from the base point's window table, identity test.
+//            point), + the [b]B point, identity test.
 //
 // All of it is host+device so that tests/emu runs the same arithmetic on the CPU against oracle/.
 // z_i: dalek draws them from a merlin transcript finalised with thread_rng(); here
-// z_i = SHA-512(key || h_i || s_i || le64(i))[..16] with a 32-byte process secret `key` - the same
-// distribution, unpredictable to whoever assembled the batch, and reproducible under a pinned key.
+// z_i = SHA-512(key || h_i || s_i || le64(i))[..16] mod 2^127 with a 32-byte process secret `key` - a uniform
+// coefficient of the same strength, unpredictable to whoever assembled the batch, and reproducible under a pinned key.
 #pragma once
 #include "verify_cached.h"
 
@@ -46,7 +49,8 @@ struct rlc_view {
     u32 np;
 };
 
-// 128-bit coefficient of signature `index`; z[4..7] = 0
+// coefficient of signature `index`: the low 127 bits of the keyed hash (z < 2^127 keeps the signed radix-256
+// recoding inside 16 windows: no carry window that would put half of all R points into one bucket); z[4..7] = 0
 HS_HD void rlc_coeff(u32 z[8], const rlc_key &key, const u32 k[8], const u32 s[8], u32 index) {
     u32 in[26];
 #pragma unroll
@@ -58,7 +62,7 @@ HS_HD void rlc_coeff(u32 z[8], const rlc_key &key, const u32 k[8], const u32 s[8
     w[13] = 0x8000000000000000ull; w[14] = 0; w[15] = 104 * 8;
     sha512_oneblock(hh, w);
     z[0] = bswap32((u32)(hh[0] >> 32)); z[1] = bswap32((u32)hh[0]);
-    z[2] = bswap32((u32)(hh[1] >> 32)); z[3] = bswap32((u32)hh[1]);
+    z[2] = bswap32((u32)(hh[1] >> 32)); z[3] = bswap32((u32)hh[1]) & 0x7fffffffu;
     z[4] = z[5] = z[6] = z[7] = 0;
 }
 
@@ -187,9 +191,8 @@ HS_HD void rlc_b_scalar(u32 b[8], const unsigned long long *csum) {
     }
 }
 
-// stage 5: Horner over the window sums (wsum: [32][40] extended points, X Y Z T limbs), + [b]B from
-// the base point's window table (verify_cached.h layout), identity test.  Quad form: one coordinate
-// per lane.  Returns the per-lane flags; the caller ANDs the quad.
+// stage 5: Horner over the window sums + the [b]B point (slots written by rlc_store_wsum), identity test.
+// Quad form: one coordinate per lane.  Returns the per-lane flags; the caller ANDs the quad.
 HS_Q qv rlc_load_point_quad(const u32 *pt40) {
 #if defined(__HIPCC__)
     qv r;
@@ -201,17 +204,34 @@ HS_Q qv rlc_load_point_quad(const u32 *pt40) {
     qv r; for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = pt40[10 * l + i]; return r;
 #endif
 }
-HS_Q qflags rlc_final_quad(const u32 *wsum, const u32 *btab, const unsigned long long *csum) {
-    qv acc = rlc_load_point_quad(wsum + (size_t)40 * (HS_RLC_WINDOWS - 1));
-#pragma nounroll
-    for (int w = HS_RLC_WINDOWS - 2; w >= 0; w--) {
-#pragma nounroll
-        for (int d = 0; d < 8; d++) acc = q_dbl(acc);
-        acc = q_add_cached(acc, q_to_cached(rlc_load_point_quad(wsum + (size_t)40 * w)));
+// window sums as handed from stage 4 to stage 5: slot w < 32 = W_w, slot 32 = [b]B; each slot holds the point
+// twice, extended (X, Y, Z, T) in words 0-39 and cached (Y-X, Y+X, 2dT, 2Z) in words 40-79
+#define HS_RLC_WSUM_WORDS 80
+HS_HD void rlc_store_wsum(u32 *slot, const ge_p3 &p) {
+    fe ymx, ypx, t2d, z2;
+    fe_sub(ymx, p.Y, p.X); fe_carry(ymx);
+    fe_add(ypx, p.Y, p.X); fe_carry(ypx);
+    fe_mul(t2d, p.T, fe_d2());
+    fe_add(z2, p.Z, p.Z); fe_carry(z2);
+    for (int i = 0; i < 10; i++) {
+        slot[i] = p.X.v[i]; slot[10 + i] = p.Y.v[i]; slot[20 + i] = p.Z.v[i]; slot[30 + i] = p.T.v[i];
+        slot[40 + i] = ymx.v[i]; slot[50 + i] = ypx.v[i]; slot[60 + i] = t2d.v[i]; slot[70 + i] = z2.v[i];
     }
+}
+// [b]B, b = -(sum z_i s_i) mod L, one lane, from the base point's window table (verify_cached.h layout)
+HS_HD void rlc_b_point(ge_p3 &bb, const u32 *btab, const unsigned long long *csum) {
     u32 b[8], bw[8];
     rlc_b_scalar(b, csum);
     sc_recode256(bw, b);
+    cached_chain(bb, btab, bw);
+}
+// the same point on a quad (one coordinate per lane): a single lane would run 256 field multiplications
+// back to back, the slowest thing in stage 4
+HS_Q qv rlc_b_point_quad(const u32 *btab, const unsigned long long *csum) {
+    u32 b[8], bw[8];
+    rlc_b_scalar(b, csum);
+    sc_recode256(bw, b);
+    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
 #pragma nounroll
     for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
         const int ds = sc_pop_digit8(bw);
@@ -219,6 +239,28 @@ HS_Q qflags rlc_final_quad(const u32 *wsum, const u32 *btab, const unsigned long
         const qv eb = q_load_entry(btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
         acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
     }
+    return acc;
+}
+// slot = extended (X, Y, Z, T) then cached (Y-X, Y+X, 2dT, 2Z), from a quad
+HS_Q void rlc_store_wsum_quad(u32 *slot, const qv &p) {
+    const qv c = q_to_cached(p);
+#if defined(__HIPCC__)
+    const u32 l = q_lane();
+#pragma unroll
+    for (int i = 0; i < 10; i++) { slot[10 * l + i] = p.v[i]; slot[40 + 10 * l + i] = c.v[i]; }
+#else
+    for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) { slot[10 * l + i] = p.l[l].v[i]; slot[40 + 10 * l + i] = c.l[l].v[i]; }
+#endif
+}
+HS_Q qflags rlc_final_quad(const u32 *wsum) {
+    qv acc = rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * (HS_RLC_WINDOWS - 1));
+#pragma nounroll
+    for (int w = HS_RLC_WINDOWS - 2; w >= 0; w--) {
+#pragma nounroll
+        for (int d = 0; d < 8; d++) acc = q_dbl(acc);
+        acc = q_add_cached(acc, rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * w + 40));
+    }
+    acc = q_add_cached(acc, rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS + 40));
     // identity: X == 0 (lane 0), Y == Z (lane 1), Z != 0 (lane 2; fail closed on a zeroed accumulator)
     const qv z = q_perm<2, 2, 2, 2>(acc);
     qflags f;

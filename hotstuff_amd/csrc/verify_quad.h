@@ -146,12 +146,15 @@ HS_Q qflags q_eq_nz(const qv &a, const qv &b_reduced) {
 
 HS_HD fe fe_small(u32 c) { fe r; fe_0(r); r.v[0] = c; return r; }
 
-// The per-signature table j*(-A), j = 0..8.  On the GPU it lives in LDS, one 23 KB slab per
-// wavefront laid out [entry][limb][lane]: whatever entry each quad picks, the 32 lanes of a
-// half-wave hit 32 different banks (bank = lane mod 32), so lookups are conflict-free - and
-// the table never touches HBM (in private memory it was 368 B x 4 lanes of write-back traffic
-// per signature, profiles/r1_pmc_traffic.json).
-#define HS_QTAB_ENTRIES 9
+// The per-signature table j*(-A), j = 1..8 (digit 0 takes the identity from a constant).  On the
+// GPU it lives in LDS, one 20,480-byte slab per wavefront laid out [entry][limb][lane]: whatever
+// entry each quad picks, the 32 lanes of a half-wave hit 32 different banks (bank = lane mod 32),
+// so lookups are conflict-free - and the table never touches HBM (in private memory it was
+// 368 B x 4 lanes of write-back traffic per signature, profiles/r1_pmc_traffic.json).
+// Eight entries, not nine: 8 x 20,480 B is exactly a CU's 160 KB of LDS, i.e. two wavefronts per
+// SIMD - which is also what the kernel's ~250 VGPRs allow; with the identity stored as a ninth
+// entry (23,040 B) only six wavefronts fit a CU.
+#define HS_QTAB_ENTRIES 8
 #if defined(__HIPCC__)
 #define HS_QTAB_WORDS (HS_QTAB_ENTRIES * 10 * 64)
 struct qtab { u32 *lds; };      // this wavefront's slab
@@ -172,6 +175,25 @@ struct qtab { qv e[HS_QTAB_ENTRIES]; };
 HS_Q void qtab_store(qtab &t, int j, const qv &e) { t.e[j] = e; }
 HS_Q qv qtab_load(const qtab &t, int j) { return t.e[j]; }
 #endif
+// |digit| * (-A) in cached form: table entry |digit| - 1, or the identity (1, 1, 0, 2) for digit 0.
+// The choice is per quad, so it is a mask, not a branch: limbs above the lowest are e & m, the
+// lowest is e0 & m | id0 & ~m.
+HS_Q qv qtab_pick(const qtab &t, int mag) {
+    const qv e = qtab_load(t, mag ? mag - 1 : 0);
+#if defined(__HIPCC__)
+    u32 m = mag ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));              // keep it a mask (v_and / v_bfi), not a VCC select
+    const u32 l = q_lane();
+    const u32 id0 = l == 2 ? 0u : (l == 3 ? 2u : 1u);
+    qv r;
+    r.v[0] = (e.v[0] & m) | (id0 & ~m);
+#pragma unroll
+    for (int i = 1; i < 10; i++) r.v[i] = e.v[i] & m;
+    return r;
+#else
+    return mag ? e : q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2));
+#endif
+}
 
 #define HS_QP(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
 // (X, Y, Z, T) -> (Y-X, Y+X, T, Z): the left operands of an addition's first round    (<= 3x)
@@ -227,15 +249,14 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
     fe nax; fe_neg(nax, ax);
     qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
 
-    // j * (-A), cached, j = 0..8
-    qtab_store(atab, 0, q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2)));
+    // j * (-A), cached, j = 1..8 at index j - 1
     {
         const qv a1 = q_to_cached(p);
-        qtab_store(atab, 1, a1);
+        qtab_store(atab, 0, a1);
 #pragma nounroll
         for (int j = 2; j <= 8; j++) {
             p = q_add_cached(p, a1);
-            qtab_store(atab, j, q_to_cached(p));
+            qtab_store(atab, j - 1, q_to_cached(p));
         }
     }
 
@@ -246,7 +267,7 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
         for (int d = 0; d < 4; d++) acc = q_dbl(acc);
         const int dk = sc_pop_digit(kw);
         const int ik = dk < 0 ? -dk : dk;
-        const qv ea = qtab_load(atab, ik);
+        const qv ea = qtab_pick(atab, ik);
         acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
         if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
             const int ds = sc_pop_digit8(sw);

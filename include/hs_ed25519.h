@@ -145,6 +145,18 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
                              const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint32_t mode,
                              uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
 
+/* Several INDEPENDENT small batches in one launch (up to 16 per grid; longer lists are cut into several
+ * launches): a node under load has many certificates pending, and a 1,024-signature batch alone is only one
+ * wavefront per SIMD of a sixteenth of the chip.  Every batch keeps its own digests, bitmap and reject counter;
+ * n <= 32,768 and mode BATCH or STRICT for each.  Pointer rules as for hs_ed25519_verify_device. */
+typedef struct hs_ed25519_batch {
+    const uint8_t *d_digests; size_t digest_stride;
+    const uint8_t *d_pks, *d_sigs;
+    size_t n; uint32_t mode;
+    uint8_t *d_bitmap; uint32_t *d_nreject;
+} hs_ed25519_batch;
+int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, void *stream);
+
 /* ---- committee key cache -------------------------------------------------------------------
  * Every key the reference verifies belongs to the committee, which is static per epoch
  * (consensus/src/config.rs:39-43).  hs_ed25519_keyset_create decompresses the n_keys public

@@ -220,7 +220,7 @@ int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, c
     if (fail) return 0;
     static std::vector<u32> btab;
     if (btab.empty()) { btab.resize(HS_KS_KEY_WORDS); emu_keyset_build_base(btab.data()); }
-    std::vector<u32> wsum((size_t)HS_RLC_WINDOWS * 40);
+    std::vector<u32> wsum((size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS);
     for (int w = 0; w < HS_RLC_WINDOWS; w++) {
         std::vector<u32> sorted; std::vector<u32> off(HS_RLC_BUCKETS + 1, 0);
         std::vector<std::vector<u32>> lists(HS_RLC_BUCKETS);
@@ -244,9 +244,17 @@ int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, c
         }
         ge_p3 W;
         rlc_bucket_fold(W, bucket);
-        for (int i = 0; i < 10; i++) { wsum[40 * w + i] = W.X.v[i]; wsum[40 * w + 10 + i] = W.Y.v[i]; wsum[40 * w + 20 + i] = W.Z.v[i]; wsum[40 * w + 30 + i] = W.T.v[i]; }
+        rlc_store_wsum(wsum.data() + (size_t)HS_RLC_WSUM_WORDS * w, W);
     }
-    const qflags f = rlc_final_quad(wsum.data(), btab.data(), csum);
+    rlc_store_wsum_quad(wsum.data() + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS, rlc_b_point_quad(btab.data(), csum));
+    {   // the one-lane form of the same point must agree (projectively): compare b B + (-(b B)) == O via the final test is overkill; check affine x, y
+        ge_p3 bb; rlc_b_point(bb, btab.data(), csum);
+        const u32 *q = wsum.data() + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS;
+        fe qx, qy, qz; for (int i = 0; i < 10; i++) { qx.v[i] = q[i]; qy.v[i] = q[10 + i]; qz.v[i] = q[20 + i]; }
+        fe l1, r1, l2, r2; fe_mul(l1, bb.X, qz); fe_mul(r1, qx, bb.Z); fe_mul(l2, bb.Y, qz); fe_mul(r2, qy, bb.Z);
+        if (!fe_eq(l1, r1) || !fe_eq(l2, r2)) return -1;
+    }
+    const qflags f = rlc_final_quad(wsum.data());
     return f.f[0] && f.f[1] && f.f[2] && f.f[3];
 }
 void emu_rlc_coeff(const uint8_t *key32, const uint8_t *k32, const uint8_t *s32, uint32_t index, uint8_t *z16) {

@@ -36,7 +36,7 @@ def test_edge_vectors_with_every_key_registered(edge_vectors):
     n = len(edge_vectors)
     keys = [H(v["pk"]) for v in edge_vectors]
     ks = _lib.KeySet(keys)
-    assert ks.hbm_bytes() == n * (32 * 129 * 160 + 36)
+    assert ks.hbm_bytes() == n * (32 * 129 * 160 + 36 + 128)      # tables + key bytes + flags + the 128-byte Niels record of the RLC path
     dg = b"".join(H(v["msg"]) for v in edge_vectors)
     sg = b"".join(H(v["sig"]) for v in edge_vectors)
     # KeySet.index keeps the first position of a repeated key; the tables of equal keys are equal

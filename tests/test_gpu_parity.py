@@ -360,3 +360,35 @@ def test_lifecycle_shutdown_reinit_and_keyset_churn():
     packed, _ = ks.indices(keys)
     assert ks.verify_packed(dg, packed, sg, n, _lib.STRICT, True)[0]
     ks.close()
+
+
+def test_several_batches_in_one_launch(oracle):
+    """hs_ed25519_verify_device_batches: 19 independent batches of different sizes, digest forms and
+    modes (> 16, so two grids), each with its own bitmap and reject counter, vs the oracle."""
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    sizes = [1, 16, 17, 63, 64, 65, 100, 333, 1024, 1000, 5, 128, 129, 700, 2, 1024, 31, 257, 64]
+    ctx = _lib.DeviceContext(1024)
+    keep, entries, expect = [], [], []
+    nr = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
+    for k, n in enumerate(sizes):
+        shared, mode = bool(k % 2), (_lib.STRICT if k % 3 else _lib.BATCH)
+        dg, pk, sg = synth.make_batch(n, shared=shared, first=1000 * k, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)
+        expect.append(oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, mode))
+        d = [t(dg), t(pk), t(sg), torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)]
+        keep.append(d)
+        entries.append((d[0].data_ptr(), 0 if shared else 32, d[1].data_ptr(), d[2].data_ptr(), n, mode, d[3].data_ptr(),
+                        nr[k:].data_ptr()))
+    torch.cuda.synchronize(dev)
+    ctx.verify_batches(_lib.batch_array(entries))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    for k, n in enumerate(sizes):
+        got = bits(bytes(keep[k][3].cpu().tolist()), n)
+        assert got == expect[k], "batch %d (n = %d)" % (k, n)
+        assert int(nr[k].item()) == sum(1 for b in got if not b)
+    # argument errors: a batch above the fused kernel's range, an RLC mode
+    big = _lib.batch_array([(keep[0][0].data_ptr(), 0, keep[0][1].data_ptr(), keep[0][2].data_ptr(), 40000, 0, keep[0][3].data_ptr(), 0)])
+    with pytest.raises(_lib.EngineError):
+        ctx.verify_batches(big)
+    ctx.close()
