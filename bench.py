@@ -342,47 +342,32 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI
-    (hs_ed25519_verify_multi / _shared).  `threads` host threads each verify their own 1,024-tuple batch in
-    a loop (ctypes releases the GIL for the call); every call stages into pinned memory, launches and waits
-    for its verdict.  PCIe-inclusive."""
-    import threading
+    (hs_ed25519_verify_multi / _shared).  `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads
+    would measure the interpreter lock) each verify their own 1,024-tuple batch in a loop; every call stages
+    into pinned memory, launches on its pool context's CU-partitioned stream and waits for its verdict.
+    PCIe-inclusive."""
     lib = _lib.lib()
-    fn = lib.hs_ed25519_verify_multi if stride else lib.hs_ed25519_verify_shared
-    bufs = []
-    for t in range(threads):
-        dg, pk, sg = batches[t % len(batches)]
-        bufs.append(tuple(ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)))
-    for b in bufs[:4]:       # warm the context pool
-        assert fn(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, mode, None) == 1
-    counts, lats, stop, go = [0] * threads, [[] for _ in range(threads)], threading.Event(), threading.Event()
-
-    def work(t):
-        a = tuple(ctypes.addressof(x) for x in bufs[t])
-        go.wait()
-        while not stop.is_set():
-            t0 = time.perf_counter()
-            rc = fn(a[0], a[1], a[2], n, mode, None)
-            lats[t].append(time.perf_counter() - t0)
-            if rc != 1:
-                counts[t] = -1
-                return
-            counts[t] += 1
-
-    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    for x in th:
-        x.start()
-    t0 = time.perf_counter()
-    go.set()
-    time.sleep(seconds)
-    stop.set()
-    for x in th:
-        x.join()
-    wall = time.perf_counter() - t0
-    assert all(c >= 0 for c in counts), "end-to-end call rejected a valid batch"
-    allv = sorted(v for l in lats for v in l)
-    return {"value": round(sum(counts) * n / wall, 1), "unit": "verifies/s", "host_threads": threads, "calls": sum(counts),
-            "signatures_per_call": n, "seconds": round(wall, 3), "call_p50_ms": round(allv[len(allv) // 2] * 1e3, 4),
-            "path": "host buffers -> pinned staging -> kernel reads over PCIe (zero-copy) -> pinned bitmap -> host verdict"}
+    dg = b"".join(b[0] for b in batches)
+    pk = b"".join(b[1] for b in batches)
+    sg = b"".join(b[2] for b in batches)
+    bufs = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    a = [ctypes.addressof(x) for x in bufs]
+    out = {"unit": "verifies/s", "signatures_per_call": n,
+           "path": "host buffers -> pinned staging -> kernel reads over PCIe (zero-copy) -> pinned bitmap -> host verdict"}
+    best = None
+    for th in sorted({1, threads // 2, threads}):
+        if th < 1:
+            continue
+        calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.hs_ed25519_loadgen(a[0], stride, a[1], a[2], n, len(batches), mode, th, seconds if th == threads else seconds / 2,
+                                          ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el)), "hs_ed25519_loadgen")
+        row = {"host_threads": th, "calls": calls.value, "seconds": round(el.value, 3), "call_p50_ms": round(p50.value, 4),
+               "value": round(calls.value * n / el.value, 1)}
+        out.setdefault("by_threads", []).append(row)
+        if best is None or row["value"] > best["value"]:
+            best = row
+    out.update(best)
+    return out
 
 
 def small_batch_crossover(_lib, synth):
@@ -526,7 +511,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="signatures per batch (one verify call)")
     ap.add_argument("--batches-per-step", type=int, default=1024,
                     help="independent 1,024-tuple batches per step per GPU")
-    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "4")),
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "2")),
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
@@ -767,6 +752,10 @@ def main():
         except Exception as e:
             cached = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # the headline's 16 stream contexts are done: release their streams before the extras create their own
+    # (HIP multiplexes streams onto 16 hardware queues; leftover streams would share queues with the extras')
+    for c in ctxs:
+        c.close()
     traffic = traffic_src = None
     kernel_name = "k_verify_fused_batches" if (K > 1 and n <= 32768) else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
@@ -868,8 +857,6 @@ def main():
     # ---- the same sharded workload from ONE process through the C ABI (rank 0 drives every GPU; the other
     # ranks have released their contexts and wait at the barrier)
     if not args.no_sharded and (exchange or os.environ.get("HS_BENCH_SHARDED_C_ABI") == "1"):
-        for c in ctxs:
-            c.close()
         if exchange:
             dist.barrier()
         if rank == 0:

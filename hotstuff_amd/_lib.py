@@ -86,6 +86,10 @@ def lib():
                 l.hs_ed25519_verify_device_tc_cached.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_batches.argtypes = [vp, vp, sz, vp]
                 l.hs_ed25519_verify_device_batches.restype = ctypes.c_int
+                l.hs_ed25519_loadgen.argtypes = [vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_double,
+                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                                 ctypes.POINTER(ctypes.c_double)]
+                l.hs_ed25519_loadgen.restype = ctypes.c_int
                 l.hs_ed25519_ctx_set_kernel.argtypes = [vp, ctypes.c_int]
                 l.hs_ed25519_ctx_set_kernel.restype = ctypes.c_int
                 l.hs_ed25519_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), sz, sz]

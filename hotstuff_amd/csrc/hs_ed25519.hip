@@ -491,16 +491,20 @@ int hs::hs_fail(int code, const char *what, hipError_t e) {
 struct dev_state {
     int ordinal = -1;
     u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
-    std::vector<hs_ed25519_ctx *> free_ctx;  // the host API's pool of stream contexts on this device
-    int live = 0;
-    unsigned cus = 0;                        // compute units (for the pool's CU-partitioned streams)
+    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one sixteenth of the CUs)
+    std::vector<hs_ed25519_ctx *> free_ctx[2];
+    int live[2] = {0, 0};
+    unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
 };
 static std::mutex g_mu;
 static std::condition_variable g_cv;
 static std::atomic<bool> g_init{false};
 static std::vector<dev_state> g_devs;        // written under g_mu by init / shutdown only
 static std::atomic<size_t> g_max_batch{0};
-static const int kMaxPool = 16;              // contexts per device slot (one HIP hardware queue each)
+// Pool sizes per device slot.  Every context owns a stream and HIP multiplexes streams onto 16 hardware queues
+// (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
+// narrow contexts - one per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
+static const int kMaxPool[2] = {4, 16};
 // cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
 // one lane per signature above (profiles/r1_cached_threshold_sweep.md: the three-wavefront form wins or ties
 // from 1,024 to ~200,000 signatures; the one-lane form does the least total work once the chip is several
@@ -508,10 +512,10 @@ static const int kMaxPool = 16;              // contexts per device slot (one HI
 static const size_t kCachedLane1Min = 196608;
 static const size_t kZeroCopyMax = 16384;    // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
-// Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel = one per SIMD of 16 CUs) run
-// on their pool context's CU-partitioned stream: concurrent callers then occupy disjoint sixteenths of the chip
-// instead of being stacked onto the same CUs by the dispatcher (13.5 -> M verifies/s end to end from 16 host
-// threads, bench.py `end_to_end`); one caller alone loses nothing, its batch is one wavefront per SIMD either way.
+// Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel = one per SIMD of 16 CUs) are
+// served by the NARROW pool, whose streams are confined to one sixteenth of the CUs each: concurrent callers then
+// occupy disjoint slices of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py
+// `end_to_end`); one caller alone loses nothing, its batch is one wavefront per SIMD either way.
 static const size_t kPartitionMaxBatch = 1024;
 static const unsigned kPoolPartitions = 16;
 
@@ -593,7 +597,6 @@ extern "C" int hs_ed25519_ctx_device(const hs_ed25519_ctx *c) { return c ? c->de
 extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream_part) { (void)hipStreamSynchronize(c->stream_part); (void)hipStreamDestroy(c->stream_part); }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
@@ -665,8 +668,10 @@ extern "C" void hs_ed25519_shutdown(void) {
     if (!g_init.load()) return;
     g_init.store(false);
     for (dev_state &d : g_devs) {
-        for (hs_ed25519_ctx *c : d.free_ctx) hs_ed25519_ctx_destroy(c);
-        d.free_ctx.clear(); d.live = 0;
+        for (int k = 0; k < 2; k++) {
+            for (hs_ed25519_ctx *c : d.free_ctx[k]) hs_ed25519_ctx_destroy(c);
+            d.free_ctx[k].clear(); d.live[k] = 0;
+        }
         if (d.base_tab) { (void)hipSetDevice(d.ordinal); (void)hipFree(d.base_tab); d.base_tab = nullptr; }
     }
     g_devs.clear();
@@ -1053,38 +1058,39 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
-int hs::pool_get(hs_ed25519_ctx **out, int slot) {
+int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n) {
+    const int k = n <= kPartitionMaxBatch ? 1 : 0;
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
     for (;;) {
         if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
         dev_state &d = g_devs[slot];
-        if (!d.free_ctx.empty()) { *out = d.free_ctx.back(); d.free_ctx.pop_back(); return 0; }
-        if (d.live < kMaxPool) { d.live++; break; }
+        if (!d.free_ctx[k].empty()) { *out = d.free_ctx[k].back(); d.free_ctx[k].pop_back(); return 0; }
+        if (d.live[k] < kMaxPool[k]) { d.live[k]++; break; }
         g_cv.wait(lk);
     }
-    const unsigned part = (unsigned)(g_devs[slot].live - 1) % kPoolPartitions, cus = g_devs[slot].cus;
+    const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
-    int rc = hs_ed25519_ctx_create_on(&c, 64, slot);
-    if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live--; g_cv.notify_one(); return rc; }
-    if (cus >= kPoolPartitions) {      // the partitioned twin of the context's stream; without it small calls just use the full one
+    int rc = -1;
+    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the CUs
         std::vector<uint32_t> mask((cus + 31) / 32, 0u);
         const unsigned lo = cus * part / kPoolPartitions, hi = cus * (part + 1) / kPoolPartitions;
         for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
-        if (hipExtStreamCreateWithCUMask(&c->stream_part, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            c->stream_part = nullptr;
-        }
+        rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
+        if (rc) (void)hipGetLastError();          // CU masking unavailable: a plain stream serves as well
     }
+    if (rc) rc = hs_ed25519_ctx_create_on(&c, 64, slot);
+    if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }
+    c->narrow = k == 1;
     *out = c;
     return 0;
 }
 void hs::pool_put(hs_ed25519_ctx *c) {
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
-    g_devs[c->slot].free_ctx.push_back(c);
+    g_devs[c->slot].free_ctx[c->narrow ? 1 : 0].push_back(c);
     g_cv.notify_all();
 }
 
@@ -1097,11 +1103,11 @@ void hs::pool_put(hs_ed25519_ctx *c) {
 int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
                     const void *keys, const uint8_t *sigs, size_t n, uint32_t mode) {
     job.c = nullptr; job.n = n;
-    int rc = pool_get(&job.c, slot);
+    int rc = pool_get(&job.c, slot, n);
     if (rc) return rc;
     hs_ed25519_ctx *c = job.c;
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
-    const size_t hint = g_max_batch.load();
+    const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
     rc = ctx_reserve(c, n > hint ? n : hint, true);
     if (rc) return rc;
     // staging layout: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n], each section 16-byte aligned
@@ -1111,17 +1117,16 @@ int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const 
     memcpy(c->h_in + off_k, keys, key_bytes);
     memcpy(c->h_in + off_sig, sigs, 64 * n);
     job.zc = n <= kZeroCopyMax;
-    job.st = (n <= kPartitionMaxBatch && c->stream_part) ? c->stream_part : c->stream;
     uint8_t *in = job.zc ? c->h_in : c->d_in, *outp = job.zc ? c->h_out : c->d_out;
     if (job.zc) memset(c->h_out, 0, bitmap_bytes(n));
     else {
-        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), job.st), "clear bitmap");
-        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, job.st), "H2D");
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
     }
-    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, job.st);
-    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, job.st);
+    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, c->stream);
+    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, c->stream);
     if (rc) return rc;
-    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, job.st), "D2H");
+    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     return 0;
 }
 // returns 1 / 0 / <0; always gives the context back.  bitmap (optional): ceil(n/8) bytes.
@@ -1131,14 +1136,13 @@ int hs::host_finish(host_job &job, uint8_t *bitmap) {
     job.c = nullptr;
     struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
-    HS_HIP(hipStreamSynchronize(job.st ? job.st : c->stream), "stream sync");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
     if (bitmap) memcpy(bitmap, c->h_out, (job.n + 7) / 8);
     return bitmap_all_ones(c->h_out, job.n) ? 1 : 0;
 }
 void hs::host_abandon(host_job &job) {
     if (!job.c) return;
     (void)hipSetDevice(job.c->device);
-    if (job.st) (void)hipStreamSynchronize(job.st);
     (void)hipStreamSynchronize(job.c->stream);
     pool_put(job.c);
     job.c = nullptr;
@@ -1184,11 +1188,11 @@ static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uin
     if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!hq_rounds || !pks_or_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_tc: null pointer");
     hs_ed25519_ctx *c = nullptr;
-    int rc = pool_get(&c, ks ? ks->slot : 0);
+    int rc = pool_get(&c, ks ? ks->slot : 0, n);
     if (rc) return rc;
     struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
-    const size_t hint = g_max_batch.load();
+    const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
     rc = ctx_reserve(c, n > hint ? n : hint, true);
     if (rc) return rc;
     // staging (128 B per signature available): [hq: 8n][keys: 32n or 4n][sigs: 64n]

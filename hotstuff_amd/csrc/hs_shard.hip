@@ -156,25 +156,24 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
             for (int s = 0; s < k && !rc; s++) {
                 hs_ed25519_ctx *c = jobs[s].c;
                 if (!c) {      // an empty shard still takes part in the collective: borrow a context for its stream
-                    rc = pool_get(&jobs[s].c, s); c = jobs[s].c; jobs[s].n = 0;
+                    rc = pool_get(&jobs[s].c, s, (size_t)-1); c = jobs[s].c; jobs[s].n = 0;
                     if (rc) break;
                 }
-                if (!jobs[s].st) jobs[s].st = c->stream;
                 if (hipSetDevice(c->device) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
                 // slice = the first slice_bytes of the gather buffer's own slot region, filled on the stream
                 send[s] = s_gather[s] + (size_t)s * slice_bytes;
-                hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, jobs[s].st);
+                hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, jobs[s].c->stream);
                 if (e == hipSuccess && jobs[s].n) {
                     const uint8_t *src = jobs[s].zc ? c->h_out : c->d_out;
                     e = hipMemcpyAsync(send[s], src, bitmap_bytes(jobs[s].n) < slice_bytes ? bitmap_bytes(jobs[s].n) : slice_bytes,
-                                       jobs[s].zc ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, jobs[s].st);
+                                       jobs[s].zc ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, jobs[s].c->stream);
                 }
                 if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the slice", e);
             }
             if (!rc) {
                 ncclResult_t r = s_rccl.GroupStart();
                 for (int s = 0; s < k && r == ncclSuccess; s++)
-                    r = s_rccl.AllGather(send[s], s_gather[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].st);   // in place
+                    r = s_rccl.AllGather(send[s], s_gather[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].c->stream);   // in place
                 const ncclResult_t r2 = s_rccl.GroupEnd();
                 if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather", r != ncclSuccess ? r : r2);
             }
@@ -182,7 +181,7 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
                 gathered->assign((size_t)k * slice_bytes, 0);
                 hs_ed25519_ctx *c0 = jobs[0].c;
                 if (hipSetDevice(c0->device) != hipSuccess ||
-                    hipMemcpyAsync(gathered->data(), s_gather[0], gathered->size(), hipMemcpyDeviceToHost, jobs[0].st) != hipSuccess)
+                    hipMemcpyAsync(gathered->data(), s_gather[0], gathered->size(), hipMemcpyDeviceToHost, jobs[0].c->stream) != hipSuccess)
                     rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: reading the gathered bitmap");
             }
         }

@@ -13,6 +13,17 @@
 //   consensus/src/error.rs                 the ConsensusError variants this path can return
 //   consensus/src/messages.rs:164-208      QC { hash, round, votes }, digest, verify
 //   consensus/src/messages.rs:283-315      TC { round, votes }, verify
+//   consensus/src/messages.rs:15-90        Block { qc, tc, author, round, payload, signature }, digest, verify
+//   consensus/src/messages.rs:112-156      Vote { hash, round, author, signature }, digest, verify
+//   consensus/src/messages.rs:211-275      Timeout { high_qc, round, author, signature }, digest, verify
+// and the two callers either side of the path that SURVEY.md 8f ranks first (protocol-neutral changes
+// on the consensus side; INTEGRATION.md section 6 has the Rust patch):
+//   VoteIngest        consensus/src/core.rs:203-225 + aggregator.rs:74-94: accumulate votes, verify them in one call
+//   VerifiedQCCache   consensus/src/messages.rs:261-263 / core.rs:227-238: a timeout storm verifies each distinct
+//                     high_qc once
+// Small calls: below hs_ed25519_min_gpu_batch() a call is cheaper on one CPU core than the
+// GPU round trip.  The Rust shim keeps those on dalek; this mirror has no CPU implementation of its own (the product
+// never links the test oracle), so the policy is a hook: SmallBatch::cpu_verify, when set, receives such calls.
 //
 // Rust's Result<(), E> becomes a small value type with is_ok() / is_err() so that the parity
 // tests read like the reference's own (crypto_tests.rs, messages_tests.rs).  There is no CPU
@@ -21,7 +32,9 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <list>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <tuple>
@@ -63,6 +76,17 @@ inline bool ensure_init() {
 }
 }  // namespace detail
 
+// SURVEY.md 8a row A7.  threshold(): the measured crossover the library reports (bench.py
+// `small_batch_crossover`); cpu_verify: the CPU path of the embedding program (the Rust shim: dalek), same
+// contract as hs_ed25519_verify_multi (digest_stride 32) / _shared (0); null = everything goes to the GPU.
+struct SmallBatch {
+    using CpuVerify = int (*)(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
+                              size_t n, uint32_t mode, uint8_t *bitmap);
+    static CpuVerify &cpu_verify() { static CpuVerify f = nullptr; return f; }
+    static size_t threshold(bool keys_registered) { return hs_ed25519_min_gpu_batch(keys_registered ? 1 : 0); }
+    static bool on_cpu(size_t n, bool keys_registered) { return cpu_verify() && n > 0 && n < threshold(keys_registered); }
+};
+
 struct Signature {
     std::array<uint8_t, 32> part1{}, part2{};             // R, s.  Default = 64 zero bytes (lib.rs Default derive)
 
@@ -80,23 +104,53 @@ struct Signature {
     }
     // lib.rs:200-204: ed25519-dalek verify_strict
     CryptoResult verify(const Digest &digest, const PublicKey &public_key) const {
-        if (!detail::ensure_init()) return CryptoResult{false};
         const auto sig = flatten();
+        if (SmallBatch::on_cpu(1, false))                  // one signature: the CPU path when the embedder provides one
+            return detail::to_result(SmallBatch::cpu_verify()(digest.b.data(), 32, public_key.b.data(), sig.data(), 1,
+                                                              HS_ED25519_STRICT, nullptr));
+        if (!detail::ensure_init()) return CryptoResult{false};
         return detail::to_result(hs_ed25519_verify_multi(digest.b.data(), public_key.b.data(), sig.data(), 1,
                                                          HS_ED25519_STRICT, nullptr));
     }
     // lib.rs:206-219: one digest shared by every (key, signature) pair; an empty batch is Ok.
     // Vec<(PublicKey, Signature)> has no guaranteed layout, so the votes are copied into packed buffers.
     static CryptoResult verify_batch(const Digest &digest, const std::vector<std::pair<PublicKey, Signature>> &votes) {
-        if (!detail::ensure_init()) return CryptoResult{false};
         std::vector<uint8_t> pks(32 * votes.size()), sigs(64 * votes.size());
         for (size_t i = 0; i < votes.size(); i++) {
             std::memcpy(&pks[32 * i], votes[i].first.b.data(), 32);
             std::memcpy(&sigs[64 * i], votes[i].second.part1.data(), 32);
             std::memcpy(&sigs[64 * i + 32], votes[i].second.part2.data(), 32);
         }
+        if (SmallBatch::on_cpu(votes.size(), false))       // e.g. the 3 votes of a 4-node committee
+            return detail::to_result(SmallBatch::cpu_verify()(digest.b.data(), 0, pks.data(), sigs.data(), votes.size(),
+                                                              HS_ED25519_BATCH, nullptr));
+        if (!detail::ensure_init()) return CryptoResult{false};
+        // dalek's verify_batch as it is computed (one random linear combination), per-signature localisation
+        // inside the same call; below hs_ed25519_rlc_min_batch() the engine runs the per-signature kernels alone
         return detail::to_result(hs_ed25519_verify_shared(digest.b.data(), pks.data(), sigs.data(), votes.size(),
-                                                          HS_ED25519_BATCH, nullptr));
+                                                          HS_ED25519_BATCH_RLC, nullptr));
+    }
+    // One digest per pair, strict semantics: the batched form of a loop of verify() calls (what VoteIngest and
+    // TC::verify need).  Returns the per-pair verdicts; empty on an engine error.
+    static std::vector<bool> verify_many(const std::vector<Digest> &digests,
+                                         const std::vector<std::pair<PublicKey, Signature>> &votes) {
+        const size_t n = votes.size();
+        std::vector<bool> out;
+        if (n == 0 || digests.size() != n) return out;
+        std::vector<uint8_t> dg(32 * n), pks(32 * n), sigs(64 * n), bm((n + 7) / 8, 0);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&dg[32 * i], digests[i].b.data(), 32);
+            std::memcpy(&pks[32 * i], votes[i].first.b.data(), 32);
+            const auto f = votes[i].second.flatten();
+            std::memcpy(&sigs[64 * i], f.data(), 64);
+        }
+        int rc;
+        if (SmallBatch::on_cpu(n, false)) rc = SmallBatch::cpu_verify()(dg.data(), 32, pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data());
+        else rc = detail::ensure_init() ? hs_ed25519_verify_multi(dg.data(), pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data()) : -1;
+        if (rc < 0) return out;
+        out.resize(n);
+        for (size_t i = 0; i < n; i++) out[i] = (bm[i >> 3] >> (i & 7)) & 1;
+        return out;
     }
 };
 
@@ -175,6 +229,31 @@ inline ConsensusResult check_quorum(const Votes &votes, NameOf name_of, const Co
     }
     if (weight < committee.quorum_threshold()) return ConsensusResult::Err(too_light);
     return ConsensusResult::Ok();
+}
+// SHA-512 of an arbitrary-length message, truncated to 32 bytes (Block::digest hashes author, round, every
+// payload digest and the parent: more than one block)
+inline Digest sha512_32_long(const std::vector<uint8_t> &msg) {
+    const hs::u64 H0[8] = HS_SHA512_H0_INIT;
+    hs::u64 st[8];
+    for (int i = 0; i < 8; i++) st[i] = H0[i];
+    std::vector<uint8_t> m(msg);
+    const uint64_t bits = 8 * (uint64_t)msg.size();
+    m.push_back(0x80);
+    while (m.size() % 128 != 112) m.push_back(0);
+    for (int i = 0; i < 8; i++) m.push_back(0);                                  // high 64 bits of the length
+    for (int i = 7; i >= 0; i--) m.push_back((uint8_t)(bits >> (8 * i)));
+    for (size_t off = 0; off < m.size(); off += 128) {
+        hs::u64 w[16], s2[8];
+        for (int i = 0; i < 16; i++) { w[i] = 0; for (int j = 0; j < 8; j++) w[i] = (w[i] << 8) | m[off + 8 * i + j]; }
+        for (int i = 0; i < 8; i++) s2[i] = st[i];
+        hs::sha512_rounds16<false>(s2, w, 0);
+        for (int r = 16; r < 80; r += 16) hs::sha512_rounds16<true>(s2, w, r);
+        for (int i = 0; i < 8; i++) st[i] += s2[i];
+    }
+    Digest d;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) d.b[8 * i + j] = (uint8_t)(st[i] >> (56 - 8 * j));
+    return d;
 }
 inline Digest sha512_32(const uint8_t *msg, size_t len) {  // len <= 111: one padded block
     hs::u64 w[16] = {0}, hh[8];
@@ -256,6 +335,176 @@ struct TC {                                                // messages.rs:283-28
             rc = hs_ed25519_verify_tc(round, hq.data(), pks.data(), sigs.data(), votes.size(), nullptr);
         }
         return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
+    }
+};
+
+// ---- single-signature messages ------------------------------------------
+struct Vote {                                              // messages.rs:112-118
+    Digest hash;
+    Round round = 0;
+    PublicKey author;
+    Signature signature;
+    Digest digest() const {                                // messages.rs:149-156: SHA-512(hash || round_le)[..32]
+        uint8_t m[40];
+        std::memcpy(m, hash.b.data(), 32);
+        for (int i = 0; i < 8; i++) m[32 + i] = (uint8_t)(round >> (8 * i));
+        return detail::sha512_32(m, 40);
+    }
+    ConsensusResult verify(const Committee &committee) const {       // messages.rs:136-146
+        if (committee.stake(author) == 0) return ConsensusResult::Err(ConsensusError::UnknownAuthority, author);
+        return signature.verify(digest(), author).is_ok() ? ConsensusResult::Ok()
+                                                          : ConsensusResult::Err(ConsensusError::InvalidSignature);
+    }
+};
+
+// core.rs:203-225 + aggregator.rs:74-94, batched.  The reference verifies each incoming vote singly on the Core
+// task, then QCMaker::append marks the author used and adds its stake.  Here the structural checks run at
+// arrival, signatures wait, and ONE call verifies everything pending as soon as the pending + verified stake
+// could form a quorum (or max_pending is reached).  As in the reference an author is `used` only once a signature
+// from it has VERIFIED: a forged vote naming authority X is dropped by the flush and X's genuine vote still
+// counts.  AuthorityReuse is returned where the reference returns it: for a vote whose author already has an
+// accepted vote.  Invalid votes are dropped individually (the per-signature bitmap says which) - the set the
+// reference drops one by one.  The QC is made once.
+struct VoteIngest {
+    using Verifier = std::vector<bool> (*)(const std::vector<Digest> &, const std::vector<std::pair<PublicKey, Signature>> &);
+    const Committee &committee;
+    Verifier verifier = &Signature::verify_many;           // injectable (tests: the oracle)
+    size_t max_pending = 0;
+    std::set<PublicKey> used;
+    std::vector<Vote> pending;
+    std::vector<std::pair<PublicKey, Signature>> valid;
+    std::vector<PublicKey> dropped;
+    Stake valid_weight = 0;
+    bool done = false, started = false;
+    size_t verify_calls = 0;
+    Digest hash;
+    Round round = 0;
+
+    explicit VoteIngest(const Committee &c, size_t max_pending_ = 0) : committee(c), max_pending(max_pending_) {}
+
+    struct Outcome { ConsensusResult status; std::unique_ptr<QC> qc; };   // qc set the first time a quorum verified
+
+    Outcome add_vote(const Vote &v) {
+        if (!started) { hash = v.hash; round = v.round; started = true; }
+        if (committee.stake(v.author) == 0) return {ConsensusResult::Err(ConsensusError::UnknownAuthority, v.author), nullptr};
+        if (used.count(v.author)) return {ConsensusResult::Err(ConsensusError::AuthorityReuse, v.author), nullptr};
+        if (done) return {ConsensusResult::Ok(), nullptr};
+        for (const Vote &p : pending)                      // byte-identical to a candidate already waiting
+            if (p.author == v.author && p.signature.flatten() == v.signature.flatten()) return {ConsensusResult::Ok(), nullptr};
+        pending.push_back(v);
+        std::set<PublicKey> authors;
+        Stake pend = 0;
+        for (const Vote &p : pending) if (authors.insert(p.author).second) pend += committee.stake(p.author);
+        if (valid_weight + pend >= committee.quorum_threshold() || (max_pending && pending.size() >= max_pending)) return flush();
+        return {ConsensusResult::Ok(), nullptr};
+    }
+    Outcome flush() {
+        if (!pending.empty()) {
+            std::vector<Digest> dg;
+            std::vector<std::pair<PublicKey, Signature>> votes;
+            for (const Vote &p : pending) { dg.push_back(p.digest()); votes.push_back({p.author, p.signature}); }
+            const std::vector<bool> ok = verifier(dg, votes);
+            verify_calls++;
+            if (ok.size() != pending.size()) { pending.clear(); return {ConsensusResult::Err(ConsensusError::InvalidSignature), nullptr}; }   // engine error: never Ok
+            for (size_t i = 0; i < pending.size(); i++) {
+                if (ok[i] && !used.count(pending[i].author)) {
+                    used.insert(pending[i].author);
+                    valid.push_back(votes[i]);
+                    valid_weight += committee.stake(pending[i].author);
+                } else if (!ok[i]) {
+                    dropped.push_back(pending[i].author);  // the reference warns and drops (core.rs:434-439)
+                }
+            }
+            pending.clear();
+        }
+        if (!done && valid_weight >= committee.quorum_threshold()) {
+            done = true;                                   // QCMaker: "ensures QC is only made once"
+            std::unique_ptr<QC> qc(new QC());
+            qc->hash = hash; qc->round = round; qc->votes = valid;
+            return {ConsensusResult::Ok(), std::move(qc)};
+        }
+        return {ConsensusResult::Ok(), nullptr};
+    }
+};
+
+// messages.rs:261-263 / core.rs:227-238: every received timeout re-verifies its embedded high_qc - up to N
+// identical batch verifications of 2f+1 signatures per view change.  Fingerprints of QCs that verified, LRU.
+struct VerifiedQCCache {
+    size_t capacity;
+    size_t hits = 0, misses = 0;
+    explicit VerifiedQCCache(size_t cap = 1024) : capacity(cap) {}
+    static Digest fingerprint(const QC &qc) {
+        std::vector<uint8_t> m(qc.hash.b.begin(), qc.hash.b.end());
+        for (int i = 0; i < 8; i++) m.push_back((uint8_t)(qc.round >> (8 * i)));
+        const uint64_t n = qc.votes.size();
+        for (int i = 0; i < 8; i++) m.push_back((uint8_t)(n >> (8 * i)));
+        for (const auto &v : qc.votes) {
+            m.insert(m.end(), v.first.b.begin(), v.first.b.end());
+            const auto f = v.second.flatten();
+            m.insert(m.end(), f.begin(), f.end());
+        }
+        return detail::sha512_32_long(m);
+    }
+    // QC::verify with memoisation; failures are not cached
+    ConsensusResult verify(const QC &qc, const Committee &committee) {
+        const Digest fp = fingerprint(qc);
+        const auto it = index_.find(fp.b);
+        if (it != index_.end()) { order_.splice(order_.begin(), order_, it->second); hits++; return ConsensusResult::Ok(); }
+        misses++;
+        const ConsensusResult r = qc.verify(committee);
+        if (r.is_err()) return r;
+        order_.push_front(fp.b);
+        index_[fp.b] = order_.begin();
+        if (order_.size() > capacity) { index_.erase(order_.back()); order_.pop_back(); }
+        return r;
+    }
+ private:
+    std::list<std::array<uint8_t, 32>> order_;
+    std::map<std::array<uint8_t, 32>, std::list<std::array<uint8_t, 32>>::iterator> index_;
+};
+
+struct Timeout {                                           // messages.rs:211-216
+    QC high_qc;
+    Round round = 0;
+    PublicKey author;
+    Signature signature;
+    Digest digest() const {                                // messages.rs:268-275: SHA-512(round_le || high_qc.round_le)[..32]
+        uint8_t m[16];
+        for (int i = 0; i < 8; i++) { m[i] = (uint8_t)(round >> (8 * i)); m[8 + i] = (uint8_t)(high_qc.round >> (8 * i)); }
+        return detail::sha512_32(m, 16);
+    }
+    ConsensusResult verify(const Committee &committee, VerifiedQCCache *qc_cache = nullptr) const {   // messages.rs:250-265
+        if (committee.stake(author) == 0) return ConsensusResult::Err(ConsensusError::UnknownAuthority, author);
+        if (signature.verify(digest(), author).is_err()) return ConsensusResult::Err(ConsensusError::InvalidSignature);
+        // `high_qc != QC::genesis()`: QC's PartialEq compares hash and round only (messages.rs:217-221)
+        if (high_qc.round != 0 || high_qc.hash != Digest{}) return qc_cache ? qc_cache->verify(high_qc, committee) : high_qc.verify(committee);
+        return ConsensusResult::Ok();
+    }
+};
+
+struct Block {                                             // messages.rs:15-24
+    QC qc;
+    std::unique_ptr<TC> tc;                                // Option<TC>
+    PublicKey author;
+    Round round = 0;
+    std::vector<Digest> payload;
+    Signature signature;
+    Digest digest() const {                                // messages.rs:79-90: SHA-512(author || round_le || payload... || qc.hash)[..32]
+        std::vector<uint8_t> m(author.b.begin(), author.b.end());
+        for (int i = 0; i < 8; i++) m.push_back((uint8_t)(round >> (8 * i)));
+        for (const Digest &x : payload) m.insert(m.end(), x.b.begin(), x.b.end());
+        m.insert(m.end(), qc.hash.b.begin(), qc.hash.b.end());
+        return detail::sha512_32_long(m);
+    }
+    ConsensusResult verify(const Committee &committee) const {       // messages.rs:55-76
+        if (committee.stake(author) == 0) return ConsensusResult::Err(ConsensusError::UnknownAuthority, author);
+        if (signature.verify(digest(), author).is_err()) return ConsensusResult::Err(ConsensusError::InvalidSignature);
+        if (qc.round != 0 || qc.hash != Digest{}) {        // != QC::genesis()
+            const ConsensusResult r = qc.verify(committee);
+            if (r.is_err()) return r;
+        }
+        if (tc) return tc->verify(committee);
+        return ConsensusResult::Ok();
     }
 };
 

@@ -308,6 +308,15 @@ int hs_ed25519_verify_multi_sharded_cached(const hs_ed25519_keyset_sharded *kss,
                                            const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
                                            uint8_t *bitmap);
 
+/* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or
+ * hs_ed25519_verify_shared (0) in a loop for `seconds`, thread t on batch t mod nbatches of the caller's
+ * packed host buffers (nbatches x n tuples, all valid).  Reports completed calls, the median call latency
+ * and the elapsed time.  This is SURVEY.md 8d's end-to-end metric - host buffers in, host verdict out -
+ * without an interpreter in the loop. */
+int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                       size_t nbatches, uint32_t mode, unsigned threads, double seconds, uint64_t *calls_out,
+                       double *p50_ms_out, double *elapsed_s_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,10 @@ struct Fixture {
     Digest digest, bad_digest, qc_hash, qc_digest;
     Signature sig[4], qc_sig[4], tc_sig[4];
     Round qc_round, tc_round, tc_hq[4];
+    // second part: single-signature messages and the callers either side of the path
+    Digest vote_hash, block_payload[2], block_digest;
+    Round vote_round, timeout_round, block_round;
+    Signature vote_sig[4], timeout_sig[4], block_sig;
 };
 static bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
 static bool load(const char *path, Fixture &x) {
@@ -31,6 +35,13 @@ static bool load(const char *path, Fixture &x) {
     for (auto &g : x.qc_sig) { ok = ok && rd(f, s, 64); g = Signature::from_bytes(s); }
     ok = ok && rd(f, x.unknown.b.data(), 32) && rd(f, &x.tc_round, 8) && rd(f, x.tc_hq, 32);
     for (auto &g : x.tc_sig) { ok = ok && rd(f, s, 64); g = Signature::from_bytes(s); }
+    ok = ok && rd(f, x.vote_hash.b.data(), 32) && rd(f, &x.vote_round, 8);
+    for (auto &g : x.vote_sig) { ok = ok && rd(f, s, 64); g = Signature::from_bytes(s); }
+    ok = ok && rd(f, &x.timeout_round, 8);
+    for (auto &g : x.timeout_sig) { ok = ok && rd(f, s, 64); g = Signature::from_bytes(s); }
+    ok = ok && rd(f, &x.block_round, 8) && rd(f, x.block_payload[0].b.data(), 32) && rd(f, x.block_payload[1].b.data(), 32)
+            && rd(f, x.block_digest.b.data(), 32) && rd(f, s, 64);
+    x.block_sig = Signature::from_bytes(s);
     fclose(f);
     return ok;
 }
@@ -149,6 +160,84 @@ int main(int argc, char **argv) {
         CHECK("tampered high_qc_round is InvalidSignature (key cache)", r.is_err() && r.err.kind == ConsensusError::InvalidSignature);
     }
     committee.drop_key_cache();
+
+    // ---- single-signature messages (messages.rs:55-76, 136-146, 250-265)
+    auto vote = [&](int i) { Vote v; v.hash = x.vote_hash; v.round = x.vote_round; v.author = x.pk[i]; v.signature = x.vote_sig[i]; return v; };
+    CHECK("Vote::verify valid", vote(2).verify(committee).is_ok());
+    { Vote v = vote(2); v.round += 1; const ConsensusResult r = v.verify(committee);
+      CHECK("Vote for another round is InvalidSignature", r.is_err() && r.err.kind == ConsensusError::InvalidSignature); }
+    { Vote v = vote(2); v.author = x.unknown; const ConsensusResult r = v.verify(committee);
+      CHECK("Vote of a stranger is UnknownAuthority", r.is_err() && r.err.kind == ConsensusError::UnknownAuthority); }
+    {
+        Block b; b.qc = qc(); b.author = x.pk[0]; b.round = x.block_round; b.payload = {x.block_payload[0], x.block_payload[1]};
+        b.signature = x.block_sig;
+        CHECK("Block::digest is SHA-512(author || round_le || payload || qc.hash)[..32]", b.digest() == x.block_digest);
+        CHECK("Block::verify valid (signature + embedded QC)", b.verify(committee).is_ok());
+        b.tc.reset(new TC(tc()));
+        CHECK("Block::verify valid with an embedded TC", b.verify(committee).is_ok());
+        std::get<2>(b.tc->votes[0]) += 1;
+        CHECK("Block with a bad embedded TC is InvalidSignature", b.verify(committee).is_err());
+        b.tc.reset();
+        b.payload.pop_back();
+        const ConsensusResult r = b.verify(committee);
+        CHECK("Block with a tampered payload is InvalidSignature", r.is_err() && r.err.kind == ConsensusError::InvalidSignature);
+    }
+    // ---- VoteIngest (core.rs:203-225 + aggregator.rs:74-94, batched)
+    {
+        VoteIngest ing(committee);
+        Vote forged[3];
+        for (int i = 0; i < 3; i++) { forged[i] = vote(i); forged[i].signature.part1[0] ^= 1; }
+        bool none = true;
+        for (int i = 0; i < 3; i++) { auto o = ing.add_vote(forged[i]); none = none && o.status.is_ok() && !o.qc; }
+        CHECK("VoteIngest: three forgeries could form a quorum -> one call, all three dropped", none && ing.verify_calls == 1
+              && ing.dropped.size() == 3 && ing.used.empty());
+        auto o0 = ing.add_vote(vote(0));                   // the genuine votes of the same authorities are still welcome
+        auto o1 = ing.add_vote(vote(1));
+        auto dup = ing.add_vote(vote(1));                  // byte-identical duplicate of a waiting candidate: ignored
+        CHECK("VoteIngest: a dropped forgery does not lock its authority out", o0.status.is_ok() && o1.status.is_ok() && dup.status.is_ok()
+              && !o0.qc && !o1.qc && !dup.qc && ing.pending.size() == 2);
+        auto o2 = ing.add_vote(vote(2));
+        CHECK("VoteIngest: QC made once, from exactly the verified votes", o2.qc && o2.qc->votes.size() == 3 && ing.verify_calls == 2
+              && o2.qc->verify(committee).is_ok());
+        const auto again = ing.add_vote(forged[0]);
+        CHECK("VoteIngest: AuthorityReuse only after a signature from the author verified",
+              again.status.is_err() && again.status.err.kind == ConsensusError::AuthorityReuse);
+        const auto late = ing.add_vote(vote(3));
+        CHECK("VoteIngest: late votes after the QC need no verification", late.status.is_ok() && !late.qc && ing.verify_calls == 2);
+    }
+    // ---- Timeout::verify and the verified-QC cache (messages.rs:250-265, core.rs:227-238)
+    {
+        VerifiedQCCache cache;
+        bool all_ok = true;
+        for (int i = 0; i < 4; i++) {
+            Timeout t; t.high_qc = qc(); t.round = x.timeout_round; t.author = x.pk[i]; t.signature = x.timeout_sig[i];
+            all_ok = all_ok && t.verify(committee, &cache).is_ok();
+        }
+        CHECK("timeout storm: four timeouts, the shared high_qc verified once", all_ok && cache.misses == 1 && cache.hits == 3);
+        Timeout bad; bad.high_qc = qc(); bad.high_qc.votes[1].second = x.qc_sig[0]; bad.round = x.timeout_round; bad.author = x.pk[0];
+        bad.signature = x.timeout_sig[0];
+        const ConsensusResult r1 = bad.verify(committee, &cache), r2 = bad.verify(committee, &cache);
+        CHECK("a forged high_qc is rejected every time (failures are not cached)", r1.is_err() && r2.is_err() && cache.misses == 3);
+        Timeout g; g.round = x.timeout_round; g.author = x.pk[0]; g.signature = x.timeout_sig[0];
+        g.high_qc.votes.push_back({x.pk[0], Signature{}});   // hash 0 / round 0 = genesis by QC's PartialEq, votes ignored
+        const ConsensusResult rg = g.verify(committee, &cache);
+        CHECK("Timeout: high_qc equal to genesis by (hash, round) is not verified", rg.is_err() && rg.err.kind == ConsensusError::InvalidSignature && cache.misses == 3);
+    }
+    // ---- the small-batch policy hook
+    {
+        static int cpu_calls = 0;
+        SmallBatch::cpu_verify() = [](const uint8_t *, size_t, const uint8_t *, const uint8_t *, size_t n, uint32_t, uint8_t *bm) -> int {
+            cpu_calls++; if (bm) std::memset(bm, 0xff, (n + 7) / 8); return 1; };
+        const size_t th = SmallBatch::threshold(false);
+        CHECK("hs_ed25519_min_gpu_batch() is a small positive number", th >= 2 && th <= 64 && SmallBatch::threshold(true) <= th);
+        const bool one = x.sig[3].verify(x.bad_digest, x.pk[3]).is_ok();          // the stub says Ok: proves the call went to the hook
+        std::vector<std::pair<PublicKey, Signature>> three;
+        for (int i = 1; i <= 3; i++) three.push_back({x.pk[i], x.sig[i]});
+        const bool b3 = Signature::verify_batch(x.bad_digest, three).is_ok();
+        CHECK("calls below the threshold go to the embedder's CPU path when one is set", one && b3 && cpu_calls == 2);
+        SmallBatch::cpu_verify() = nullptr;
+        CHECK("without a CPU path every call goes to the GPU", x.sig[3].verify(x.bad_digest, x.pk[3]).is_err());
+    }
     hs_ed25519_shutdown();
     printf("%d failed\n", failures);
     return failures;

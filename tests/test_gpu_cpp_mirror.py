@@ -38,6 +38,20 @@ def _fixture(tmp_path):
     tc_sigs = [synth.sign(s, hashlib.sha512(struct.pack("<QQ", tc_round, hq)).digest()[:32])[1] for s, hq in zip(seeds, tc_hq)]
     blob = (b"".join(pks) + digest + bad_digest + b"".join(sigs) + qc_hash + struct.pack("<Q", qc_round) + qc_digest
             + b"".join(qc_sigs) + unknown + struct.pack("<Q", tc_round) + struct.pack("<4Q", *tc_hq) + b"".join(tc_sigs))
+    # single-signature messages: votes over SHA-512(hash || round), timeouts over SHA-512(round || high_qc.round),
+    # a block by authority 0 over SHA-512(author || round || payload... || qc.hash) - messages.rs:79-90, 149-156, 268-275
+    vote_hash, vote_round = hashlib.sha512(b"a block").digest()[:32], 11
+    vote_digest = hashlib.sha512(vote_hash + struct.pack("<Q", vote_round)).digest()[:32]
+    vote_sigs = [synth.sign(s, vote_digest)[1] for s in seeds]
+    timeout_round = 12
+    timeout_digest = hashlib.sha512(struct.pack("<QQ", timeout_round, qc_round)).digest()[:32]
+    timeout_sigs = [synth.sign(s, timeout_digest)[1] for s in seeds]
+    block_round = 13
+    payload = [hashlib.sha512(b"batch %d" % i).digest()[:32] for i in range(2)]
+    block_digest = hashlib.sha512(pks[0] + struct.pack("<Q", block_round) + b"".join(payload) + qc_hash).digest()[:32]
+    block_sig = synth.sign(seeds[0], block_digest)[1]
+    blob += (vote_hash + struct.pack("<Q", vote_round) + b"".join(vote_sigs) + struct.pack("<Q", timeout_round)
+             + b"".join(timeout_sigs) + struct.pack("<Q", block_round) + b"".join(payload) + block_digest + block_sig)
     path = str(tmp_path / "fixture.bin")
     with open(path, "wb") as f:
         f.write(blob)
@@ -54,7 +68,7 @@ def _run(tmp_path):
 def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
     assert torch.cuda.is_available()
     rc, cases = _run(tmp_path)
-    assert len(cases) == 23, cases
+    assert len(cases) == 41, cases
     assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
 
 
@@ -67,9 +81,16 @@ def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
     rc, cases = _run(tmp_path)
     for name in ("committee quorum_threshold is 3 of 4", "QC::digest is SHA-512(hash || round_le)[..32]",
                  "verify_qc_authority_reuse", "verify_qc_unknown_authority", "verify_qc_insufficient_stake",
-                 "verify_tc_insufficient_stake", "verify_invalid_signature", "verify_invalid_batch"):
+                 "verify_tc_insufficient_stake", "verify_invalid_signature", "verify_invalid_batch",
+                 "Block::digest is SHA-512(author || round_le || payload || qc.hash)[..32]",
+                 "Vote of a stranger is UnknownAuthority", "hs_ed25519_min_gpu_batch() is a small positive number",
+                 "calls below the threshold go to the embedder's CPU path when one is set",
+                 "without a CPU path every call goes to the GPU"):
         assert cases[name], name
     for name in ("verify_valid_signature", "verify_valid_batch", "verify_valid_qc", "verify_valid_tc",
-                 "committee.cache_keys()", "verify_valid_qc (key cache)", "verify_valid_tc (key cache)"):
+                 "committee.cache_keys()", "verify_valid_qc (key cache)", "verify_valid_tc (key cache)",
+                 "Vote::verify valid", "Block::verify valid (signature + embedded QC)",
+                 "VoteIngest: QC made once, from exactly the verified votes",
+                 "timeout storm: four timeouts, the shared high_qc verified once"):
         assert not cases[name], name          # would need the GPU: must not be Ok
     assert rc != 0
