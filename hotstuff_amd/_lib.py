@@ -90,6 +90,18 @@ def lib():
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                                  ctypes.POINTER(ctypes.c_double)]
                 l.hs_ed25519_loadgen.restype = ctypes.c_int
+                l.hs_ed25519_verify_wire_shared.argtypes = [vp, vp, sz, u32, vp]
+                l.hs_ed25519_verify_wire_shared.restype = ctypes.c_int
+                l.hs_ed25519_verify_wire_tc.argtypes = [u64, vp, sz, vp]
+                l.hs_ed25519_verify_wire_tc.restype = ctypes.c_int
+                l.hs_ed25519_wire_decode_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+                l.hs_ed25519_wire_decode_device.restype = ctypes.c_int
+                l.hs_ed25519_sign_batch.argtypes = [vp, vp, sz, sz, vp]
+                l.hs_ed25519_sign_batch.restype = ctypes.c_int
+                l.hs_ed25519_sign_device.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+                l.hs_ed25519_sign_device.restype = ctypes.c_int
+                l.hs_ed25519_public_keys.argtypes = [vp, sz, vp]
+                l.hs_ed25519_public_keys.restype = ctypes.c_int
                 l.hs_ed25519_ctx_set_kernel.argtypes = [vp, ctypes.c_int]
                 l.hs_ed25519_ctx_set_kernel.restype = ctypes.c_int
                 l.hs_ed25519_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), sz, sz]
@@ -345,6 +357,41 @@ def verify_tc_packed(round_, hq_rounds, pks, sigs, keyset=None):
     check(rc, "hs_ed25519_verify_tc")
     del k1, k2, k3
     return rc == 1, bytes(bm)
+
+
+def verify_wire(frames, n, digest=None, mode=BATCH, tc_round=None):
+    """hs_ed25519_verify_wire_shared / _tc: QC (116-byte) or TC (124-byte) vote elements as they sit in the
+    received bincode frame.  Returns (all_ok, bitmap)."""
+    ensure_init()
+    if n == 0:
+        return True, b""
+    bm = (ctypes.c_ubyte * ((n + 7) // 8))()
+    pf, k1 = _buf(frames)
+    if tc_round is None:
+        pd, k2 = _buf(digest)
+        rc = lib().hs_ed25519_verify_wire_shared(pd, pf, n, mode, ctypes.cast(bm, ctypes.c_void_p))
+    else:
+        rc = lib().hs_ed25519_verify_wire_tc(int(tc_round), pf, n, ctypes.cast(bm, ctypes.c_void_p))
+    check(rc, "hs_ed25519_verify_wire")
+    return rc == 1, bytes(bm)
+
+
+def sign_batch(secrets, digests, n, shared):
+    """hs_ed25519_sign_batch: n x 64-byte secrets (seed || pk), digests n x 32 or one -> n x 64 signature bytes."""
+    ensure_init()
+    out = (ctypes.c_ubyte * (64 * max(1, n)))()
+    ps, k1 = _buf(secrets)
+    pd, k2 = _buf(digests)
+    check(lib().hs_ed25519_sign_batch(ps, pd, 0 if shared else 32, n, ctypes.cast(out, ctypes.c_void_p)), "hs_ed25519_sign_batch")
+    return bytes(out)[:64 * n]
+
+
+def public_keys(seeds, n):
+    ensure_init()
+    out = (ctypes.c_ubyte * (32 * max(1, n)))()
+    ps, k1 = _buf(seeds)
+    check(lib().hs_ed25519_public_keys(ps, n, ctypes.cast(out, ctypes.c_void_p)), "hs_ed25519_public_keys")
+    return bytes(out)[:32 * n]
 
 
 class Batch(ctypes.Structure):

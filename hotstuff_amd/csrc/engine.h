@@ -48,6 +48,8 @@ struct hs_ed25519_ctx {
     uint8_t *h_out = nullptr;     // pinned mirror of d_out
     hs::u32 *d_tc = nullptr;      // timeout-certificate digests built by k_tc_digests (tc_cap signatures)
     size_t tc_cap = 0;
+    uint8_t *d_wire = nullptr;    // hs_wire.hip: decoded (pk | sig | round) of wire frames, wire_cap signatures
+    size_t wire_cap = 0;
     bool staging = false;
     int kernel = HS_K_AUTO;       // per-context kernel choice (tests, A/B); HS_K_AUTO = by batch size
     void *rlc = nullptr;          // hs_rlc.hip: this context's MSM workspace (rlc_ws *), freed by rlc_release
@@ -85,6 +87,8 @@ int host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint
 int host_finish(host_job &job, uint8_t *bitmap);          // 1 / 0 / <0; returns the context to its pool
 void host_abandon(host_job &job);                          // after a failed submit
 const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap (valid until finish)
+// hs_wire.hip
+void wire_release(hs_ed25519_ctx *c);
 // hs_rlc.hip
 void rlc_release(hs_ed25519_ctx *c);
 int rlc_reserve(hs_ed25519_ctx *ctx, size_t n);     // all allocation of an n-signature RLC call, ahead of time

@@ -601,6 +601,7 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
     hs::rlc_release(c);
+    hs::wire_release(c);
     ctx_release(c);
     delete c;
 }

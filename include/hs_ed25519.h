@@ -308,6 +308,34 @@ int hs_ed25519_verify_multi_sharded_cached(const hs_ed25519_keyset_sharded *kss,
                                            const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint32_t mode,
                                            uint8_t *bitmap);
 
+/* ---- wire decode --------------------------------------------------------------
+ * votes: Vec<(PublicKey, Signature)> of a QC travels as n bincode elements of 116 bytes each -
+ * u64 LE 44 | 44 base64 characters (crypto/src/lib.rs:94-101 serialises a key as a string) | 64 signature
+ * bytes - and a TC's (PublicKey, Signature, Round) elements carry a u64 LE round more (124 bytes).  These
+ * take the elements as received: the base64 decode and the transposition into the packed arrays run on the
+ * device ahead of the verification kernels, on the same stream.  Contract: the canonical encoding the
+ * reference's serialiser always emits (length 44, standard alphabet, one '=', zero trailing bits); any other
+ * element is rejected whatever its signature says (bit i = 0) - the shim re-parses such a frame with the
+ * reference's own deserialiser.  Verdicts, bitmap and modes as hs_ed25519_verify_shared / _tc. */
+int hs_ed25519_verify_wire_shared(const uint8_t digest[32], const uint8_t *frames, size_t n, uint32_t mode, uint8_t *bitmap);
+int hs_ed25519_verify_wire_tc(uint64_t round, const uint8_t *frames, size_t n, uint8_t *bitmap);
+/* Decode only, device buffers: frame_bytes 116 (d_rounds may be NULL) or 124; d_pks n*32, d_sigs n*64 (16-byte
+ * aligned), d_rounds n uint64, *d_nbad incremented per non-canonical element (may be NULL). */
+int hs_ed25519_wire_decode_device(hs_ed25519_ctx *ctx, const uint8_t *d_frames, size_t frame_bytes, size_t n,
+                                  uint8_t *d_pks, uint8_t *d_sigs, uint64_t *d_rounds, uint32_t *d_nbad, void *stream);
+
+/* ---- batch signing for load generation -----------------------------------------
+ * Signature::new (crypto/src/lib.rs:185-191) = RFC 8032 5.1.6 with the key pair's stored public key, for n
+ * (secret, digest) pairs at once: secrets n x 64 bytes (seed || public key, the layout of crypto::SecretKey),
+ * digests n x 32 (digest_stride 32) or one shared (0), signatures n x 64 out - bit-identical to dalek / OpenSSL
+ * (signing is deterministic).  Not on a node's hot path (one signature per block / vote / timeout): it makes
+ * 10^5 - 10^6 signature synthetic sets take milliseconds.  hs_ed25519_public_keys derives n public keys from
+ * n 32-byte seeds.  Return 0 or HS_ED25519_E_*. */
+int hs_ed25519_sign_batch(const uint8_t *secrets, const uint8_t *digests, size_t digest_stride, size_t n, uint8_t *sigs_out);
+int hs_ed25519_sign_device(hs_ed25519_ctx *ctx, const uint8_t *d_secrets, const uint8_t *d_digests, size_t digest_stride,
+                           size_t n, uint8_t *d_sigs, void *stream);
+int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out);
+
 /* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or
  * hs_ed25519_verify_shared (0) in a loop for `seconds`, thread t on batch t mod nbatches of the caller's
  * packed host buffers (nbatches x n tuples, all valid).  Reports completed calls, the median call latency

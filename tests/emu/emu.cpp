@@ -8,6 +8,7 @@
 #include "../../hotstuff_amd/csrc/verify_quad.h"
 #include "../../hotstuff_amd/csrc/verify_cached.h"
 #include "../../hotstuff_amd/csrc/rlc.h"
+#include "../../hotstuff_amd/csrc/wire.h"
 using namespace hs;
 
 static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
@@ -262,5 +263,25 @@ void emu_rlc_coeff(const uint8_t *key32, const uint8_t *k32, const uint8_t *s32,
     u32 k[8], s[8], z[8]; load_words(k, k32, 8); load_words(s, s32, 8);
     rlc_coeff(z, key, k, s, index);
     memcpy(z16, z, 16);
+}
+
+// ---- wire decode and signing (wire.h) ----
+int emu_wire_decode(const uint8_t *frame116, uint8_t *pk32, uint8_t *sig64) {
+    u32 f[29], pk[8], sig[16]; memcpy(f, frame116, 116);
+    for (int i = 0; i < 8; i++) pk[i] = 0;
+    const bool ok = wire_decode_vote(pk, sig, f);
+    memcpy(pk32, pk, 32); memcpy(sig64, sig, 64);
+    return ok;
+}
+static std::vector<u32> &emu_btab() { static std::vector<u32> t; if (t.empty()) { t.resize(HS_KS_KEY_WORDS); emu_keyset_build_base(t.data()); } return t; }
+void emu_sign(const uint8_t *secret64, const uint8_t *msg32, uint8_t *sig64) {
+    u32 sk[16], m[8], sig[16]; memcpy(sk, secret64, 64); memcpy(m, msg32, 32);
+    sign_one(sig, sk, m, emu_btab().data());
+    memcpy(sig64, sig, 64);
+}
+void emu_public_key(const uint8_t *seed32, uint8_t *pk32) {
+    u32 sd[8], pk[8]; memcpy(sd, seed32, 32);
+    public_key_of(pk, sd, emu_btab().data());
+    memcpy(pk32, pk, 32);
 }
 }
