@@ -119,9 +119,11 @@ class Signature:
         try:
             if keyset is not None and all(k in keyset.index for k in keys):
                 packed, _ = keyset.indices(keys)
-                ok, _ = keyset.verify_packed(digest.b, packed, bytes(sigs), n, _lib.BATCH, shared=True)
+                ok, _ = keyset.verify_packed(digest.b, packed, bytes(sigs), n, _lib.BATCH_RLC, shared=True)
             else:
-                ok, _ = _lib.verify_packed(digest.b, bytes(pks), bytes(sigs), n, _lib.BATCH, shared=True)
+                # BATCH_RLC = dalek's verify_batch as computed (one random linear combination, MSM on the GPU) from
+                # hs_ed25519_rlc_min_batch() signatures up, the per-signature kernels below it and as its localiser
+                ok, _ = _lib.verify_packed(digest.b, bytes(pks), bytes(sigs), n, _lib.BATCH_RLC, shared=True)
         except _lib.EngineError as e:
             raise CryptoError(str(e)) from e
         if not ok:

@@ -1329,10 +1329,15 @@ static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
 }
 
 extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_t mode) {
-    if (!r || slot >= r->slots.size() || mode > 1) return fail(HS_ED25519_E_ARG, "ring_submit: bad arguments");
+    if (!r || slot >= r->slots.size() || mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "ring_submit: bad arguments");
     ring_slot &s = r->slots[slot];
     if (!s.begun || s.inflight) return fail(HS_ED25519_E_ARG, "ring_submit: slot not begun / already in flight");
     HS_HIP(hipSetDevice(s.ctx->device), "hipSetDevice");
+    if (mode == HS_ED25519_BATCH_RLC) {      // the MSM workspace is allocated here, never under graph capture
+        int rc = rlc_reserve(s.ctx, s.n);
+        if (rc) return rc;
+        if (!dev_base_table(s.ctx->slot)) return HS_ED25519_E_DEVICE;
+    }
     hipStream_t st = s.ctx->stream;
     // the verdict is read from the pinned bitmap: clear it so that a round whose kernels did not
     // write it can never be read as accepted (the zero-copy kernels write this memory directly)

@@ -329,8 +329,9 @@ rlc_key g_key;
 bool g_key_set = false;
 
 // Below this many signatures the pipeline (five stages, the last a 248-doubling chain on one quad) costs
-// more than the per-signature kernels (profiles/r2_rlc_ab.md): the call then runs plain BATCH.
-const size_t kRlcMinBatch = 16384;
+// more than the per-signature kernels: the call then runs plain BATCH.  profiles/r2_sweeps.md: the RLC path wins
+// throughput from ~12,000 signatures and latency from ~20,000 (0.67 vs 0.73 ms at 24,576; 0.91 vs 1.76 ms at 66,667).
+const size_t kRlcMinBatch = 20480;
 const u32 kTabWords = HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1);
 const u32 kMinChunk = 8;
 

@@ -297,7 +297,7 @@ struct QC {                                                // messages.rs:164-16
                 std::memcpy(&sigs[64 * i], f.data(), 64);
             }
             const int rc = hs_ed25519_verify_shared_cached(committee.keyset(), d.b.data(), idx.data(), sigs.data(), votes.size(),
-                                                           HS_ED25519_BATCH, nullptr);
+                                                           HS_ED25519_BATCH_RLC, nullptr);
             return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
         }
         return Signature::verify_batch(digest(), votes).is_ok() ? ConsensusResult::Ok()
