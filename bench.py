@@ -467,40 +467,22 @@ def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
     return out
 
 
-def sharded_c_abi(_lib, synth, ngpus, validators=100000, iters=30):
-    """BASELINE configs[3] the way the reference's ONE-process node would run it: this process opens every
-    GPU (hs_ed25519_init_devices) and calls hs_ed25519_verify_shared_sharded - one contiguous shard per
-    GPU launched from one thread, bitmap slices exchanged through the host or an in-process RCCL all-gather."""
-    n = 2 * validators // 3 + 1
-    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
-    _lib.shutdown()
-    _lib.init_devices(list(range(ngpus)), 8192)
-    lib = _lib.lib()
-    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
-    a = [ctypes.addressof(x) for x in b]
-    out = {"n_validators": validators, "signatures": n, "gpus": ngpus, "process": "one (rank 0 drives every GPU)",
-           "signatures_per_shard": _lib.shard_plan(n, ngpus, 0)[1]}
-    for name, how in (("host_exchange", _lib.EXCHANGE_HOST), ("rccl_all_gather", _lib.EXCHANGE_RCCL)):
-        try:
-            lib.hs_ed25519_set_shard_exchange(how)
-            for mode_name, mode in (("per_signature", _lib.BATCH), ("rlc_msm", _lib.BATCH_RLC)):
-                times = []
-                for i in range(iters + 3):
-                    t0 = time.perf_counter()
-                    rc = lib.hs_ed25519_verify_shared_sharded(a[0], a[1], a[2], n, mode, None)
-                    dt = time.perf_counter() - t0
-                    if rc != 1:
-                        raise RuntimeError("sharded QC rejected / failed (%d): %s" % (rc, _lib.last_error()))
-                    if i >= 3:
-                        times.append(dt)
-                times.sort()
-                out.setdefault(name, {})[mode_name] = {"p50_ms": round(times[len(times) // 2] * 1e3, 4),
-                                                       "verifies_per_s": round(n / times[len(times) // 2], 1)}
-        except Exception as e:
-            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
-    lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
-    _lib.shutdown()
-    return out
+def sharded_c_abi(ngpus, validators=100000, timeout_s=150):
+    """BASELINE configs[3] from ONE process through the C ABI (hs_ed25519_init_devices +
+    hs_ed25519_verify_shared_sharded; host and in-process RCCL exchange; per-signature and RLC): tools/sharded_c_abi.py,
+    run in a SUBPROCESS with a timeout - this path has never run on multi-GPU hardware, and a fault or a hang there
+    must not cost the bench line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                              "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_c_abi.py"), str(ngpus), str(validators)],
+                           capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "tools/sharded_c_abi.py did not finish within %d s" % timeout_s}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "tools/sharded_c_abi.py exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+    return json.loads(lines[-1])
 
 
 def main():
@@ -861,7 +843,7 @@ def main():
             dist.barrier()
         if rank == 0:
             try:
-                out["sharded_c_abi"] = sharded_c_abi(_lib, synth, world, validators=args.large_committee)
+                out["sharded_c_abi"] = sharded_c_abi(world, validators=args.large_committee)
             except Exception as e:
                 out["sharded_c_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
     line = json.dumps(out) if rank == 0 else None

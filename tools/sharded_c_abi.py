@@ -1,0 +1,72 @@
+"""BASELINE configs[3] the way the reference's ONE-process node would run it: this process opens `gpus` GPUs
+(hs_ed25519_init_devices) and calls hs_ed25519_verify_shared_sharded - one contiguous shard per GPU launched from
+one thread, bitmap slices exchanged through the host or an in-process RCCL all-gather.  Prints one JSON object.
+
+    python tools/sharded_c_abi.py <gpus> [validators] [iters]
+
+Run by bench.py (rank 0) in a subprocess with a timeout, so that a fault on hardware this path has never seen
+cannot cost the bench line."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ngpus = int(sys.argv[1])
+    validators = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    import synth
+    from hotstuff_amd import _lib
+    n = 2 * validators // 3 + 1
+    _lib.init_devices(list(range(ngpus)), 8192)
+    lib = _lib.lib()
+    # the synthetic QC is signed on the GPU (hs_ed25519_public_keys / hs_ed25519_sign_batch): milliseconds instead of seconds
+    seeds = b"".join(synth.key_seed(9_000_000 + i) for i in range(n))
+    pk = _lib.public_keys(seeds, n)
+    secrets = b"".join(seeds[32 * i:32 * i + 32] + pk[32 * i:32 * i + 32] for i in range(n))
+    dg = synth.shared_digest(9)
+    sg = _lib.sign_batch(secrets, dg, n, shared=True)
+    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    a = [ctypes.addressof(x) for x in b]
+    out = {"n_validators": validators, "signatures": n, "gpus": ngpus, "process": "one process drives every GPU through the C ABI",
+           "signatures_per_shard": _lib.shard_plan(n, ngpus, 0)[1]}
+    for name, how in (("host_exchange", _lib.EXCHANGE_HOST), ("rccl_all_gather", _lib.EXCHANGE_RCCL)):
+        try:
+            lib.hs_ed25519_set_shard_exchange(how)
+            for mode_name, mode in (("per_signature", _lib.BATCH), ("rlc_msm", _lib.BATCH_RLC)):
+                times = []
+                for i in range(iters + 3):
+                    t0 = time.perf_counter()
+                    rc = lib.hs_ed25519_verify_shared_sharded(a[0], a[1], a[2], n, mode, None)
+                    dt = time.perf_counter() - t0
+                    if rc != 1:
+                        raise RuntimeError("sharded QC rejected / failed (%d): %s" % (rc, _lib.last_error()))
+                    if i >= 3:
+                        times.append(dt)
+                times.sort()
+                out.setdefault(name, {})[mode_name] = {"p50_ms": round(times[len(times) // 2] * 1e3, 4),
+                                                       "verifies_per_s": round(n / times[len(times) // 2], 1)}
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # one corrupted signature must be localised across the shards
+    try:
+        lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
+        victim = n - 5
+        s2 = bytearray(sg); s2[64 * victim + 40] ^= 1
+        ok, bm = _lib.verify_packed_sharded(dg, pk, bytes(s2), n, _lib.BATCH_RLC, True, want_bitmap=True)
+        bad = [i for i in range(n) if not (bm[i >> 3] >> (i & 7)) & 1]
+        out["localisation_check"] = "ok" if (not ok and bad == [victim]) else "FAILED: %r" % bad[:5]
+    except Exception as e:
+        out["localisation_check"] = "%s: %s" % (type(e).__name__, e)
+    _lib.shutdown()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
