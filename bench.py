@@ -507,11 +507,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline + cpu_baseline only")
     ap.add_argument("--partitions", type=int, default=None,
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
-                         "default 16 for batches up to 4,096 signatures, 0 above)")
+                         "default 8 (one XCD each, two stream contexts per slice) for batches up to 4,096 signatures, 0 above)")
     args = ap.parse_args()
     if args.partitions is None:
         env = os.environ.get("HS_BENCH_PARTITIONS")
-        args.partitions = int(env) if env is not None else (16 if args.batch <= 4096 else 0)
+        # 8 slices of 32 CUs = one XCD (its own L2) each, two stream contexts per slice: measured best
+        # (profiles/r2_partition_sweep.txt: 16 x 16 CUs 43.9 M/s, 8 x 32 CUs with two streams each 51.1 M/s)
+        args.partitions = int(env) if env is not None else (8 if args.batch <= 4096 else 0)
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to

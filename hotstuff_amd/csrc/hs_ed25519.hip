@@ -517,7 +517,7 @@ static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (la
 // occupy disjoint slices of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py
 // `end_to_end`); one caller alone loses nothing, its batch is one wavefront per SIMD either way.
 static const size_t kPartitionMaxBatch = 1024;
-static const unsigned kPoolPartitions = 16;
+static unsigned kPoolPartitions = 16;           // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
 
 int hs::dev_slots() { return g_init.load() ? (int)g_devs.size() : 0; }
 int hs::dev_ordinal(int slot) { return (slot >= 0 && slot < hs::dev_slots()) ? g_devs[slot].ordinal : -1; }
@@ -637,6 +637,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     // runtime reads this when it initialises, so it only takes effect when this library is the
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
     int have = 0;
     HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");
     for (size_t i = 0; i < count; i++)
@@ -694,6 +695,12 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     const int f = ctx ? ctx->kernel : HS_K_AUTO;
     if (f == HS_K_AUTO) return n <= kQuadMaxBatch ? HS_K_FUSED : HS_K_LANE;
     return f;
+}
+// diagnostics: how many workgroups of the fused kernel the runtime says fit one CU (LDS 20,480 B and ~250 VGPRs per wavefront)
+extern "C" int hs_ed25519_debug_fused_blocks_per_cu(void) {
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_verify_fused_batches, 64, 0) != hipSuccess) return -1;
+    return nb;
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }

@@ -31,6 +31,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -70,10 +71,24 @@ struct CryptoResult {
 namespace detail {
 // 1 -> Ok, 0 (rejected) and < 0 (engine error) -> Err; the engine never reports success on failure.
 inline CryptoResult to_result(int rc) { return CryptoResult{rc == 1}; }
+// Devices: HS_ED25519_DEVICES="0,1,2,..." opens several GPUs behind this one process (the reference node is one
+// process); unset = the GPU named by HS_ED25519_DEVICE (default 0).  Idempotent and thread-safe in the library.
 inline bool ensure_init() {
-    static const int rc = hs_ed25519_init(0, 8192);      // idempotent and thread-safe in the library
+    static const int rc = [] {
+        std::vector<int> devs;
+        if (const char *e = std::getenv("HS_ED25519_DEVICES")) {
+            int v = 0; bool have = false;
+            for (const char *p = e;; p++) {
+                if (*p >= '0' && *p <= '9') { v = 10 * v + (*p - '0'); have = true; }
+                else { if (have) devs.push_back(v); v = 0; have = false; if (!*p) break; }
+            }
+        }
+        if (devs.empty()) { const char *e = std::getenv("HS_ED25519_DEVICE"); devs.push_back(e ? std::atoi(e) : 0); }
+        return hs_ed25519_init_devices(devs.data(), devs.size(), 8192);
+    }();
     return rc == 0;
 }
+inline bool several_devices() { return hs_ed25519_device_count() > 1; }
 }  // namespace detail
 
 // SURVEY.md 8a row A7.  threshold(): the measured crossover the library reports (bench.py
@@ -127,8 +142,9 @@ struct Signature {
         if (!detail::ensure_init()) return CryptoResult{false};
         // dalek's verify_batch as it is computed (one random linear combination), per-signature localisation
         // inside the same call; below hs_ed25519_rlc_min_batch() the engine runs the per-signature kernels alone
-        return detail::to_result(hs_ed25519_verify_shared(digest.b.data(), pks.data(), sigs.data(), votes.size(),
-                                                          HS_ED25519_BATCH_RLC, nullptr));
+        // with several device slots open the call is cut into one shard per GPU (hs_shard.hip)
+        const auto fn = detail::several_devices() ? hs_ed25519_verify_shared_sharded : hs_ed25519_verify_shared;
+        return detail::to_result(fn(digest.b.data(), pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH_RLC, nullptr));
     }
     // One digest per pair, strict semantics: the batched form of a loop of verify() calls (what VoteIngest and
     // TC::verify need).  Returns the per-pair verdicts; empty on an engine error.

@@ -238,6 +238,22 @@ int main(int argc, char **argv) {
         SmallBatch::cpu_verify() = nullptr;
         CHECK("without a CPU path every call goes to the GPU", x.sig[3].verify(x.bad_digest, x.pk[3]).is_err());
     }
+    // ---- the multi-GPU entry points of the C ABI, driven here on the one device that is open
+    {
+        uint8_t pks[3 * 32], sigs[3 * 64], bm[1] = {0};
+        for (int i = 0; i < 3; i++) {
+            std::memcpy(pks + 32 * i, x.pk[i].b.data(), 32);
+            const auto f = x.qc_sig[i].flatten();
+            std::memcpy(sigs + 64 * i, f.data(), 64);
+        }
+        size_t lo = 1, hi = 0;
+        const bool plan = hs_ed25519_shard_plan(3, 1, 0, &lo, &hi) == 0 && lo == 0 && hi == 3;
+        const int ok = hs_ed25519_verify_shared_sharded(x.qc_digest.b.data(), pks, sigs, 3, HS_ED25519_BATCH, bm);
+        sigs[64 + 40] ^= 1;
+        uint8_t bm2[1] = {0xff};
+        const int bad = hs_ed25519_verify_shared_sharded(x.qc_digest.b.data(), pks, sigs, 3, HS_ED25519_STRICT, bm2);
+        CHECK("hs_ed25519_verify_shared_sharded on one device slot", hs_ed25519_device_count() == 1 && plan && ok == 1 && bm[0] == 7 && bad == 0 && bm2[0] == 5);
+    }
     hs_ed25519_shutdown();
     printf("%d failed\n", failures);
     return failures;
