@@ -91,7 +91,7 @@ const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap 
 void wire_release(hs_ed25519_ctx *c);
 // hs_rlc.hip
 void rlc_release(hs_ed25519_ctx *c);
-int rlc_reserve(hs_ed25519_ctx *ctx, size_t n);     // all allocation of an n-signature RLC call, ahead of time
+int rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream = nullptr);     // all allocation of an n-signature RLC call, ahead of time
 int enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
                 const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream);
 }  // namespace hs

@@ -364,13 +364,14 @@ void hs::rlc_release(hs_ed25519_ctx *c) {
 }
 
 // all allocation of an n-signature RLC call (none happens later, e.g. under graph capture)
-int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n) {
+int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream) {
     rlc_ws *w = ws_of(ctx);
     if (!w) return fail(HS_ED25519_E_NOMEM, "rlc: out of memory");
     const size_t np = round_up(n, 64);
     if (np <= w->np) return 0;
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(ctx->stream), "stream sync");       // the old buffers may be in use
+    if (stream && (hipStream_t)stream != ctx->stream) HS_HIP(hipStreamSynchronize((hipStream_t)stream), "stream sync");
     ws_free(w);
     const size_t NP = 2 * np;
     HS_HIP(hipMalloc((void **)&w->rec, (NP + 1) * 128), "hipMalloc rlc records");
@@ -438,7 +439,7 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     if (n < min_batch || n > 0x0fffffffu) return 0;      // too small to pay for the pipeline (or absurdly large): plain per-signature BATCH
     const u32 *btab = dev_base_table(ctx->slot);
     if (!btab) return HS_ED25519_E_DEVICE;
-    int rc = rlc_reserve(ctx, n);
+    int rc = rlc_reserve(ctx, n, stream);
     if (rc) return rc;
     rlc_key key;
     rc = current_key(key);

@@ -147,9 +147,12 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
         rc = host_submit(jobs[s], s, items[s].ks, items[s].digests, digest_stride, items[s].keys, items[s].sigs, items[s].n, mode);
     }
     if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
+    // the communicators and the gather buffers are shared: a call that uses them keeps the lock until its streams
+    // have drained (the read-back of the gathered bitmap is asynchronous), so concurrent sharded callers serialise here
+    std::unique_lock<std::mutex> lk(s_mu, std::defer_lock);
     if (want_rccl) {
         // all-gather of equal slice_bytes slices: slot s contributes its bitmap padded with zeros
-        std::lock_guard<std::mutex> lk(s_mu);
+        lk.lock();
         rc = rccl_ensure(slice_bytes);
         if (!rc) {
             std::vector<uint8_t *> send(k, nullptr);

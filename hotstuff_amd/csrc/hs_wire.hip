@@ -184,6 +184,7 @@ extern "C" int hs_ed25519_sign_batch(const uint8_t *secrets, const uint8_t *dige
         rc = hs_ed25519_sign_device(c, d, d + off_dg, digest_stride, n, d + off_sig, c->stream);
         if (!rc) e = hipMemcpyAsync(sigs_out, d + off_sig, 64 * n, hipMemcpyDeviceToHost, c->stream);
     }
+    (void)hipMemsetAsync(d, 0, 64 * n, c->stream);          // the secrets do not outlive the call in device memory
     const hipError_t e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (rc) return rc;
