@@ -5,10 +5,10 @@
 // The arithmetic of every stage is in rlc.h (host+device, validated on the CPU by tests/emu);
 // this file maps it onto the chip:
 //
-//   k_rlc_prepare   one lane per point (2n lanes; n when A comes from a key set's Niels records):
-//                   decompress -> 128-byte affine Niels record (one cache line, dwordx4 stores);
-//                   the R lane hashes, draws z_i, z_i h_i and z_i s_i mod L, writes 2 x 32 digit bytes
-//                   [window][point] and adds z_i s_i into eight 64-bit limb sums (atomics, carry-free).
+//   k_rlc_prepare   one lane per task, three kinds in separate wavefronts: decompress R_i / decompress A_i
+//                   (absent when A comes from a key set's Niels records) -> 128-byte affine Niels record (one
+//                   cache line, dwordx4 stores); hash, draw z_i, z_i h_i and z_i s_i mod L, write 2 x 32 digit
+//                   bytes [window][point] and add z_i s_i into eight 64-bit limb sums (atomics, carry-free).
 //   k_rlc_hist / k_rlc_offsets / k_rlc_scatter   counting sort of every window's points by |digit|:
 //                   LDS histograms per (slice, window) workgroup, one lane per window turns them into
 //                   bucket offsets and chunk offsets, then each workgroup reserves its share of every
@@ -46,14 +46,17 @@ struct rlc_keys_src {            // where signature i's key bytes / curve flag c
     u32 nkeys;
 };
 
+// Three kinds of task, one lane each, in separate wavefronts: [0, n) decompress R_i; [n, 2n) hash, draw z_i, form the
+// scalars and digits of signature i; [2n, 3n) decompress A_i (absent when A comes from a key set).  The scalar work
+// (two SHA-512 blocks, two 256 x 256-bit products mod L, 64 digit bytes) is as long a chain as a decompression: on
+// the lane that also decompressed R it made k_rlc_prepare 0.29 ms at 66,667 signatures, of which only 0.04 ms went
+// away when the A decompressions did.
 __global__ void __launch_bounds__(64, 3)
 k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u32 *__restrict__ sigs, u32 n) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) rlc_store_identity_record(v.rec + (size_t)HS_RLC_REC_WORDS * 2 * v.np);
-    const u32 tasks = keys.pks ? 2 * n : n;
-    if (t >= tasks) return;
-    const bool is_r = t < n;
-    const u32 i = is_r ? t : t - n;
+    const u32 kind = t / v.np, i = t - kind * v.np;          // np lanes per kind: whole wavefronts are of one kind
+    if (i >= n || kind >= (keys.pks ? 3u : 2u)) return;
     const u32 *sig = sigs + (size_t)16 * i;
     const u32 *pk;
     bool ok = true;
@@ -64,14 +67,15 @@ k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u3
         pk = keys.ks_pk + (size_t)8 * (known ? ki : 0);
         ok = known && (keys.ks_flag[known ? ki : 0] & HS_F_ONCURVE);
     }
-    u32 enc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) enc[j] = is_r ? sig[j] : pk[j];
-    ok = rlc_point(v, is_r ? i : v.np + i, enc) && ok;
-    if (is_r) {
+    if (kind == 1) {
         u32 msg[8];
         load_msg(msg, msgs, i);
         ok = rlc_scalars(v, i, key, pk, sig, msg) && ok;
+    } else {
+        u32 enc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) enc[j] = kind == 0 ? sig[j] : pk[j];
+        ok = rlc_point(v, kind == 0 ? i : v.np + i, enc) && (kind == 0 || ok);
     }
     if (!ok) atomicOr(v.failed, 1u);
 }
@@ -459,7 +463,7 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     keys.pks = ks ? nullptr : (const u32 *)d_pks; keys.key_idx = ks ? d_key_idx : nullptr;
     keys.ks_pk = ks ? ks->d_pk : nullptr; keys.ks_flag = ks ? ks->d_flag : nullptr; keys.nkeys = ks ? (u32)ks->nkeys : 0;
     const u32 *p_sg = (const u32 *)d_sigs;
-    const u32 tasks = ks ? nn : 2 * nn;
+    const u32 tasks = (ks ? 2u : 3u) * np;                  // np lanes per task kind (k_rlc_prepare)
     const uint8_t *p_dig = w->dig;
     {
         void *a[] = { &v, &key, &msgs, &keys, &p_sg, (void *)&nn };

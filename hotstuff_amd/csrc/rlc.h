@@ -151,18 +151,23 @@ HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *
 // the wavefront (idle lanes add the identity record).  ksn: the key set's Niels array or null.
 HS_HD void rlc_accum_lane(ge_p3 &acc, const u32 *sorted, u32 lo, u32 hi, u32 trip, const u32 *rec, const u32 *ksn, u32 id_identity) {
     ge_identity(acc);
+    if (trip == 0) return;
+    // software-pipelined: the entry and the 128-byte record of step t + 1 are in flight while step t's addition
+    // computes (two dependent loads per step, ~3 us of latency a two-wavefronts-per-SIMD kernel cannot hide otherwise)
+    u32 e = lo < hi ? sorted[lo] : id_identity;
+    ge_niels q;
+    rlc_load_record(q, (e & HS_RLC_ID_CACHED) ? ksn + (size_t)HS_RLC_REC_WORDS * (e & 0x3fffffffu) : rec + (size_t)HS_RLC_REC_WORDS * (e & 0x3fffffffu));
 #pragma nounroll
     for (u32 t = 0; t < trip; t++) {
-        const u32 pos = lo + t;
-        const bool live = pos < hi;
-        const u32 e = live ? sorted[pos] : id_identity;
-        const u32 id = e & 0x3fffffffu;
-        const u32 *r = (e & HS_RLC_ID_CACHED) ? ksn + (size_t)HS_RLC_REC_WORDS * id : rec + (size_t)HS_RLC_REC_WORDS * id;
-        ge_niels q;
-        rlc_load_record(q, r);
+        const u32 pos = lo + t + 1;
+        const u32 e_next = (t + 1 < trip && pos < hi) ? sorted[pos] : id_identity;
+        ge_niels q_next;
+        rlc_load_record(q_next, (e_next & HS_RLC_ID_CACHED) ? ksn + (size_t)HS_RLC_REC_WORDS * (e_next & 0x3fffffffu)
+                                                            : rec + (size_t)HS_RLC_REC_WORDS * (e_next & 0x3fffffffu));
         ge_p1p1 s;
         ge_madd(s, acc, q, (e & HS_RLC_ID_NEG) != 0);
         ge_p1p1_to_p3(acc, s, true);
+        q = q_next; e = e_next;
     }
 }
 

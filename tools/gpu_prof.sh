@@ -11,7 +11,7 @@ python tools/rocpd_summary.py $O/kt/kt_results.db > $O/r2_bench_default_kernel_s
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c (headline)"; timeout 600 rocprofv3 --pmc $c -d $O/pmc_$c -o p -- python bench.py --steps 3 --warmup 1 --no-extras --no-cpu > /dev/null 2> $O/pmc_$c.err; echo rc=$?
   python tools/rocpd_pmc.py $O/pmc_$c/p_results.db k_verify > $O/r2_pmc_${c}_headline.json; cat $O/r2_pmc_${c}_headline.json | tr -d '\n '; echo
-  echo "== pmc $c (rlc 66667)"; timeout 600 rocprofv3 --pmc $c -d $O/pmcr_$c -o p -- python tools/dbg1.py rlc 66667 > /dev/null 2> $O/pmcr_$c.err; echo rc=$?
+  echo "== pmc $c (rlc 66667)"; timeout 600 rocprofv3 --pmc $c -d $O/pmcr_$c -o p -- python tools/rlc_probe.py rlc 66667 > /dev/null 2> $O/pmcr_$c.err; echo rc=$?
   python tools/rocpd_pmc.py $O/pmcr_$c/p_results.db k_rlc k_verify k_prepare > $O/r2_pmc_${c}_rlc66667.json; cat $O/r2_pmc_${c}_rlc66667.json | tr -d '\n '; echo
 done
 echo "== SQ counters (headline)"; timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $O/pmc_sq -o p -- python bench.py --steps 3 --warmup 1 --no-extras --no-cpu > /dev/null 2> $O/pmc_sq.err; echo rc=$?

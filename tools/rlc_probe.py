@@ -1,3 +1,7 @@
+"""Probe used for the round-2 profiles: `python tools/rlc_probe.py qc` (device-resident QC at N = 10,000, cold and
+cached) or `python tools/rlc_probe.py rlc <n> [cached]` (six HS_ED25519_BATCH_RLC calls, then six plain BATCH calls, on
+one context with the RLC threshold lowered to 1; prints the last call's wall time) - run under rocprofv3 to get the
+per-stage kernel times in profiles/r2_rlc_*_kernel_stats.csv."""
 import ctypes, os, sys, time, struct
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import torch, synth
