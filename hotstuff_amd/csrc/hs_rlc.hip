@@ -55,8 +55,11 @@ __global__ void __launch_bounds__(64, 3)
 k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u32 *__restrict__ sigs, u32 n) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) rlc_store_identity_record(v.rec + (size_t)HS_RLC_REC_WORDS * 2 * v.np);
-    const u32 kind = t / v.np, i = t - kind * v.np;          // np lanes per kind: whole wavefronts are of one kind
-    if (i >= n || kind >= (keys.pks ? 3u : 2u)) return;
+    const u32 kind = t / v.np, i0 = t - kind * v.np;         // np lanes per kind: whole wavefronts are of one kind
+    if (kind >= (keys.pks ? 3u : 2u)) return;
+    const bool active = i0 < n;
+    if (kind != 1 && !active) return;
+    const u32 i = active ? i0 : n - 1;                       // idle lanes of a scalar wavefront shadow the last signature (shuffles below)
     const u32 *sig = sigs + (size_t)16 * i;
     const u32 *pk;
     bool ok = true;
@@ -68,9 +71,19 @@ k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u3
         ok = known && (keys.ks_flag[known ? ki : 0] & HS_F_ONCURVE);
     }
     if (kind == 1) {
-        u32 msg[8];
+        u32 msg[8], c[8];
         load_msg(msg, msgs, i);
-        ok = rlc_scalars(v, i, key, pk, sig, msg) && ok;
+        ok = (rlc_scalars(v, i, key, pk, sig, msg, c) && ok) || !active;
+        // sum z_i s_i over the wavefront (limb-wise, carry-free in 64 bits), then ONE atomic per limb
+        unsigned long long c64[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned long long x = active ? c[j] : 0ull;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+            c64[j] = x;
+        }
+        if (threadIdx.x == 0) rlc_add_csum(v.csum, c64);
     } else {
         u32 enc[8];
 #pragma unroll

@@ -116,20 +116,22 @@ HS_HD void rlc_store_digits(uint8_t *dig, size_t stride, const u32 r[8]) {
 #pragma unroll
     for (int w = 0; w < HS_RLC_WINDOWS; w++) dig[(size_t)w * stride] = (uint8_t)(r[w >> 2] >> (8 * (w & 3)));
 }
-HS_HD void rlc_add_csum(unsigned long long *csum, const u32 c[8]) {
+HS_HD void rlc_add_csum(unsigned long long *csum, const unsigned long long c[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-        atomicAdd(csum + j, (unsigned long long)c[j]);
+        atomicAdd(csum + j, c[j]);
 #else
         csum[j] += c[j];
 #endif
     }
 }
 // stage 1b: the scalars of signature i (pk / sig / msg: its bytes as little-endian words).
-// Returns false when s >= L.
-HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *pk, const u32 *sig, const u32 *msg) {
-    u32 in[24], h[16], k[8], s[8], z[8], a[8], c[8], r[8];
+// c = z_i s_i mod L (zero when s >= L), to be added into v.csum by the caller - the kernel first sums it across
+// the wavefront: 8 atomics per SIGNATURE on the same eight addresses serialised k_rlc_prepare (0.27 ms of atomics at
+// 66,667 signatures).  Returns false when s >= L.
+HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *pk, const u32 *sig, const u32 *msg, u32 c[8]) {
+    u32 in[24], h[16], k[8], s[8], z[8], a[8], r[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
     sha512_96(h, in);
@@ -143,7 +145,10 @@ HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *
     rlc_store_digits(v.dig + i, stride, r);
     sc_recode256(r, a);
     rlc_store_digits(v.dig + v.np + i, stride, r);
-    if (canon) rlc_add_csum(v.csum, c);
+    if (!canon) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = 0;
+    }
     return canon;
 }
 

@@ -215,7 +215,11 @@ int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, c
         load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
         if (!rlc_point(v, (u32)i, sig)) fail = 1;
         if (!rlc_point(v, np + (u32)i, pk)) fail = 1;
-        if (!rlc_scalars(v, (u32)i, key, pk, sig, msg)) fail = 1;
+        u32 c[8];
+        if (!rlc_scalars(v, (u32)i, key, pk, sig, msg, c)) fail = 1;
+        unsigned long long c64[8];
+        for (int j = 0; j < 8; j++) c64[j] = c[j];
+        rlc_add_csum(csum, c64);
     }
     rlc_store_identity_record(rec.data() + (size_t)NP * HS_RLC_REC_WORDS);
     if (fail) return 0;

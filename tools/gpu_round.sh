@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_rlc.py tests/test_gpu_sharded.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_rlc.py tests/test_gpu_sharded.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | head -5
 show() { python - "$1" <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
