@@ -363,7 +363,7 @@ void ws_free(rlc_ws *w) {
     w->rec = w->sorted = w->part = w->wsum = w->tabs = nullptr; w->dig = w->small = nullptr; w->np = 0;
 }
 u32 chunk_for(size_t n) {          // points per lane of stage 3: enough lanes to fill the chip, runs long enough to amortise the scan
-    return n <= 16384 ? 8u : (n <= 32768 ? 16u : 32u);
+    return n <= 16384 ? 8u : (n <= 131072 ? 16u : 32u);      // profiles/r2_rlc_tuning_ab.txt: 32 from 32,768 up was measured and lost
 }
 u32 lane_cap(size_t np, u32 C) { return (u32)round_up(2 * np / C + HS_RLC_BUCKETS, 64); }   // chunks per window, upper bound
 rlc_ws *ws_of(hs_ed25519_ctx *ctx) {

@@ -159,7 +159,7 @@ def test_ring_protocol_errors_are_errors():
     dg, pk, sg = synth.make_batch(8, shared=True, cache_dir=CACHE)
     fill(ring, 0, dg, pk, sg, 8, True)
     with pytest.raises(_lib.EngineError):
-        ring.submit(0, 2)                                # bad mode: still begun, not in flight
+        ring.submit(0, 7)                                # bad mode: still begun, not in flight
     ring.submit(0, _lib.STRICT)
     with pytest.raises(_lib.EngineError):
         ring.begin(0, 8, True)                           # in flight: wait first
@@ -168,6 +168,10 @@ def test_ring_protocol_errors_are_errors():
     ok, bm = ring.wait(0)
     assert ok and bm == b"\xff"
     assert ring.poll(0) and ring.poll(1)
+    fill(ring, 1, dg, pk, sg, 8, True)
+    ring.submit(1, _lib.BATCH_RLC)                       # a valid mode in the ring too (below the RLC threshold: per-signature kernels)
+    ok, bm = ring.wait(1)
+    assert ok and bm == b"\xff"
     ring.close()
 
 

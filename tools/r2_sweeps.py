@@ -74,11 +74,15 @@ print("# Round-2 sweeps (one MI355X, device-resident inputs, `tools/r2_sweeps.py
 print("## 1. Cold QC path: per-signature kernels vs batch RLC / MSM (HS_ED25519_BATCH_RLC)\n")
 print("| signatures | per-signature p50 ms | RLC p50 ms | per-signature M sig/s (4 in flight) | RLC M sig/s (4 in flight) |")
 print("|---|---|---|---|---|")
-for n in (2048, 4096, 6667, 8192, 12288, 16384, 24576, 32768, 49152, 66667, 131072, 262144):
+SIZES = [int(x) for x in os.environ["HS_SWEEP_SIZES"].split(",")] if os.environ.get("HS_SWEEP_SIZES") else \
+    [2048, 4096, 6667, 8192, 12288, 16384, 24576, 32768, 49152, 66667, 131072, 262144]
+for n in SIZES:
     a = measure(n, _lib.BATCH)
     b = measure(n, _lib.BATCH_RLC)
     print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
 print("\nlibrary threshold (hs_ed25519_rlc_min_batch): %d\n" % _lib.lib().hs_ed25519_rlc_min_batch())
+if os.environ.get("HS_SWEEP_SIZES"):
+    sys.exit(0)
 print("## 2. Per-signature cold path (strict, one digest per signature): fused four-lane kernel vs one lane per signature\n")
 print("| signatures | k_verify_fused p50 ms | k_prepare + k_verify p50 ms | fused M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
 print("|---|---|---|---|---|")
