@@ -673,7 +673,7 @@ def main():
                   "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": _lib.lib().hs_ed25519_cached_kernel_for(n).decode(),
                   "avg_kernel_ms": round(k_ms, 4), "keys": n * ns, "keyset_hbm_bytes": ks.hbm_bytes(),
                   "keyset_build_ms": round(build_ms, 2),
-                  "table_bytes_read_per_verify": 64 * 160,
+                  "table_bytes_read_per_verify": 64 * 128,
                   "note": "keys pre-registered (static committee); not comparable with `value`, which is the cold path"}
         ks.close()
         # large committee, one launch (BASELINE configs[3] on ONE GPU): N = 100,000 validators (66 GB of
@@ -704,10 +704,10 @@ def main():
             l_el = time.perf_counter() - t0
             assert int(l_nr.item()) == 0
             lk_ms = lctx.kernel_times()[1] / max(1, lctx.kernel_times()[2])
-            gather = 32 * 160 * nl                      # bytes of the keys' tables read per launch
+            gather = 32 * 128 * nl                      # bytes of the keys' tables read per launch (one 128-byte affine entry per window)
             l_traffic = None
             try:    # HBM bytes per launch from the committed rocprofv3 PMC pass (same kernel, same launch size)
-                lp = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json"))).get("large_committee", {})
+                lp = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json"))).get("large_committee", {})
                 if lp.get("signatures_per_launch") == nl and lp.get("kernel") == _lib.lib().hs_ed25519_cached_kernel_for(nl).decode():
                     l_traffic = lp["hbm_bytes_per_launch"]
             except Exception:
@@ -719,9 +719,9 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "algorithmic_bytes_per_launch": gather, "traffic": l_traffic,
-                             "traffic_source": "profiles/r1_pmc_traffic.json large_committee (rocprofv3 --pmc FETCH_SIZE, "
+                             "traffic_source": "profiles/r2_pmc_traffic.json large_committee (rocprofv3 --pmc FETCH_SIZE, "
                                                "uncorrected)" if l_traffic else None,
-                             "note": "32 table entries x 160 B per verification gathered from the key set"}}
+                             "note": "32 table entries x 128 B (one cache line each) per verification gathered from the key set"}}
             lctx.close(); lks.close()
         except Exception as e:        # never let the extra break the headline
             cached["large_committee"] = {"error": str(e)}

@@ -217,8 +217,22 @@ k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u3
     fe ax, ay;
 #pragma unroll
     for (int j = 0; j < 10; j++) { ax.v[j] = axy[(size_t)20 * k + j]; ay.v[j] = axy[(size_t)20 * k + 10 + j]; }
-    keyset_build_window(tab + (size_t)k * HS_KS_KEY_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
+    keyset_build_window(tab + (size_t)k * HS_KS_KEY_PROJ_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_PROJ_WORDS,
                         ax, ay, negate != 0, (int)w);
+}
+// registration pass 3: one lane per entry - projective scratch -> the affine 128-byte entry the verification kernels read
+__global__ void __launch_bounds__(64, 3)
+k_keyset_affine(const u32 *__restrict__ proj, u32 *__restrict__ tab, unsigned long long entries) {
+    const unsigned long long e = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (e >= entries) return;
+    u32 in[HS_KS_PROJ_WORDS], out[HS_KS_ENTRY_WORDS];
+    const uint4 *src = reinterpret_cast<const uint4 *>(proj + e * HS_KS_PROJ_WORDS);
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const uint4 v = src[i]; in[4 * i] = v.x; in[4 * i + 1] = v.y; in[4 * i + 2] = v.z; in[4 * i + 3] = v.w; }
+    keyset_affine_entry(out, in);
+    uint4 *dst = reinterpret_cast<uint4 *>(tab + e * HS_KS_ENTRY_WORDS);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
 }
 #ifdef HS_AB_VARIANTS
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
@@ -506,10 +520,10 @@ static std::atomic<size_t> g_max_batch{0};
 // narrow contexts - one per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
 static const int kMaxPool[2] = {4, 16};
 // cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
-// one lane per signature above (profiles/r1_cached_threshold_sweep.md: the three-wavefront form wins or ties
-// from 1,024 to ~200,000 signatures; the one-lane form does the least total work once the chip is several
-// times over-subscribed)
-static const size_t kCachedLane1Min = 196608;
+// one lane per signature above.  Round 1 switched at 196,608; with the affine 128-byte table entries the one-lane
+// kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
+// (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
+static const size_t kCachedLane1Min = 98304;
 static const size_t kZeroCopyMax = 16384;    // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel = one per SIMD of 16 CUs) are
@@ -901,12 +915,32 @@ extern "C" int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_
 }
 
 // ---- key sets --------------------------------------------------------------------------------
+// tables of `nkeys` keys: projective multiples into a scratch buffer (chunks of kBuildChunk keys, 2.7 GB), then one
+// inversion per entry into the affine table
+static const size_t kBuildChunk = 4096;
 static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate, hipStream_t st) {
-    const u32 nk = (u32)nkeys, pad = (u32)round_up(nkeys, 16), neg = negate ? 1u : 0u;
-    void *args[] = { &d_tab, &d_axy, (void *)&nk, (void *)&pad, (void *)&neg };
-    HS_HIP(hipLaunchKernel((const void *)k_keyset_build, dim3(pad / 16 * HS_KS_WINDOWS), dim3(64), args, 0, st),
-           "launch k_keyset_build");
-    return 0;
+    const size_t chunk = nkeys < kBuildChunk ? nkeys : kBuildChunk;
+    u32 *d_proj = nullptr;
+    HS_HIP(hipMalloc((void **)&d_proj, chunk * (size_t)HS_KS_KEY_PROJ_WORDS * 4), "hipMalloc table scratch");
+    int rc = 0;
+    for (size_t c0 = 0; c0 < nkeys && !rc; c0 += chunk) {
+        const size_t nc = nkeys - c0 < chunk ? nkeys - c0 : chunk;
+        const u32 nk = (u32)nc, pad = (u32)round_up(nc, 16), neg = negate ? 1u : 0u;
+        const u32 *p_axy = d_axy + (size_t)20 * c0;
+        void *args[] = { &d_proj, &p_axy, (void *)&nk, (void *)&pad, (void *)&neg };
+        hipError_t e = hipLaunchKernel((const void *)k_keyset_build, dim3(pad / 16 * HS_KS_WINDOWS), dim3(64), args, 0, st);
+        if (e == hipSuccess) {
+            const u32 *p_proj = d_proj; u32 *p_tab = d_tab + c0 * (size_t)HS_KS_KEY_WORDS;
+            unsigned long long entries = (unsigned long long)nc * HS_KS_WINDOWS * HS_KS_ENTRIES;
+            void *a2[] = { &p_proj, &p_tab, &entries };
+            e = hipLaunchKernel((const void *)k_keyset_affine, dim3((unsigned)((entries + 63) / 64)), dim3(64), a2, 0, st);
+        }
+        if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "launch k_keyset_build / k_keyset_affine", e);
+    }
+    const hipError_t es = hipStreamSynchronize(st);          // the scratch is freed below
+    (void)hipFree(d_proj);
+    if (!rc && es != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "table build", es);
+    return rc;
 }
 static int ensure_base_table(int slot) {        // caller holds no lock; idempotent under g_mu
     std::lock_guard<std::mutex> lk(g_mu);

@@ -16,11 +16,15 @@
 // the form the default kernels use, because it takes the 254-squaring chain off the addition chains.
 //
 // Cost: 64 additions + 1 inversion or square root, against 252 doublings + 96 additions + 2
-// square roots for the cold path.  Price: 129 * 32 cached points = 660,480 bytes of HBM per key
-// (6.6 GB for 10,000 validators, 66 GB for 100,000 - MI355X has 288 GB).
+// square roots for the cold path.  Price: 129 * 32 entries of 128 bytes = 528,384 bytes of HBM per key
+// (5.3 GB for 10,000 validators, 53 GB for 100,000 - MI355X has 288 GB).
 //
-// Table entries use the quad kernel's cached layout, (Y-X, Y+X, 2dT, 2Z) one coordinate per
-// lane, so the same q_add_cached serves; entry 0 of every window is the identity.
+// Table entries are AFFINE Niels points (y-x, y+x, 2dxy) padded to 128 bytes = exactly one cache line per
+// lookup (round 1 stored projective (Y-X, Y+X, 2dT, 2Z), 160 bytes straddling two or three lines: an
+// addition then cost 8 multiplications instead of 7, and a gather twice the lines).  Registration builds
+// the projective multiples with the quad kernel's formulas and normalises every entry with an inversion of
+// its own (one lane per entry; 4,128 inversions per key, ~4 us of chip time per key).  The quad forms read
+// the fourth coordinate, 2Z = 2, from a constant; entry 0 of every window is the identity.
 // Same accept set as verify_lane / verify_quad (tests run all 70 edge vectors through it).
 #pragma once
 #include "verify_quad.h"
@@ -29,12 +33,14 @@ namespace hs {
 
 #define HS_KS_WINDOWS 32
 #define HS_KS_ENTRIES 129
-#define HS_KS_ENTRY_WORDS 40                                   // 4 lanes x 10 limbs
+#define HS_KS_ENTRY_WORDS 32                                   // (y-x)[10] (y+x)[10] (2dxy)[10] pad[2]: 128 bytes
 #define HS_KS_KEY_WORDS (HS_KS_WINDOWS * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS)
+#define HS_KS_PROJ_WORDS 40                                    // registration scratch: projective (Y-X, Y+X, 2dT, 2Z), 4 lanes x 10 limbs
+#define HS_KS_KEY_PROJ_WORDS (HS_KS_WINDOWS * HS_KS_ENTRIES * HS_KS_PROJ_WORDS)
 
 // per-key header written by the registration pass
 struct keyset_view {
-    const u32 *tab;      // [key][window][entry][lane][limb]
+    const u32 *tab;      // [key][window][entry][32 words]
     const u32 *pk;       // [key][8]   the 32 key bytes (hash input)
     const u32 *flag;     // [key]      HS_F_ONCURVE | HS_F_SMALL
 };
@@ -53,14 +59,18 @@ HS_Q bool q_quad_all(const qflags &f) {       // all four lanes set, uniform ove
     const int c = __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true), d = __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true);
     return a && b && c && d;
 }
-HS_Q qv q_load_entry(const u32 *entry) {      // this lane's coordinate of a 40-word entry
-    const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * q_lane());
+HS_Q qv q_load_entry(const u32 *entry) {      // this lane's coordinate of an affine entry: lanes 0-2 read, lane 3 is the constant 2Z = 2
+    const u32 l = q_lane();
+    const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * (l < 3 ? l : 2));
+    u32 m = l < 3 ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));              // a mask (v_and / v_bfi), not a VCC select
     qv r;
 #pragma unroll
-    for (int i = 0; i < 5; i++) { const uint2 v = p[i]; r.v[2 * i] = v.x; r.v[2 * i + 1] = v.y; }
+    for (int i = 0; i < 5; i++) { const uint2 v = p[i]; r.v[2 * i] = v.x & m; r.v[2 * i + 1] = v.y & m; }
+    r.v[0] |= 2u & ~m;
     return r;
 }
-HS_Q void q_store_entry(u32 *entry, const qv &e) {
+HS_Q void q_store_entry(u32 *entry, const qv &e) {      // a PROJECTIVE entry of the registration scratch (40 words)
     uint2 *p = reinterpret_cast<uint2 *>(entry + 10 * q_lane());
 #pragma unroll
     for (int i = 0; i < 5; i++) p[i] = make_uint2(e.v[2 * i], e.v[2 * i + 1]);
@@ -94,7 +104,8 @@ HS_Q qv q_invert(const qv &z) { qv r; for (int i = 0; i < 4; i++) fe_invert(r.l[
 HS_Q bool q_quad_and01(const qflags &f) { return f.f[0] && f.f[1]; }
 HS_Q bool q_quad_all(const qflags &f) { return f.f[0] && f.f[1] && f.f[2] && f.f[3]; }
 HS_Q qv q_load_entry(const u32 *entry) {
-    qv r; for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i]; return r;
+    qv r; for (int l = 0; l < 3; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i];
+    r.l[3] = fe_small(2); return r;
 }
 HS_Q void q_store_entry(u32 *entry, const qv &e) {
     for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) entry[10 * l + i] = e.l[l].v[i];
@@ -115,9 +126,9 @@ HS_Q qflags q_identity_lanes(const qv &p) {
 }
 #endif
 
-// ---- registration: one quad per (key, window) ---------------------------------------------
+// ---- registration: one quad per (key, window), then one lane per entry ------------------------
 // ax, ay: the decompressed key (affine); negate: tables of -A (keys) or +B (base point).
-// Writes entries 0..128 of window `w`: j * 2^(8w) * (+-A) in cached form.
+// Writes entries 0..128 of window `w` into the PROJECTIVE scratch: j * 2^(8w) * (+-A) as (Y-X, Y+X, 2dT, 2Z).
 HS_Q void keyset_build_window(u32 *win /* [129][40] */, const fe &ax, const fe &ay, bool negate, int w) {
     fe x = ax;
     if (negate) fe_neg(x, ax);
@@ -126,12 +137,24 @@ HS_Q void keyset_build_window(u32 *win /* [129][40] */, const fe &ax, const fe &
     for (int d = 0; d < 8 * w; d++) p = q_dbl(p);
     q_store_entry(win, q_lanes(fe_small(1), fe_small(1), fe_small(0), fe_small(2)));
     const qv e1 = q_to_cached(p);
-    q_store_entry(win + HS_KS_ENTRY_WORDS, e1);
+    q_store_entry(win + HS_KS_PROJ_WORDS, e1);
 #pragma nounroll
     for (int j = 2; j < HS_KS_ENTRIES; j++) {
         p = q_add_cached(p, e1);
-        q_store_entry(win + (size_t)j * HS_KS_ENTRY_WORDS, q_to_cached(p));
+        q_store_entry(win + (size_t)j * HS_KS_PROJ_WORDS, q_to_cached(p));
     }
+}
+// projective (A, B, C, D) = (Y-X, Y+X, 2dT, 2Z)  ->  affine (y-x, y+x, 2dxy) = (A, B, C) * 2 / D   (2dxy = 2dT / Z)
+HS_HD void keyset_affine_entry(u32 *out /* 32 words */, const u32 *in /* 40 words */) {
+    fe a, b, c, d, inv;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { a.v[i] = in[i]; b.v[i] = in[10 + i]; c.v[i] = in[20 + i]; d.v[i] = in[30 + i]; }
+    fe_invert(inv, d);
+    fe_add(inv, inv, inv);                  // 2 / D  (2x: the first operand of the multiplications below)
+    fe_mul(a, inv, a); fe_mul(b, inv, b); fe_mul(c, inv, c);
+#pragma unroll
+    for (int i = 0; i < 10; i++) { out[i] = a.v[i]; out[10 + i] = b.v[i]; out[20 + i] = c.v[i]; }
+    out[30] = 0; out[31] = 0;
 }
 
 // ---- verification: one quad per signature -------------------------------------------------
@@ -173,24 +196,24 @@ HS_Q bool cached_quad_match_point(const qv &acc, const fe &rx, const fe &ry, u32
 }
 
 // ---- one lane per signature (throughput form, large batches) -------------------------------
-// Same tables, read whole (40 words = 160 contiguous bytes per lookup and lane).  Per signature:
-// 64 serial table additions (8 field multiplications each) + one inversion, against 4x-replicated
-// work in the quad form - ~780 field multiplications per verification.
-struct tab_entry { fe ymx, ypx, t2d, z2; };      // (Y-X, Y+X, 2dT, 2Z) as stored
+// Same tables, read whole (one 128-byte line per lookup and lane).  Per signature:
+// 64 serial table additions (7 field multiplications each) + one inversion, against 4x-replicated
+// work in the quad form - ~715 field multiplications per verification.
+struct tab_entry { fe ymx, ypx, t2d; };          // affine (y-x, y+x, 2dxy) as stored
 
 HS_HD void load_tab_entry(tab_entry &e, const u32 *p) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    u32 w[40];
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);       // the whole 128-byte line
+    u32 w[32];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    for (int i = 0; i < 8; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
 #else
     const u32 *w = p;
 #endif
 #pragma unroll
-    for (int i = 0; i < 10; i++) { e.ymx.v[i] = w[i]; e.ypx.v[i] = w[10 + i]; e.t2d.v[i] = w[20 + i]; e.z2.v[i] = w[30 + i]; }
+    for (int i = 0; i < 10; i++) { e.ymx.v[i] = w[i]; e.ypx.v[i] = w[10 + i]; e.t2d.v[i] = w[20 + i]; }
 }
-// r = p +- e  (extended += stored cached entry); 8 multiplications, result reduced
+// r = p +- e  (extended += stored affine entry); 7 multiplications, result reduced
 HS_HD void ge_add_tab(ge_p3 &r, const ge_p3 &p, const tab_entry &e, bool neg) {
     fe qa, qb, a, b, c, d, t;
     fe_select(qa, e.ymx, e.ypx, neg);
@@ -198,7 +221,7 @@ HS_HD void ge_add_tab(ge_p3 &r, const ge_p3 &p, const tab_entry &e, bool neg) {
     fe_sub(t, p.Y, p.X); fe_mul(a, t, qa);        // A = (Y1-X1)(Y2-+X2)
     fe_add(t, p.Y, p.X); fe_mul(b, t, qb);        // B = (Y1+X1)(Y2+-X2)
     fe_mul(c, p.T, e.t2d);                        // C = T1 2dT2
-    fe_mul(d, p.Z, e.z2);                         // D = Z1 2Z2
+    fe_add(d, p.Z, p.Z); fe_carry(d);             // D = 2 Z1   (Z2 = 1)
     fe E, H, zs, zd, F, G;
     fe_sub(E, b, a);                              // 3x
     fe_add(H, b, a);                              // 2x

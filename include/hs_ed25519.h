@@ -160,7 +160,7 @@ int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch
 /* ---- committee key cache -------------------------------------------------------------------
  * Every key the reference verifies belongs to the committee, which is static per epoch
  * (consensus/src/config.rs:39-43).  hs_ed25519_keyset_create decompresses the n_keys public
- * keys once and builds per-key window tables in HBM (660,516 bytes per key; see
+ * keys once and builds per-key window tables in HBM (528,420 bytes per key; see
  * hs_ed25519_keyset_bytes) so that a verification needs no doublings and no decompression:
  * 64 table additions + 1 inversion.  The *_cached calls take key_idx[i] = position of
  * signature i's key in the set instead of the key bytes (the Rust shim resolves it with the
@@ -255,7 +255,7 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
 
 /* Per-context kernel choice, for tests and A/B measurements (the host-pointer calls always use
  * the default): 0 = by batch size (cold: fused 4-lanes-per-signature kernel up to 32,768
- * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 196,608, the
+ * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 98,304, the
  * one-lane kernel above), 1 = the one-lane-per-signature kernels, 3 = the fused / two-lane
  * kernels at any size.  All have the same accept set.  Returns the previous choice or
  * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
@@ -289,7 +289,7 @@ int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, 
                                     uint32_t mode, uint8_t *bitmap);
 /* Committee key cache over several GPUs.  A QC is an arbitrary 2f+1 subset of the committee, so the
  * votes of a call do not line up with any slicing of the key table:
- *   HS_ED25519_KEYS_REPLICATE  every slot holds the whole table (100,000 validators: 66 GB of 288 GB
+ *   HS_ED25519_KEYS_REPLICATE  every slot holds the whole table (100,000 validators: 53 GB of 288 GB
  *                              per GPU); shards stay contiguous
  *   HS_ED25519_KEYS_BY_OWNER   slot s holds the keys of hs_ed25519_shard_plan(n_keys, k, s); the
  *                              call routes each vote to its key's owner and scatters the verdict bits

@@ -138,6 +138,43 @@ uint32_t emu_genuine_point_accepts(void) {
     return out;
 }
 // ---- committee key cache (verify_cached.h) ----
+// The device normalises every table entry with an inversion of its own (keyset_affine_entry, one lane per entry).
+// Doing the same 4,128 inversions per key serially on the CPU made this harness the slowest thing in the suite, so the
+// emulation normalises a window with Montgomery's trick (one inversion per 129 entries) - and emu_affine_forms_agree
+// checks that both forms give the same field elements.
+static void affine_window_batch(u32 *dst /* [129][32] */, const u32 *proj /* [129][40] */) {
+    fe d[HS_KS_ENTRIES], pre[HS_KS_ENTRIES];
+    for (int j = 0; j < HS_KS_ENTRIES; j++) for (int i = 0; i < 10; i++) d[j].v[i] = proj[(size_t)j * HS_KS_PROJ_WORDS + 30 + i];
+    pre[0] = d[0];
+    for (int j = 1; j < HS_KS_ENTRIES; j++) fe_mul(pre[j], pre[j - 1], d[j]);
+    fe inv; fe_invert(inv, pre[HS_KS_ENTRIES - 1]);
+    for (int j = HS_KS_ENTRIES - 1; j >= 0; j--) {
+        fe dj_inv;
+        if (j) { fe_mul(dj_inv, inv, pre[j - 1]); fe_mul(inv, inv, d[j]); } else dj_inv = inv;
+        fe two; fe_add(two, dj_inv, dj_inv);
+        const u32 *in = proj + (size_t)j * HS_KS_PROJ_WORDS; u32 *out = dst + (size_t)j * HS_KS_ENTRY_WORDS;
+        fe a, b, c;
+        for (int i = 0; i < 10; i++) { a.v[i] = in[i]; b.v[i] = in[10 + i]; c.v[i] = in[20 + i]; }
+        fe_mul(a, two, a); fe_mul(b, two, b); fe_mul(c, two, c);
+        for (int i = 0; i < 10; i++) { out[i] = a.v[i]; out[10 + i] = b.v[i]; out[20 + i] = c.v[i]; }
+        out[30] = out[31] = 0;
+    }
+}
+// 1 when the per-entry device form and the batch form above agree (as field elements) on every entry of a window
+int emu_affine_forms_agree(const uint8_t *pk32, int win) {
+    u32 w[8]; load_words(w, pk32, 8); ge_p3 p; if (!ge_decompress(p, w)) return -1;
+    std::vector<u32> proj((size_t)HS_KS_ENTRIES * HS_KS_PROJ_WORDS), x((size_t)HS_KS_ENTRIES * HS_KS_ENTRY_WORDS), y(x.size());
+    keyset_build_window(proj.data(), p.X, p.Y, true, win);
+    affine_window_batch(x.data(), proj.data());
+    for (int j = 0; j < HS_KS_ENTRIES; j++) keyset_affine_entry(y.data() + (size_t)j * HS_KS_ENTRY_WORDS, proj.data() + (size_t)j * HS_KS_PROJ_WORDS);
+    for (int j = 0; j < HS_KS_ENTRIES; j++) for (int c = 0; c < 3; c++) {
+        fe f, g; u32 fw[8], gw[8];
+        for (int i = 0; i < 10; i++) { f.v[i] = x[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; g.v[i] = y[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; }
+        fe_to_words(fw, f); fe_to_words(gw, g);
+        if (memcmp(fw, gw, 32)) return 0;
+    }
+    return 1;
+}
 size_t emu_keyset_words(size_t nkeys) { return nkeys * (size_t)HS_KS_KEY_WORDS; }
 // tab: nkeys * HS_KS_KEY_WORDS words; flag: nkeys words.  Key `nkeys` is not stored here: the
 // base point's own table is built by emu_keyset_build_base.
@@ -147,15 +184,22 @@ void emu_keyset_build(const uint8_t *pks, size_t nkeys, uint32_t *tab, uint32_t 
         ge_p3 p; u32 fl = ge_decompress(p, w) ? HS_F_ONCURVE : 0;
         fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
         flag[k] = fl;
-        for (int win = 0; win < HS_KS_WINDOWS; win++)
-            keyset_build_window(tab + k * (size_t)HS_KS_KEY_WORDS + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS,
-                                p.X, p.Y, true, win);
+        for (int win = 0; win < HS_KS_WINDOWS; win++) {
+            std::vector<u32> proj((size_t)HS_KS_ENTRIES * HS_KS_PROJ_WORDS);
+            keyset_build_window(proj.data(), p.X, p.Y, true, win);
+            u32 *dst = tab + k * (size_t)HS_KS_KEY_WORDS + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS;
+            affine_window_batch(dst, proj.data());
+        }
     }
 }
 void emu_keyset_build_base(uint32_t *tab) {
     ge_p3 b; ge_basepoint(b);
-    for (int win = 0; win < HS_KS_WINDOWS; win++)
-        keyset_build_window(tab + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS, b.X, b.Y, false, win);
+    for (int win = 0; win < HS_KS_WINDOWS; win++) {
+        std::vector<u32> proj((size_t)HS_KS_ENTRIES * HS_KS_PROJ_WORDS);
+        keyset_build_window(proj.data(), b.X, b.Y, false, win);
+        u32 *dst = tab + (size_t)win * HS_KS_ENTRIES * HS_KS_ENTRY_WORDS;
+        affine_window_batch(dst, proj.data());
+    }
 }
 // lane_form = 1: the one-lane-per-signature core (verify_cached_lane), 0: the quad core
 static int g_cached_lane_form = 0;

@@ -228,3 +228,12 @@ def test_every_finishing_form_fails_closed_on_a_zero_accumulator(emu):
     emu.emu_genuine_point_accepts.restype = ctypes.c_uint32
     assert emu.emu_genuine_point_accepts() == 0b1111
     assert emu.emu_zero_accumulator_accepts() == 0
+
+
+def test_affine_table_entries_device_form_equals_batch_form(emu):
+    """Key-table entries are affine Niels points; the device inverts every entry on a lane of its own
+    (keyset_affine_entry), the emulation normalises a window with one shared inversion - same field elements."""
+    import synth
+    for i, win in ((0, 0), (1, 7), (2, 31)):
+        pk, _ = synth.sign(synth.key_seed(600 + i), b"m" * 32)
+        assert emu.emu_affine_forms_agree(pk, win) == 1

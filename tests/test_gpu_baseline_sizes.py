@@ -1,7 +1,7 @@
 """Bit-exact GPU-vs-C-oracle parity AT BASELINE.json's sizes, ~3 % of the signatures corrupted
 (SURVEY.md 8d mix): n = 6,667 (config 3: N = 10,000), n = 66,667 (config 4: N = 100,000; cold
 two-kernel path and the cached three-wavefront kernel, by size), n = 8,384 (the shard one of 8 GPUs
-gets) and n > 196,608 (the one-lane cached kernel reached by size, not by a selector).  Cold and
+gets) and n > 98,304 (the one-lane cached kernel reached by size, not by a selector).  Cold and
 key-cache paths, both modes, through the host-pointer C ABI."""
 import os
 
@@ -49,13 +49,13 @@ def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
 
 
 def test_one_lane_cached_kernel_reached_by_size(oracle):
-    """n = 197,632 > 196,608: hs_ed25519_verify_shared_cached dispatches k_verify_cached_lane by size.
+    """n = 197,632 > 98,304: hs_ed25519_verify_shared_cached dispatches k_verify_cached_lane by size.
     1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted individually."""
     base = 1024
     dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
     reps = 193
     n = base * reps
-    assert n > 196608 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane"
+    assert n > 98304 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane"
     pk_t, sg_t = pk * reps, sg * reps
     dg2, pk_t, sg_t, bad = synth.corrupt(dg, pk_t, sg_t, n, True, rate_byte=8)
     keys = [pk[32 * i:32 * i + 32] for i in range(base)]

@@ -36,7 +36,7 @@ def test_edge_vectors_with_every_key_registered(edge_vectors):
     n = len(edge_vectors)
     keys = [H(v["pk"]) for v in edge_vectors]
     ks = _lib.KeySet(keys)
-    assert ks.hbm_bytes() == n * (32 * 129 * 160 + 36 + 128)      # tables + key bytes + flags + the 128-byte Niels record of the RLC path
+    assert ks.hbm_bytes() == n * (32 * 129 * 128 + 36 + 128)      # affine 128-byte table entries + key bytes + flags + the Niels record of the RLC path
     dg = b"".join(H(v["msg"]) for v in edge_vectors)
     sg = b"".join(H(v["sig"]) for v in edge_vectors)
     # KeySet.index keeps the first position of a repeated key; the tables of equal keys are equal
@@ -176,7 +176,7 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     ks = _lib.KeySet([bytes(pks[32 * i:32 * i + 32]) for i in range(n)])
     ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs), keyset=ks)
     assert not ok and bits(bm, n) == expect
-    # the two-kernel path (n > 32,768 by size) and the one-lane cached kernel (n > 196,608 by size), forced per context
+    # the two-kernel path (n > 32,768 by size) and the one-lane cached kernel (n > 98,304 by size), forced per context
     r = DeviceRunner(n, kernel=_lib.KERNEL_LANE)
     assert r.tc_bits(rnd, hq, bytes(pks), bytes(sigs)) == expect
     keys = [bytes(pks[32 * i:32 * i + 32]) for i in range(n)]
@@ -212,7 +212,7 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
 
 @pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED])
 def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
-    """The default cached kernel up to 196,608 signatures is the three-wavefront one (two lanes per
+    """The default cached kernel up to 98,304 signatures is the three-wavefront one (two lanes per
     signature + concurrent R decompression); above, one lane per signature.  Force each on small
     inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
     r = DeviceRunner(1024, kernel=kernel)

@@ -4,6 +4,8 @@
      contexts in flight, n = 2,048 ... 262,144 -> where the library's threshold belongs
   2. per-signature cold path above the fused kernel's default range: k_verify_fused (four lanes per signature,
      table in LDS) forced at every size vs k_prepare + k_verify (one lane per signature, table in private memory)
+  3. key-cache path: k_verify_cached_lane2r (two lanes per signature + an R-decompression wavefront) vs
+     k_verify_cached_lane (one lane per signature) by size, with the affine 128-byte table entries
 Synthetic sets are signed on the GPU (hs_ed25519_public_keys / hs_ed25519_sign_batch)."""
 import os
 import sys
@@ -76,17 +78,67 @@ print("| signatures | per-signature p50 ms | RLC p50 ms | per-signature M sig/s 
 print("|---|---|---|---|---|")
 SIZES = [int(x) for x in os.environ["HS_SWEEP_SIZES"].split(",")] if os.environ.get("HS_SWEEP_SIZES") else \
     [2048, 4096, 6667, 8192, 12288, 16384, 24576, 32768, 49152, 66667, 131072, 262144]
-for n in SIZES:
+for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else SIZES):
     a = measure(n, _lib.BATCH)
     b = measure(n, _lib.BATCH_RLC)
     print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
 print("\nlibrary threshold (hs_ed25519_rlc_min_batch): %d\n" % _lib.lib().hs_ed25519_rlc_min_batch())
+SKIP12 = os.environ.get("HS_SWEEP_ONLY") == "3"
 if os.environ.get("HS_SWEEP_SIZES"):
     sys.exit(0)
 print("## 2. Per-signature cold path (strict, one digest per signature): fused four-lane kernel vs one lane per signature\n")
 print("| signatures | k_verify_fused p50 ms | k_prepare + k_verify p50 ms | fused M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
 print("|---|---|---|---|---|")
-for n in (16384, 32768, 49152, 66667, 131072, 262144):
+for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else (16384, 32768, 49152, 66667, 131072, 262144)):
     a = measure(n, _lib.STRICT, _lib.KERNEL_FUSED, shared=False)
     b = measure(n, _lib.STRICT, _lib.KERNEL_LANE, shared=False)
+    print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
+
+print("\n## 3. Key-cache path (batch semantics, shared digest, one key per signature): two-lane + R-wavefront kernel vs one-lane kernel\n")
+print("| signatures | lane2r p50 ms | lane p50 ms | lane2r M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
+print("|---|---|---|---|---|")
+
+
+def measure_cached(n, kernel, nctx=4, calls=20, reps=8):
+    dg, pk, sg = make(n, True)
+    ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(n)])
+    d_dg, d_sg = t(dg), t(sg)
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+    ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+    for c in ctxs:
+        c.set_kernel(kernel)
+    bms = [torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev) for _ in range(nctx)]
+    nrs = torch.zeros(nctx, dtype=torch.int32, device=dev)
+    sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+    torch.cuda.synchronize(dev)
+
+    def call(j):
+        ctxs[j].verify_cached(ks, d_dg.data_ptr(), 0, d_ki.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bms[j].data_ptr(), nrs[j:].data_ptr(), 0)
+    lat = []
+    for i in range(calls + 4):
+        sts[0].synchronize(); t0 = time.perf_counter(); call(0); sts[0].synchronize()
+        if i >= 4:
+            lat.append(time.perf_counter() - t0)
+    assert bool((bms[0].view(torch.int64)[: n // 64] == -1).all()) and int(nrs[0].item()) == 0
+    for j in range(nctx):
+        call(j)
+    for s_ in sts:
+        s_.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        for j in range(nctx):
+            call(j)
+    for s_ in sts:
+        s_.synchronize()
+    wall = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    ks.close()
+    lat.sort()
+    return lat[len(lat) // 2] * 1e3, reps * nctx * n / wall / 1e6
+
+
+for n in (1024, 6667, 16384, 66667, 131072, 262144):
+    a = measure_cached(n, _lib.KERNEL_FUSED)
+    b = measure_cached(n, _lib.KERNEL_LANE)
     print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
