@@ -392,3 +392,75 @@ def test_several_batches_in_one_launch(oracle):
     with pytest.raises(_lib.EngineError):
         ctx.verify_batches(big)
     ctx.close()
+
+
+def test_mixed_concurrent_callers(oracle):
+    """24 host threads hammer the host-pointer API at once with every kind of call - small strict batches (narrow
+    pool), QC-sized batch / RLC calls (wide pool), key-cache calls, wire frames, timeout certificates - each with a
+    few corrupted signatures.  Every verdict and bitmap must equal the oracle's; nothing may deadlock (pools of 16 + 4
+    contexts serve 24 callers)."""
+    import base64
+    import hashlib
+    import struct
+    import threading
+    from test_wire_and_sign_emu import element
+    cases = []
+    for k, (n, shared, mode) in enumerate([(1, False, _lib.STRICT), (3, True, _lib.BATCH), (64, False, _lib.STRICT), (700, True, _lib.BATCH_RLC),
+                                           (1024, False, _lib.STRICT), (6667, True, _lib.BATCH), (6667, True, _lib.BATCH_RLC), (200, False, _lib.BATCH)]):
+        dg, pk, sg = synth.make_batch(n, shared=shared, first=50000 + 7000 * k, cache_dir=CACHE)
+        if n > 2:
+            dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=24)
+        expect = oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, 1 if mode == _lib.STRICT else 0)
+        cases.append(("plain", (dg, pk, sg, n, mode, shared), expect))
+    n = 500
+    dg, pk, sg = synth.make_batch(n, shared=True, first=90000, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    dgc, pkc, sgc, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=16)
+    keysc = [pkc[32 * i:32 * i + 32] for i in range(n)]
+    packed, idx = ks.indices(keysc)
+    expect = bytearray(oracle_verify_many(oracle, dgc, 0, pkc, sgc, n, 0))
+    for i in range(n):
+        if idx[i] == _lib.KeySet.UNKNOWN:
+            expect[i] = 0
+    cases.append(("cached", (dgc, packed, sgc, n), bytes(expect)))
+    frames = b"".join(element(base64.b64encode(pkc[32 * i:32 * i + 32]).decode(), sgc[64 * i:64 * i + 64]) for i in range(n))
+    cases.append(("wire", (dgc, frames, n), oracle_verify_many(oracle, dgc, 0, pkc, sgc, n, 0)))
+    rnd, hq = 31, [i % 5 for i in range(n)]
+    tpk, tsg = bytearray(), bytearray()
+    for i in range(n):
+        p, s = synth.sign(synth.key_seed(95000 + i), hashlib.sha512(struct.pack("<QQ", rnd, hq[i])).digest()[:32])
+        tpk += p; tsg += s if i % 97 else s[:40] + bytes([s[40] ^ 8]) + s[41:]
+    tdg = b"".join(hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq)
+    cases.append(("tc", (rnd, hq, bytes(tpk), bytes(tsg)), oracle_verify_many(oracle, tdg, 32, bytes(tpk), bytes(tsg), n, 1)))
+    errors = []
+
+    def worker(t):
+        try:
+            for r in range(12):
+                kind, a, expect = cases[(t + r) % len(cases)]
+                if kind == "plain":
+                    dg_, pk_, sg_, n_, mode_, shared_ = a
+                    ok, bm = _lib.verify_packed(dg_, pk_, sg_, n_, mode_, shared=shared_, want_bitmap=True)
+                elif kind == "cached":
+                    ok, bm = ks.verify_packed(a[0], a[1], a[2], a[3], _lib.BATCH, shared=True, want_bitmap=True)
+                    n_ = a[3]
+                elif kind == "wire":
+                    ok, bm = _lib.verify_wire(a[1], a[2], digest=a[0], mode=_lib.BATCH)
+                    n_ = a[2]
+                else:
+                    ok, bm = _lib.verify_tc_packed(a[0], a[1], a[2], a[3])
+                    n_ = len(a[1])
+                if bits(bm, n_) != expect or ok != all(expect):
+                    errors.append((t, r, kind))
+        except Exception as e:       # noqa: BLE001 - the test reports it
+            errors.append((t, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+    for x in threads:
+        x.start()
+    for x in threads:
+        x.join(timeout=120)
+    assert not any(x.is_alive() for x in threads), "a caller is stuck"
+    assert not errors, errors[:5]
+    ks.close()
