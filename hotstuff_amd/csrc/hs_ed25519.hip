@@ -518,7 +518,7 @@ static std::atomic<size_t> g_max_batch{0};
 // Pool sizes per device slot.  Every context owns a stream and HIP multiplexes streams onto 16 hardware queues
 // (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
 // narrow contexts - one per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
-static const int kMaxPool[2] = {4, 16};
+static int kMaxPool[2] = {4, 16};              // HS_ED25519_POOL_NARROW overrides the second (read at init; measurement aid)
 // cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
 // one lane per signature above.  Round 1 switched at 196,608; with the affine 128-byte table entries the one-lane
 // kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
@@ -651,6 +651,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     // runtime reads this when it initialises, so it only takes effect when this library is the
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
     int have = 0;
     HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");

@@ -1,15 +1,24 @@
 #!/bin/bash
-mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "== full suite"; timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/t_all.log 2>&1; echo "rc=$?"; grep -E "passed|failed" gpurun_out/t_all.log; grep -E "^FAILED" gpurun_out/t_all.log | head
-echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "rc=$?"
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench.json'))
-print(d['value'], d['roofline']['avg_kernel_ms'])
-c=d['committee_cached']; print({k:c[k] for k in ('value','avg_kernel_ms','keyset_build_ms','keyset_hbm_bytes')}); print(json.dumps(c['large_committee'])[:600])
-q=d['qc_verify_latency']; print(q['p50_ms_host_api'], q['p50_ms_device_resident'], q['committee_cached'])
-s=d['streamed_rounds']; print({k:(v['signatures_per_s'],v['submit_to_verdict_p50_ms']) for k,v in s.items() if isinstance(v,dict)})
-print(d['small_batch_crossover']['rows'][:3])
+for cfg in "16 16 16" "32 16 16" "32 16 32" "32 8 32" "24 8 16"; do
+set -- $cfg
+HS_ED25519_POOL_NARROW=$1 HS_ED25519_POOL_PARTITIONS=$2 GPU_MAX_HW_QUEUES=$3 python - <<'PY'
+import ctypes, os, sys
+sys.path.insert(0,'.'); sys.path.insert(0,'tools')
+import synth
+from hotstuff_amd import _lib
+_lib.init(0,1024)
+lib=_lib.lib()
+n=1024
+bt=[synth.make_batch(n, shared=False, first=j*n, cache_dir='/tmp/hs_synth') for j in range(16)]
+dg=b"".join(b[0] for b in bt); pk=b"".join(b[1] for b in bt); sg=b"".join(b[2] for b in bt)
+bufs=[ctypes.create_string_buffer(x,len(x)) for x in (dg,pk,sg)]
+a=[ctypes.addressof(x) for x in bufs]
+out=[]
+for th in (16,24,32,48):
+    calls,p50,el=ctypes.c_uint64(),ctypes.c_double(),ctypes.c_double()
+    rc=lib.hs_ed25519_loadgen(a[0],32,a[1],a[2],n,16,1,th,0.5,ctypes.byref(calls),ctypes.byref(p50),ctypes.byref(el))
+    out.append('%d thr: %.1f M/s p50 %.3f' % (th, calls.value*n/el.value/1e6, p50.value))
+print('narrow', os.environ['HS_ED25519_POOL_NARROW'], 'partitions', os.environ['HS_ED25519_POOL_PARTITIONS'], 'hwq', os.environ['GPU_MAX_HW_QUEUES'], '|', ' | '.join(out))
 PY
+done
