@@ -229,7 +229,10 @@ __device__ __forceinline__ void pt_store40(u32 *dst, const ge_p3 &p) {
 // owns chunks segoff[j] .. segoff[j + 1]); chunks of one bucket sit in consecutive lanes, so the wavefront then
 // folds them with a SEGMENTED suffix scan (6 shuffle + add steps keyed by the bucket) and only the first lane of
 // each bucket's stretch writes a partial: a bucket ends up with one partial per wavefront it spans.
-__global__ void __launch_bounds__(64)
+#ifndef HS_RLC_ACCUM_WAVES
+#define HS_RLC_ACCUM_WAVES 2       // wavefronts per SIMD the register allocator leaves room for (A/B: -DHS_RLC_ACCUM_WAVES=3)
+#endif
+__global__ void __launch_bounds__(64, HS_RLC_ACCUM_WAVES)
 k_rlc_accum(const u32 *__restrict__ sorted, const u32 *__restrict__ boff, const u32 *__restrict__ segoff,
             const u32 *__restrict__ rec, const u32 *__restrict__ ksn, u32 NP, u32 C, u32 Lcap, u32 *__restrict__ part) {
     __shared__ u32 s_seg[HS_RLC_BUCKETS + 1], s_off[HS_RLC_BUCKETS + 1];
