@@ -497,6 +497,8 @@ def main():
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
+    ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "2")),
+                    help="batches per hs_ed25519_verify_device_batches_cached launch in the committee_cached extra")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
     ap.add_argument("--no-cached", action="store_true", help="skip the committee-key-cache extra")
@@ -645,32 +647,38 @@ def main():
         build_ms = (time.perf_counter() - t0) * 1e3
         d_ki = torch.arange(n * ns, dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
+        KC = max(1, min(16, args.cached_batches_per_launch))
+        # context j verifies KC independent batches per launch (its own and its neighbours'), each with its own bitmap
+        c_bm = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns * KC)]
+        c_nr = torch.zeros(ns * KC, dtype=torch.int32, device=dev)
+        clists = [_lib.batch_array([(p_in[(j + k) % ns][0], stride, d_ki[((j + k) % ns) * n:].data_ptr(), p_in[(j + k) % ns][2], n, mode,
+                                     c_bm[j * KC + k].data_ptr(), c_nr[j * KC + k:].data_ptr()) for k in range(KC)]) for j in range(ns)]
+        cfn = _lib.lib().hs_ed25519_verify_device_batches_cached
+        ccalls = [(ctxs[j]._h, ks.handle, ctypes.cast(clists[j], ctypes.c_void_p), KC, p_st[j]) for j in range(ns)]
+        claunches = (B + KC - 1) // KC
         for c in ctxs:
-            c.set_profiling(max(1, per_ctx // args.event_stride + 1), every=args.event_stride)
-        cfn = _lib.lib().hs_ed25519_verify_device_cached
-        ccalls = [(ctxs[j]._h, ks.handle, p_in[j][0], stride, d_ki[j * n:].data_ptr(), p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j])
-                  for j in range(ns)]
-        for c in ctxs:
-            c.set_profiling(max(1, (args.steps * B + ns - 1) // ns // args.event_stride + 1), every=args.event_stride)
+            c.set_profiling(max(1, (args.steps * claunches + ns - 1) // ns // args.event_stride + 1), every=args.event_stride)
 
         def cstep(i):
-            for b in range(B):
+            for b in range(claunches):
                 if cfn(*ccalls[b % ns]) != 0:
-                    raise RuntimeError("hs_ed25519_verify_device_cached failed: " + _lib.last_error())
+                    raise RuntimeError("hs_ed25519_verify_device_batches_cached failed: " + _lib.last_error())
 
         for i in range(args.warmup):
             cstep(i)
-        nrej.zero_()
+        c_nr.zero_()
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
             cstep(i)
         fence()
         c_elapsed = time.perf_counter() - t0
-        assert int(nrej.sum().item()) == 0, "cached path rejected valid signatures"
+        assert int(c_nr.sum().item()) == 0, "cached path rejected valid signatures"
+        for bmp in c_bm:
+            assert bool((bmp.view(torch.int64)[: n // 64] == -1).all()), "bitmap of a timed key-cache batch is not all ones"
         k_ms = sum(c.kernel_times()[1] for c in ctxs) / max(1, sum(c.kernel_times()[2] for c in ctxs))
-        cached = {"value": round(n * B * args.steps / c_elapsed, 1), "unit": "verifies/s",
-                  "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": _lib.lib().hs_ed25519_cached_kernel_for(n).decode(),
+        cached = {"value": round(n * claunches * KC * args.steps / c_elapsed, 1), "unit": "verifies/s", "batches_per_launch": KC,
+                  "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": "k_verify_cached_lane2r_batches",
                   "avg_kernel_ms": round(k_ms, 4), "keys": n * ns, "keyset_hbm_bytes": ks.hbm_bytes(),
                   "keyset_build_ms": round(build_ms, 2),
                   "table_bytes_read_per_verify": 64 * 128,

@@ -86,6 +86,8 @@ def lib():
                 l.hs_ed25519_verify_device_tc_cached.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_batches.argtypes = [vp, vp, sz, vp]
                 l.hs_ed25519_verify_device_batches.restype = ctypes.c_int
+                l.hs_ed25519_verify_device_batches_cached.argtypes = [vp, vp, vp, sz, vp]
+                l.hs_ed25519_verify_device_batches_cached.restype = ctypes.c_int
                 l.hs_ed25519_loadgen.argtypes = [vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_double,
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                                  ctypes.POINTER(ctypes.c_double)]
@@ -500,6 +502,11 @@ class DeviceContext:
         """hs_ed25519_verify_device_batches: `batches` = a ctypes array from batch_array()."""
         check(lib().hs_ed25519_verify_device_batches(self._h, ctypes.cast(batches, ctypes.c_void_p), len(batches), stream or None),
               "hs_ed25519_verify_device_batches")
+
+    def verify_batches_cached(self, keyset, batches, stream=0):
+        """hs_ed25519_verify_device_batches_cached: d_pks of every entry = the batch's uint32 key indices."""
+        check(lib().hs_ed25519_verify_device_batches_cached(self._h, keyset.handle, ctypes.cast(batches, ctypes.c_void_p), len(batches),
+                                                            stream or None), "hs_ed25519_verify_device_batches_cached")
 
     def verify_cached(self, keyset, d_digests, digest_stride, d_key_idx, d_sigs, n, mode, d_bitmap, d_nreject=0, stream=0):
         check(lib().hs_ed25519_verify_device_cached(self._h, keyset.handle, d_digests, digest_stride, d_key_idx, d_sigs,

@@ -385,23 +385,22 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
 // wavefront 2 meanwhile decompresses the 64 R's one lane each and hands (x_R, y_R, flags) over
 // through LDS; the chains then finish with a projective comparison instead of an inversion that both
 // lanes of a pair would execute.  Per 64 signatures: 2 x 52 K + 36 K instructions instead of 2 x 82 K.
-__global__ void __launch_bounds__(192)
-k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
-                       const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                       u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
+// `block` = this workgroup's index within its batch (64 signatures per workgroup)
+__device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ btab,
+                                                    msg_src msgs, const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                                                    u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (skip && *skip) {
-        const u32 first = blockIdx.x * 64 + wave * 32;
+        const u32 first = block * 64 + wave * 32;
         const u32 here = first < n ? min(32u, n - first) : 0u;
-        if (wave < 2 && lane == 0) bitmap32[blockIdx.x * 2 + wave] = here == 32 ? 0xffffffffu : ((1u << here) - 1);
+        if (wave < 2 && lane == 0) bitmap32[block * 2 + wave] = here == 32 ? 0xffffffffu : ((1u << here) - 1);
         return;
     }
     const bool strict = (mode & HS_MODE_STRICT) != 0;
     ge_p3 acc;
     bool ok = false, active = false;
     if (wave == 2) {
-        const u32 i = blockIdx.x * 64 + lane;
+        const u32 i = block * 64 + lane;
         const u32 j = i < n ? i : n - 1;
         u32 enc[8];
 #pragma unroll
@@ -413,7 +412,7 @@ k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, 
         for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
         s_r[20][lane] = fl;
     } else {
-        const u32 i = blockIdx.x * 64 + wave * 32 + (lane >> 1);
+        const u32 i = block * 64 + wave * 32 + (lane >> 1);
         active = i < n;
         const u32 j = active ? i : n - 1;
         const u32 ki_raw = key_idx[j];
@@ -444,14 +443,34 @@ k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, 
     m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
     m = (m | (m >> 16)) & 0xffffffffull;
     if (lane == 0) {
-        bitmap32[blockIdx.x * 2 + wave] = (u32)m;
+        bitmap32[block * 2 + wave] = (u32)m;
         if (nreject) {
-            const u32 first = blockIdx.x * 64 + wave * 32;
+            const u32 first = block * 64 + wave * 32;
             const u32 sigs_here = first < n ? min(32u, n - first) : 0u;
             const u32 bad = sigs_here - (u32)__popcll(m);
             if (bad) atomicAdd(nreject, bad);
         }
     }
+}
+__global__ void __launch_bounds__(192)
+k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+                       const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                       u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
+    cached_lane2r_block(s_r, blockIdx.x, ks, nkeys, btab, msgs, key_idx, sigs, n, mode, bitmap32, nreject, skip);
+}
+// several independent small key-cache batches in one grid (hs_ed25519_verify_device_batches_cached): a 1,024-signature
+// batch is only 16 workgroups of three wavefronts here
+struct cached_batch { msg_src msgs; const u32 *key_idx, *sigs; u32 *bitmap32; u32 *nreject; u32 n, mode, first_block, pad; };
+struct cached_batch_list { cached_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+__global__ void __launch_bounds__(192)
+k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, cached_batch_list L) {
+    __shared__ u32 s_r[21][64];
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const cached_batch &B = L.b[k];
+    cached_lane2r_block(s_r, blockIdx.x - B.first_block, ks, nkeys, btab, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
 }
 
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches
@@ -859,6 +878,47 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
         void *a[] = { &L };
         HS_HIP(launch1((const void *)k_verify_fused_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused_batches");
+    }
+    return 0;
+}
+// The same for the key-cache path: batches[i].d_pks holds the uint32 key indices of batch i.
+extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const hs_ed25519_batch *batches,
+                                                       size_t count, void *stream) {
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!ctx || !ks || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: null context / key set / list");
+    if (ks->slot != ctx->slot) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: the key set lives on another device slot than the context");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
+    u32 nkeys = (u32)ks->nkeys;
+    const u32 *p_bt = g_devs[ctx->slot].base_tab;
+    size_t done = 0;
+    while (done < count) {
+        cached_batch_list L;
+        L.count = 0;
+        u32 blocks = 0;
+        for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
+            const hs_ed25519_batch &b = batches[done];
+            if (b.n == 0) continue;
+            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: mode must be BATCH / STRICT and n <= 32,768");
+            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: null pointer");
+            if (misaligned(b.d_pks, 4) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
+                return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: misaligned pointer");
+            cached_batch &f = L.b[L.count++];
+            int rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
+            if (rc) return rc;
+            f.key_idx = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap32 = (u32 *)b.d_bitmap;
+            f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode; f.first_block = blocks; f.pad = 0;
+            blocks += (u32)(round_up(b.n, 64) / 64);
+        }
+        if (!L.count) continue;
+        const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+        const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+        hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
+        if (ev) ctx->ev_mid[slot] = 0;
+        void *a[] = { &kv, &nkeys, &p_bt, &L };
+        HS_HIP(launch1((const void *)k_verify_cached_lane2r_batches, dim3(blocks), dim3(192), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_cached_lane2r_batches");
     }
     return 0;
 }

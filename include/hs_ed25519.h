@@ -181,6 +181,10 @@ int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *d
 int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
                                     size_t digest_stride, const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n,
                                     uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream);
+/* Several small key-cache batches in one launch (hs_ed25519_verify_device_batches with key indices): batches[i].d_pks
+ * holds batch i's n uint32 key indices (4-byte aligned) instead of key bytes; mode BATCH or STRICT, n <= 32,768 each. */
+int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const hs_ed25519_batch *batches,
+                                            size_t count, void *stream);
 
 /* ---- TC::verify with the per-vote digests built on the device ------------------------------
  * consensus/src/messages.rs:307-313 hashes SHA-512(round_le || high_qc_round_le)[..32] on the

@@ -113,7 +113,7 @@ def test_qc_and_tc_through_the_committee_cache(openssl_vectors):
 
 
 def test_qc_10000_validators_cached_properties():
-    """BASELINE config 3 with the committee cached: N = 10,000 keys (6.6 GB of tables in HBM),
+    """BASELINE config 3 with the committee cached: N = 10,000 keys (5.3 GB of tables in HBM),
     a QC of 6,667 votes by a subset; oracle-free properties."""
     N, n = 10000, 6667
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)

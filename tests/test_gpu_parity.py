@@ -394,6 +394,56 @@ def test_several_batches_in_one_launch(oracle):
     ctx.close()
 
 
+def test_several_key_cache_batches_in_one_launch(oracle):
+    """hs_ed25519_verify_device_batches_cached: 18 independent batches (two grids) against one key set - different
+    sizes, digest forms and modes, permuted / repeated / unknown key indices, corrupted signatures - each with its
+    own bitmap and reject counter; verdicts vs the oracle (an unknown index is a rejected signature)."""
+    import random
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    nk = 300
+    _, kpk, _ = synth.make_batch(nk, shared=True, first=0, cache_dir=CACHE)
+    keys = [kpk[32 * i:32 * i + 32] for i in range(nk)]
+    ks = _lib.KeySet(keys)
+    sizes = [1, 2, 31, 32, 33, 63, 64, 65, 127, 200, 300, 1024, 1000, 5, 129, 700, 257, 64]
+    ctx = _lib.DeviceContext(1024)
+    rng = random.Random(11)
+    keep, entries, expect = [], [], []
+    nr = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
+    for k, n in enumerate(sizes):
+        shared, mode = bool(k % 2), (_lib.STRICT if k % 3 else _lib.BATCH)
+        who = [rng.randrange(nk) for _ in range(n)]
+        dg = os.urandom(32) if shared else os.urandom(32 * n)
+        sg = b"".join(synth.sign(synth.key_seed(who[i]), dg if shared else dg[32 * i:32 * i + 32])[1] for i in range(n))
+        pk = b"".join(keys[w] for w in who)
+        dg, _, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=40)      # key-byte flips cannot be expressed here: keys stay as built
+        want = bytearray(oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, mode))
+        idx = list(who)
+        if n > 4:
+            idx[3] = _lib.KeySet.UNKNOWN
+            want[3] = 0
+        d = [t(dg), torch.tensor([x if x < 2 ** 31 else x - 2 ** 32 for x in idx], dtype=torch.int32, device=dev),
+             t(sg), torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)]
+        keep.append(d)
+        expect.append(bytes(want))
+        entries.append((d[0].data_ptr(), 0 if shared else 32, d[1].data_ptr(), d[2].data_ptr(), n, mode, d[3].data_ptr(),
+                        nr[k:].data_ptr()))
+    torch.cuda.synchronize(dev)
+    ctx.verify_batches_cached(ks, _lib.batch_array(entries))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    for k, n in enumerate(sizes):
+        got = bits(bytes(keep[k][3].cpu().tolist()), n)
+        assert got == expect[k], "batch %d (n = %d)" % (k, n)
+        assert int(nr[k].item()) == sum(1 for b in got if not b)
+    assert any(all(e) for e in expect) and sum(1 for e in expect if not all(e)) >= 10
+    bad_mode = _lib.batch_array([(keep[0][0].data_ptr(), 0, keep[0][1].data_ptr(), keep[0][2].data_ptr(), 1, _lib.BATCH_RLC,
+                                  keep[0][3].data_ptr(), 0)])
+    with pytest.raises(_lib.EngineError):
+        ctx.verify_batches_cached(ks, bad_mode)
+    ctx.close()
+    ks.close()
+
+
 def test_mixed_concurrent_callers(oracle):
     """24 host threads hammer the host-pointer API at once with every kind of call - small strict batches (narrow
     pool), QC-sized batch / RLC calls (wide pool), key-cache calls, wire frames, timeout certificates - each with a
