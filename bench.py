@@ -340,12 +340,13 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
     return out
 
 
-def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8):
-    """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI
-    (hs_ed25519_verify_multi / _shared).  `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads
-    would measure the interpreter lock) each verify their own 1,024-tuple batch in a loop; every call stages
-    into pinned memory, launches on its pool context's CU-partitioned stream and waits for its verdict.
-    PCIe-inclusive."""
+def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8, inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2))):
+    """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
+    `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads would measure the interpreter lock) each
+    verify their own 1,024-tuple batch in a loop; every call stages into pinned memory, launches on a pool context's
+    CU-partitioned stream and waits for its verdict.  PCIe-inclusive.  Rows: the synchronous calls
+    (hs_ed25519_verify_multi) from 1, threads/2 and threads threads, then the asynchronous form
+    (hs_ed25519_submit / hs_ed25519_ticket_wait) as (threads, tickets in flight per thread, batches per launch)."""
     lib = _lib.lib()
     dg = b"".join(b[0] for b in batches)
     pk = b"".join(b[1] for b in batches)
@@ -353,16 +354,20 @@ def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8):
     bufs = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
     a = [ctypes.addressof(x) for x in bufs]
     out = {"unit": "verifies/s", "signatures_per_call": n,
-           "path": "host buffers -> pinned staging -> kernel reads over PCIe (zero-copy) -> pinned bitmap -> host verdict"}
+           "path": "host buffers -> pinned staging -> kernel reads over PCIe (zero-copy) -> pinned bitmap -> host verdict",
+           "api": "rows with in_flight_per_thread 1: hs_ed25519_verify_multi (synchronous); above: hs_ed25519_submit bursts "
+                  "(HS_ED25519_SUBMIT_MORE on all but the last of `batches_per_launch`) + hs_ed25519_ticket_wait"}
     best = None
-    for th in sorted({1, threads // 2, threads}):
-        if th < 1:
-            continue
+    # (host threads, tickets in flight per thread): the synchronous calls at 1, half and all the threads, then
+    # the asynchronous form (hs_ed25519_submit / hs_ed25519_ticket_wait) with the same threads
+    shapes = [(th, 1, 1) for th in sorted({1, threads // 2, threads}) if th >= 1]
+    shapes += [(th, k, bpl) for th, k, bpl in inflight]
+    for th, k, bpl in shapes:
         calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.hs_ed25519_loadgen(a[0], stride, a[1], a[2], n, len(batches), mode, th, seconds if th == threads else seconds / 2,
+        _lib.check(lib.hs_ed25519_loadgen(a[0], stride, a[1], a[2], n, len(batches), mode, th, k, bpl, seconds if th == threads else seconds / 2,
                                           ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el)), "hs_ed25519_loadgen")
-        row = {"host_threads": th, "calls": calls.value, "seconds": round(el.value, 3), "call_p50_ms": round(p50.value, 4),
-               "value": round(calls.value * n / el.value, 1)}
+        row = {"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": bpl, "calls": calls.value, "seconds": round(el.value, 3),
+               "call_p50_ms": round(p50.value, 4), "value": round(calls.value * n / el.value, 1)}
         out.setdefault("by_threads", []).append(row)
         if best is None or row["value"] > best["value"]:
             best = row

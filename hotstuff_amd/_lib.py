@@ -26,6 +26,10 @@ class EngineError(RuntimeError):
     it as a verification failure - never as success."""
 
 
+class PoolBusy(EngineError):
+    """hs_ed25519_submit: HS_ED25519_E_BUSY - every pool context is in flight; wait on a ticket and retry."""
+
+
 _lib = None
 _lock = threading.Lock()
 _inited = False
@@ -88,7 +92,13 @@ def lib():
                 l.hs_ed25519_verify_device_batches.restype = ctypes.c_int
                 l.hs_ed25519_verify_device_batches_cached.argtypes = [vp, vp, vp, sz, vp]
                 l.hs_ed25519_verify_device_batches_cached.restype = ctypes.c_int
-                l.hs_ed25519_loadgen.argtypes = [vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_double,
+                l.hs_ed25519_submit.argtypes = [ctypes.POINTER(ctypes.c_void_p), vp, vp, sz, vp, vp, sz, u32, u32]
+                l.hs_ed25519_submit.restype = ctypes.c_int
+                l.hs_ed25519_ticket_ready.argtypes = [vp]
+                l.hs_ed25519_ticket_ready.restype = ctypes.c_int
+                l.hs_ed25519_ticket_wait.argtypes = [vp, vp]
+                l.hs_ed25519_ticket_wait.restype = ctypes.c_int
+                l.hs_ed25519_loadgen.argtypes = [vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                                  ctypes.POINTER(ctypes.c_double)]
                 l.hs_ed25519_loadgen.restype = ctypes.c_int
@@ -409,6 +419,52 @@ def batch_array(entries):
     for a, e in zip(arr, entries):
         a.d_digests, a.digest_stride, a.d_pks, a.d_sigs, a.n, a.mode, a.d_bitmap, a.d_nreject = e
     return arr
+
+
+SUBMIT_MORE = 1
+E_BUSY = -5
+
+
+class Ticket:
+    """hs_ed25519_submit / hs_ed25519_ticket_wait: an asynchronous host-pointer verification.  `keys` = packed key
+    bytes, or (with `keyset`) a sequence of key indices.  Raises PoolBusy when every pool context is in flight."""
+
+    def __init__(self, digests, keys, sigs, n, mode=STRICT, shared=False, keyset=None, more=False):
+        ensure_init()
+        if keyset is not None and not isinstance(keys, (bytes, bytearray)):
+            import struct
+            keys = struct.pack("<%dI" % n, *keys)
+        self.n = n
+        self._h = ctypes.c_void_p()
+        rc = lib().hs_ed25519_submit(ctypes.byref(self._h), keyset.handle if keyset is not None else None, bytes(digests),
+                                     0 if shared else 32, bytes(keys), bytes(sigs), n, mode, SUBMIT_MORE if more else 0)
+        if rc == E_BUSY:
+            raise PoolBusy("every pool context is in flight: wait on a ticket first")
+        check(rc, "hs_ed25519_submit")
+
+    def ready(self):
+        if not self._h:
+            raise EngineError("ticket already waited on")
+        rc = lib().hs_ed25519_ticket_ready(self._h)
+        check(rc, "hs_ed25519_ticket_ready")
+        return bool(rc)
+
+    def wait(self):
+        """-> (verdict: bool, accept bitmap bytes); consumes the ticket"""
+        if not self._h:
+            raise EngineError("ticket already waited on")
+        bm = ctypes.create_string_buffer(max(1, (self.n + 7) // 8))
+        h, self._h = self._h, ctypes.c_void_p()
+        rc = lib().hs_ed25519_ticket_wait(h, bm)
+        check(rc, "hs_ed25519_ticket_wait")
+        return rc == 1, bm.raw[:(self.n + 7) // 8]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().hs_ed25519_ticket_wait(self._h, None)
+            except Exception:
+                pass
 
 
 class KeySet:

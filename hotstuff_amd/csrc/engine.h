@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include <vector>
 #include "verify.h"
 #include "../../include/hs_ed25519.h"
@@ -39,7 +40,8 @@ enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3 };
 struct hs_ed25519_ctx {
     int slot = 0, device = 0;
     hipStream_t stream = nullptr;
-    bool narrow = false;          // a pool context whose stream is confined to one sixteenth of the CUs (small host-API calls)
+    hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
+    bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     size_t cap = 0;               // signatures
     hs::u32 *d_ws = nullptr;      // workspace of the two-kernel cold path
     uint8_t *d_in = nullptr;      // digests | keys | sigs   (host API only)
@@ -70,7 +72,8 @@ struct hs_ed25519_keyset {
 
 namespace hs {
 int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging);
-int pool_get(hs_ed25519_ctx **out, int slot, size_t n);   // a narrow (CU-partitioned) context for small n, a wide one above
+// a narrow (CU-partitioned) context for small n, a wide one above; nowait: HS_ED25519_E_BUSY instead of waiting for a free one
+int pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait = false);
 void pool_put(hs_ed25519_ctx *c);
 int make_digest_src(msg_src &m, const uint8_t *d_digests, size_t digest_stride);
 // per-signature cold path over n signatures, optionally skipped when *d_skip != 0 (then the bitmap is
@@ -83,7 +86,7 @@ int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msg
 // one host-pointer verification on one device slot, split so that several devices can be in flight from one thread
 struct host_job { hs_ed25519_ctx *c = nullptr; size_t n = 0; bool zc = false; };
 int host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
-                const void *keys, const uint8_t *sigs, size_t n, uint32_t mode);
+                const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait = false);
 int host_finish(host_job &job, uint8_t *bitmap);          // 1 / 0 / <0; returns the context to its pool
 void host_abandon(host_job &job);                          // after a failed submit
 const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap (valid until finish)

@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <new>
 #include <mutex>
 #include <condition_variable>
 #include <vector>
@@ -164,7 +165,7 @@ k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict_
     fused_block(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
 }
 // Several independent small batches in ONE grid (hs_ed25519_verify_device_batches): a 1,024-signature
-// batch is only 64 wavefronts - one per SIMD of the 16 CUs its stream is confined to - and a lone
+// batch is only 64 wavefronts - at most one per SIMD of the CU slice its stream is confined to - and a lone
 // wavefront issues at about half the rate two co-resident ones reach (profiles/r1_ubench_valu.txt).
 // Back-to-back launches of one stream do not overlap and more than 16 streams collapse
 // (profiles/r1_stream_sweep.txt), so the way to more wavefronts per SIMD is more batches per launch.
@@ -524,7 +525,7 @@ int hs::hs_fail(int code, const char *what, hipError_t e) {
 struct dev_state {
     int ordinal = -1;
     u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
-    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one sixteenth of the CUs)
+    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one XCD-aligned slice of the CUs)
     std::vector<hs_ed25519_ctx *> free_ctx[2];
     int live[2] = {0, 0};
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
@@ -536,7 +537,7 @@ static std::vector<dev_state> g_devs;        // written under g_mu by init / shu
 static std::atomic<size_t> g_max_batch{0};
 // Pool sizes per device slot.  Every context owns a stream and HIP multiplexes streams onto 16 hardware queues
 // (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
-// narrow contexts - one per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
+// narrow contexts - two per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
 static int kMaxPool[2] = {4, 16};              // HS_ED25519_POOL_NARROW overrides the second (read at init; measurement aid)
 // cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
 // one lane per signature above.  Round 1 switched at 196,608; with the affine 128-byte table entries the one-lane
@@ -545,12 +546,17 @@ static int kMaxPool[2] = {4, 16};              // HS_ED25519_POOL_NARROW overrid
 static const size_t kCachedLane1Min = 98304;
 static const size_t kZeroCopyMax = 16384;    // host-pointer calls up to this size let the kernels read pinned memory directly
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
-// Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel = one per SIMD of 16 CUs) are
-// served by the NARROW pool, whose streams are confined to one sixteenth of the CUs each: concurrent callers then
-// occupy disjoint slices of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py
-// `end_to_end`); one caller alone loses nothing, its batch is one wavefront per SIMD either way.
+// Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
+// pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
+// of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py `end_to_end`); one caller
+// alone loses nothing, its batch is at most one wavefront per SIMD either way.
 static const size_t kPartitionMaxBatch = 1024;
-static unsigned kPoolPartitions = 16;           // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
+// The narrow pool's streams are confined to XCD-aligned slices of the chip: 8 slices of 32 CUs, two contexts on each.
+// Two launches of two 1,024-signature batches then share a slice at two wavefronts per SIMD: 49-50 M verifies/s from
+// host buffers through hs_ed25519_submit bursts (16 slices of 16 CUs with one context each: 41.7 M - the two
+// wavefronts of a SIMD then come from ONE launch and run 18 % longer; profiles/r2_e2e_async.txt).  The synchronous
+// calls pay for it at 16 concurrent callers (21.5 against 26.8 M verifies/s; equal up to 8 callers).
+static unsigned kPoolPartitions = 8;            // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
 
 int hs::dev_slots() { return g_init.load() ? (int)g_devs.size() : 0; }
 int hs::dev_ordinal(int slot) { return (slot >= 0 && slot < hs::dev_slots()) ? g_devs[slot].ordinal : -1; }
@@ -631,6 +637,7 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->done) (void)hipEventDestroy(c->done);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
     hs::rlc_release(c);
@@ -709,6 +716,7 @@ extern "C" void hs_ed25519_shutdown(void) {
             d.free_ctx[k].clear(); d.live[k] = 0;
         }
         if (d.base_tab) { (void)hipSetDevice(d.ordinal); (void)hipFree(d.base_tab); d.base_tab = nullptr; }
+        // tickets still outstanding keep their group alive; its context is destroyed when they are waited on
     }
     g_devs.clear();
 }
@@ -1161,7 +1169,7 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
-int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n) {
+int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     const int k = n <= kPartitionMaxBatch ? 1 : 0;
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
@@ -1171,6 +1179,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n) {
         dev_state &d = g_devs[slot];
         if (!d.free_ctx[k].empty()) { *out = d.free_ctx[k].back(); d.free_ctx[k].pop_back(); return 0; }
         if (d.live[k] < kMaxPool[k]) { d.live[k]++; break; }
+        if (nowait) return HS_ED25519_E_BUSY;       // not an error worth a message: the caller retries after a wait
         g_cv.wait(lk);
     }
     const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
@@ -1204,9 +1213,9 @@ void hs::pool_put(hs_ed25519_ctx *c) {
 // exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
 //   keys: n*32 key bytes (ks == NULL) or n uint32 indices into `ks`
 int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
-                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode) {
+                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait) {
     job.c = nullptr; job.n = n;
-    int rc = pool_get(&job.c, slot, n);
+    int rc = pool_get(&job.c, slot, n, nowait);
     if (rc) return rc;
     hs_ed25519_ctx *c = job.c;
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
@@ -1252,15 +1261,197 @@ void hs::host_abandon(host_job &job) {
 }
 const uint8_t *hs::host_job_bitmap(const host_job &job) { return job.c ? job.c->h_out : nullptr; }
 
+// ---- small host calls: several per launch ------------------------------------------------------
+// One 1,024-signature batch is one wavefront per SIMD of its context's CU slice, and a lone
+// wavefront issues the 64-bit multiply-adds at half the rate two co-resident ones reach; the streams
+// cannot be multiplied instead (16 hardware queues).  So the small host calls (n <= kPartitionMaxBatch)
+// of one BURST - consecutive submits of one thread, all but the last flagged HS_ED25519_SUBMIT_MORE -
+// form a GROUP: one pool context, one launch (k_verify_fused_batches / k_verify_cached_lane2r_batches),
+// each member with its own slice of the pinned staging and its own bitmap.  A group launches when a
+// member arrives without the flag, when it is full, when a call of another kind follows, or when any
+// of its tickets is waited on or polled - never by a timer, and never later than that: a lone
+// synchronous call launches at once, exactly as before.  Groups are per thread (a burst is not
+// diluted by other threads' calls); tickets may be waited on from any thread.
+static const unsigned kGroupMax = 4;
+struct host_group {
+    std::mutex mu;
+    std::condition_variable cv;
+    hs_ed25519_ctx *c = nullptr;
+    const hs_ed25519_keyset *ks = nullptr;
+    int slot = 0;
+    // all under mu
+    unsigned members = 0, staged = 0, refs = 0;
+    bool closed = false, launched = false;
+    int launch_rc = 0;
+    hs_ed25519_batch desc[kGroupMax];
+};
+static const size_t kGroupInStride = 128 * kPartitionMaxBatch;       // staging bytes per member
+static size_t group_out_stride() { return bitmap_bytes(kPartitionMaxBatch); }
+
+// no more members; then on its stream (idempotent; waits until every member's bytes are staged)
+static int group_close_and_launch(host_group *g) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->closed = true;
+    if (g->launched) return g->launch_rc;
+    g->cv.wait(lk, [g] { return g->staged == g->members || g->launched; });
+    if (g->launched) return g->launch_rc;
+    int rc = 0;
+    if (hipSetDevice(g->c->device) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    else if (g->ks) rc = hs_ed25519_verify_device_batches_cached(g->c, g->ks, g->desc, g->members, g->c->stream);
+    else rc = hs_ed25519_verify_device_batches(g->c, g->desc, g->members, g->c->stream);
+    if (!rc && hipEventRecord(g->c->done, g->c->stream) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipEventRecord");
+    g->launch_rc = rc;
+    g->launched = true;
+    g->cv.notify_all();
+    return rc;
+}
+static void group_unref(host_group *g) {
+    bool last;
+    { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
+    if (last) { pool_put(g->c); delete g; }
+}
+// this thread's open group (it holds a reference); a thread that exits launches what it left open
+struct open_group_slot {
+    host_group *g = nullptr;
+    void drop(bool launch) { if (g) { if (launch) (void)group_close_and_launch(g); group_unref(g); g = nullptr; } }
+    ~open_group_slot() { drop(true); }
+};
+static thread_local open_group_slot t_open;
+
+// join this thread's open group or start one; stage; launch unless `more`.  *idx_out = the member's position.
+static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                        const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool more, bool nowait) {
+    const int slot = ks ? ks->slot : 0;
+    host_group *g = t_open.g;
+    unsigned idx = 0;
+    bool closer = false;
+    if (g) {
+        bool joined = false;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (!g->closed && g->ks == ks && g->slot == slot && g->members < kGroupMax) {
+                idx = g->members++; g->refs++; joined = true;
+                if (!more || g->members == kGroupMax) { g->closed = true; closer = true; }
+            }
+        }
+        if (!joined) { t_open.drop(true); g = nullptr; }       // waited on meanwhile, or another kind of call: that group goes now
+    }
+    if (!g) {
+        hs_ed25519_ctx *c = nullptr;
+        int rc = pool_get(&c, slot, n, nowait);
+        if (rc) return rc;
+        rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+        if (!rc) rc = ctx_reserve(c, kGroupMax * kPartitionMaxBatch, true);
+        if (!rc && !c->done && hipEventCreateWithFlags(&c->done, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+            rc = fail(HS_ED25519_E_DEVICE, "hipEventCreate");
+        if (!rc && !(g = new (std::nothrow) host_group())) rc = fail(HS_ED25519_E_NOMEM, "out of memory");
+        if (rc) { pool_put(c); return rc; }
+        g->c = c; g->ks = ks; g->slot = slot;
+        g->members = 1; g->refs = 1; idx = 0;
+        if (more) { g->refs++; t_open.g = g; }                  // the thread's reference to its open group
+        else { g->closed = true; closer = true; }
+    }
+    // this member's slice of the pinned staging: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n]
+    hs_ed25519_ctx *c = g->c;
+    uint8_t *in = c->h_in + idx * kGroupInStride, *outp = c->h_out + idx * group_out_stride();
+    const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16);
+    memcpy(in, digests, dg_bytes);
+    memcpy(in + off_k, keys, key_bytes);
+    memcpy(in + off_sig, sigs, 64 * n);
+    memset(outp, 0, bitmap_bytes(n));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        hs_ed25519_batch &d = g->desc[idx];
+        d.d_digests = in; d.digest_stride = digest_stride; d.d_pks = in + off_k; d.d_sigs = in + off_sig; d.n = n;
+        d.mode = mode == HS_ED25519_STRICT ? HS_ED25519_STRICT : HS_ED25519_BATCH;   // BATCH_RLC this small is the per-signature BATCH law
+        d.d_bitmap = outp; d.d_nreject = nullptr;
+        g->staged++;
+        g->cv.notify_all();
+    }
+    *g_out = g; *idx_out = idx;
+    if (closer) {
+        if (t_open.g == g) t_open.drop(false);
+        const int rc = group_close_and_launch(g);
+        if (rc) { group_unref(g); *g_out = nullptr; return rc; }
+    }
+    return 0;
+}
+// verdict of member idx; always drops the member's reference
+static int group_finish(host_group *g, unsigned idx, size_t n, uint8_t *bitmap) {
+    int rc = group_close_and_launch(g);
+    if (!rc && hipSetDevice(g->c->device) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    if (!rc) { const hipError_t e = hipEventSynchronize(g->c->done); if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, hipGetErrorString(e)); }
+    int verdict = rc;
+    if (!rc) {
+        const uint8_t *outp = g->c->h_out + idx * group_out_stride();
+        if (bitmap) memcpy(bitmap, outp, (n + 7) / 8);
+        verdict = bitmap_all_ones(outp, n) ? 1 : 0;
+    } else if (g->launched) (void)hipStreamSynchronize(g->c->stream);      // nothing of this group may still run when the context goes back
+    group_unref(g);
+    return verdict;
+}
+static bool group_sized(size_t n, uint32_t mode) { return n && n <= kPartitionMaxBatch && mode <= HS_ED25519_BATCH_RLC; }
+
 static int verify_host(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const void *keys,
                        const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
     if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify: bad mode");
     if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
+    if (group_sized(n, mode)) {
+        host_group *g = nullptr; unsigned idx = 0;
+        const int rc = group_submit(&g, &idx, ks, digests, digest_stride, keys, sigs, n, mode, false, false);
+        if (rc) return rc;
+        return group_finish(g, idx, n, bitmap);
+    }
     host_job job;
     int rc = host_submit(job, ks ? ks->slot : 0, ks, digests, digest_stride, keys, sigs, n, mode);
     if (rc) { host_abandon(job); return rc; }
     return host_finish(job, bitmap);
+}
+
+// ---- the same, asynchronous: submit now, collect the verdict later -------------------------------
+// A ticket owns a pool context (or a share of a group's) from submit to wait.  The reference is a
+// tokio program: its verify_batch call sites sit on async tasks (consensus/src/core.rs, mempool),
+// so the binding can submit from the task and await the ticket on a blocking-pool thread - or keep
+// several certificates in flight from one thread, which is what fills the GPU.
+struct hs_ed25519_ticket { host_job job; host_group *g = nullptr; unsigned idx = 0; size_t n = 0; };
+extern "C" int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                                 const void *pks_or_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint32_t flags) {
+    if (!out) return fail(HS_ED25519_E_ARG, "submit: null ticket slot");
+    *out = nullptr;
+    if (mode > HS_ED25519_BATCH_RLC || (flags & ~(uint32_t)HS_ED25519_SUBMIT_MORE)) return fail(HS_ED25519_E_ARG, "submit: bad mode / flags");
+    if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "submit: digest_stride must be 0 or 32");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (n && (!digests || !pks_or_idx || !sigs)) return fail(HS_ED25519_E_ARG, "submit: null pointer");
+    hs_ed25519_ticket *t = new (std::nothrow) hs_ed25519_ticket();
+    if (!t) return fail(HS_ED25519_E_NOMEM, "submit: out of memory");
+    t->n = n;
+    int rc = 0;
+    if (group_sized(n, mode)) rc = group_submit(&t->g, &t->idx, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, flags & HS_ED25519_SUBMIT_MORE, true);
+    else if (n) { rc = host_submit(t->job, ks ? ks->slot : 0, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true); if (rc) host_abandon(t->job); }
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return 0;
+}
+extern "C" int hs_ed25519_ticket_ready(hs_ed25519_ticket *t) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_ready: null ticket");
+    hs_ed25519_ctx *c = t->g ? t->g->c : t->job.c;
+    if (!c) return 1;
+    if (t->g) { const int rc = group_close_and_launch(t->g); if (rc) return 1; }      // the error is reported by wait
+    if (hipSetDevice(c->device) != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    const hipError_t e = t->g ? hipEventQuery(c->done) : hipStreamQuery(c->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(HS_ED25519_E_DEVICE, hipGetErrorString(e));
+}
+extern "C" int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_wait: null ticket");
+    int rc = 1;                                                        // an empty batch is Ok (crypto/src/lib.rs:212-219 on no votes)
+    if (t->g) rc = group_finish(t->g, t->idx, t->n, bitmap);
+    else if (t->job.c) rc = host_finish(t->job, bitmap);
+    delete t;
+    return rc;
 }
 
 extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,

@@ -7,6 +7,7 @@
 //            per signature, R = [r]B from the base point's window table (no doublings) - for load generation.
 //   the native load generator used to measure the host-pointer API end to end.
 // Arithmetic in wire.h (host+device, validated on the CPU by tests/emu against OpenSSL / Python base64).
+#include <deque>
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <algorithm>
@@ -223,7 +224,8 @@ extern "C" int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *p
 // for the interpreter lock); this drives it from `threads` native threads instead: each loops over
 // hs_ed25519_verify_multi / _shared on its own batch (batch t of `nbatches`, round-robin) for `seconds`.
 extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
-                                  size_t n, size_t nbatches, uint32_t mode, unsigned threads, double seconds,
+                                  size_t n, size_t nbatches, uint32_t mode, unsigned threads, unsigned inflight, unsigned batches_per_launch,
+                                  double seconds,
                                   uint64_t *calls_out, double *p50_ms_out, double *elapsed_s_out) {
     if (!digests || !pks || !sigs || !n || !nbatches || !threads || threads > 256 || seconds <= 0 || !calls_out)
         return fail(HS_ED25519_E_ARG, "loadgen: bad arguments");
@@ -240,6 +242,39 @@ extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, 
             const uint8_t *d = digests + b * dg_bytes, *p = pks + b * 32 * n, *s = sigs + b * 64 * n;
             lat[t].reserve(4096);
             while (!go.load()) std::this_thread::yield();
+            if (inflight > 1) {          // a window of tickets: submit until full (or the pool is busy), then collect the oldest
+                const unsigned burst = batches_per_launch < 1 ? 1 : (batches_per_launch > inflight ? inflight : batches_per_launch);
+                std::deque<std::pair<hs_ed25519_ticket *, std::chrono::steady_clock::time_point>> win;
+                auto collect = [&]() -> bool {
+                    const int rc = hs_ed25519_ticket_wait(win.front().first, nullptr);
+                    lat[t].push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - win.front().second).count());
+                    win.pop_front();
+                    if (rc != 1) { bad.store(rc == 0 ? 1 : rc); return false; }
+                    calls[t]++;
+                    return true;
+                };
+                bool ok = true;
+                while (ok && !stop.load()) {
+                    // refill in bursts of `burst` (one launch each): MORE on all but the last of a burst
+                    while (ok && win.size() + burst <= inflight) {
+                        unsigned sent = 0;
+                        for (unsigned k = 0; k < burst; k++) {
+                            hs_ed25519_ticket *tk = nullptr;
+                            const auto t0 = std::chrono::steady_clock::now();
+                            const int rc = hs_ed25519_submit(&tk, nullptr, d, digest_stride, p, s, n, mode, k + 1 < burst ? HS_ED25519_SUBMIT_MORE : 0);
+                            if (rc == 0) { win.emplace_back(tk, t0); sent++; continue; }
+                            if (rc != HS_ED25519_E_BUSY) { bad.store(rc); ok = false; }
+                            break;
+                        }
+                        if (sent < burst) break;       // pool busy (or failed): collect first
+                    }
+                    if (!ok) break;
+                    if (win.empty()) { std::this_thread::yield(); continue; }
+                    ok = collect();
+                }
+                while (!win.empty()) if (!collect()) { while (!win.empty()) { (void)hs_ed25519_ticket_wait(win.front().first, nullptr); win.pop_front(); } }
+                return;
+            }
             while (!stop.load()) {
                 const auto t0 = std::chrono::steady_clock::now();
                 const int rc = digest_stride ? hs_ed25519_verify_multi(d, p, s, n, mode, nullptr)

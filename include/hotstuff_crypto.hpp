@@ -146,6 +146,44 @@ struct Signature {
         const auto fn = detail::several_devices() ? hs_ed25519_verify_shared_sharded : hs_ed25519_verify_shared;
         return detail::to_result(fn(digest.b.data(), pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH_RLC, nullptr));
     }
+    // Several certificates at once - a block's payload certificates, the QCs of a catch-up range: every entry is
+    // one verify_batch call (same law, same Ok-on-empty), all in flight together through the ticket API, small
+    // certificates sharing launches (HS_ED25519_SUBMIT_MORE).  Result i = verify_batch(certs[i]).
+    static std::vector<CryptoResult> verify_batches(const std::vector<std::pair<Digest, std::vector<std::pair<PublicKey, Signature>>>> &certs) {
+        std::vector<CryptoResult> out(certs.size(), CryptoResult{false});
+        if (certs.empty() || !detail::ensure_init()) return out;
+        std::vector<std::pair<size_t, hs_ed25519_ticket *>> inflight;
+        auto collect_oldest = [&]() {
+            out[inflight.front().first] = detail::to_result(hs_ed25519_ticket_wait(inflight.front().second, nullptr));
+            inflight.erase(inflight.begin());
+        };
+        std::vector<uint8_t> pks, sigs;
+        for (size_t c = 0; c < certs.size(); c++) {
+            const auto &votes = certs[c].second;
+            pks.resize(32 * votes.size()); sigs.resize(64 * votes.size());
+            for (size_t i = 0; i < votes.size(); i++) {
+                std::memcpy(&pks[32 * i], votes[i].first.b.data(), 32);
+                const auto f = votes[i].second.flatten();
+                std::memcpy(&sigs[64 * i], f.data(), 64);
+            }
+            if (SmallBatch::on_cpu(votes.size(), false)) {
+                out[c] = detail::to_result(SmallBatch::cpu_verify()(certs[c].first.b.data(), 0, pks.data(), sigs.data(), votes.size(),
+                                                                  HS_ED25519_BATCH, nullptr));
+                continue;
+            }
+            const uint32_t flags = c + 1 < certs.size() ? HS_ED25519_SUBMIT_MORE : 0;      // submit copies: the buffers are reused at once
+            for (;;) {
+                hs_ed25519_ticket *t = nullptr;
+                const int rc = hs_ed25519_submit(&t, nullptr, certs[c].first.b.data(), 0, pks.data(), sigs.data(), votes.size(),
+                                                 HS_ED25519_BATCH_RLC, flags);
+                if (rc == 0) { inflight.push_back({c, t}); break; }
+                if (rc != HS_ED25519_E_BUSY || inflight.empty()) { out[c] = CryptoResult{false}; break; }   // engine error: Err
+                collect_oldest();
+            }
+        }
+        while (!inflight.empty()) collect_oldest();
+        return out;
+    }
     // One digest per pair, strict semantics: the batched form of a loop of verify() calls (what VoteIngest and
     // TC::verify need).  Returns the per-pair verdicts; empty on an engine error.
     static std::vector<bool> verify_many(const std::vector<Digest> &digests,

@@ -73,6 +73,7 @@ extern "C" {
 #define HS_ED25519_E_DEVICE (-2)   /* HIP runtime error (see hs_ed25519_last_error) */
 #define HS_ED25519_E_ARG (-3)      /* null / misaligned pointer, bad mode           */
 #define HS_ED25519_E_NOMEM (-4)    /* allocation failure                            */
+#define HS_ED25519_E_BUSY (-5)     /* hs_ed25519_submit only: every pool context is in flight - wait on a ticket, retry */
 
 /* Select the GPU (HIP ordinal), upload the base-point table and pre-size the
  * context pool for batches of `max_batch` signatures (contexts grow on demand).
@@ -147,7 +148,7 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
 
 /* Several INDEPENDENT small batches in one launch (up to 16 per grid; longer lists are cut into several
  * launches): a node under load has many certificates pending, and a 1,024-signature batch alone is only one
- * wavefront per SIMD of a sixteenth of the chip.  Every batch keeps its own digests, bitmap and reject counter;
+ * wavefront per SIMD of the slice of the chip its stream runs on.  Every batch keeps its own digests, bitmap and reject counter;
  * n <= 32,768 and mode BATCH or STRICT for each.  Pointer rules as for hs_ed25519_verify_device. */
 typedef struct hs_ed25519_batch {
     const uint8_t *d_digests; size_t digest_stride;
@@ -340,14 +341,42 @@ int hs_ed25519_sign_device(hs_ed25519_ctx *ctx, const uint8_t *d_secrets, const 
                            size_t n, uint8_t *d_sigs, void *stream);
 int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out);
 
+/* ---- asynchronous host-pointer verification -------------------------------------------------
+ * hs_ed25519_submit stages the caller's buffers (they may be reused as soon as it returns) and
+ * enqueues the verification; hs_ed25519_ticket_wait blocks until it is done, writes the optional
+ * bitmap and returns the call's verdict exactly like the synchronous forms (1 / 0 / <0), consuming
+ * the ticket.  hs_ed25519_ticket_ready polls (1 = wait will not block, 0 = not yet).
+ *   ks == NULL: pks_or_idx = n x 32 key bytes;  else n uint32 indices into the key set
+ *   digest_stride: 0 = one shared digest (QC shape), 32 = one per signature
+ * A ticket holds one of the pool's contexts (16 for n <= 1,024 - shared by the tickets of one burst - and 4 above,
+ * per device slot): when none
+ * is free, submit returns HS_ED25519_E_BUSY WITHOUT blocking (a thread that holds every ticket itself
+ * would otherwise deadlock) - wait on an outstanding ticket and retry.  Every ticket must be waited on.
+ * flags: HS_ED25519_SUBMIT_MORE on every batch but the last of a burst lets calls of n <= 1,024 signatures share
+ * one launch (the TCP_CORK idea): a 1,024-signature batch alone is one wavefront per SIMD of its CU slice, two per
+ * launch reach the chip's full multiply-add issue rate.  Without the flag the call launches at once.  A batch
+ * submitted with the flag launches when its successor arrives, when a call of another kind (another key set, a
+ * larger batch) follows, or when any ticket of its launch is waited on or polled - never later.  Bursts are per
+ * thread (another thread's calls never join or delay them); tickets may be waited on from any thread.
+ * Replaces nothing in the reference (crypto/src/lib.rs:212-219 is synchronous); it is what lets one
+ * tokio task keep several certificates in flight. */
+typedef struct hs_ed25519_ticket hs_ed25519_ticket;
+#define HS_ED25519_SUBMIT_MORE 1u  /* another submit follows at once: this launch may wait for it (up to 4 batches per launch) */
+int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                      const void *pks_or_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint32_t flags);
+int hs_ed25519_ticket_ready(hs_ed25519_ticket *t);
+int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap);
+
 /* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or
  * hs_ed25519_verify_shared (0) in a loop for `seconds`, thread t on batch t mod nbatches of the caller's
  * packed host buffers (nbatches x n tuples, all valid).  Reports completed calls, the median call latency
  * and the elapsed time.  This is SURVEY.md 8d's end-to-end metric - host buffers in, host verdict out -
- * without an interpreter in the loop. */
+ * without an interpreter in the loop.  inflight <= 1: the synchronous calls; inflight = k > 1: every thread
+ * keeps k tickets outstanding through hs_ed25519_submit / hs_ed25519_ticket_wait (latency = submit to verdict),
+ * submitted in bursts of batches_per_launch (HS_ED25519_SUBMIT_MORE on all but the last of a burst). */
 int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
-                       size_t nbatches, uint32_t mode, unsigned threads, double seconds, uint64_t *calls_out,
-                       double *p50_ms_out, double *elapsed_s_out);
+                       size_t nbatches, uint32_t mode, unsigned threads, unsigned inflight, unsigned batches_per_launch,
+                       double seconds, uint64_t *calls_out, double *p50_ms_out, double *elapsed_s_out);
 
 #ifdef __cplusplus
 }

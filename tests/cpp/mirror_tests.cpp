@@ -71,6 +71,25 @@ int main(int argc, char **argv) {
         CHECK("verify_invalid_batch", Signature::verify_batch(x.digest, votes).is_err());
     }
     CHECK("verify_batch of nothing is Ok", Signature::verify_batch(x.digest, {}).is_ok());
+    {
+        // forty certificates in flight at once (more than the pool holds): valid ones, one with a default signature,
+        // one signed over another digest, an empty one - each entry must equal its own verify_batch
+        std::vector<std::pair<PublicKey, Signature>> good, bad;
+        for (int i = 3; i >= 1; i--) good.push_back({x.pk[i], x.sig[i]});
+        bad = good; bad[2].second = Signature{};
+        std::vector<std::pair<Digest, std::vector<std::pair<PublicKey, Signature>>>> certs;
+        std::vector<bool> want;
+        for (int c = 0; c < 40; c++) {
+            if (c % 7 == 3) { certs.push_back({x.digest, bad}); want.push_back(false); }
+            else if (c % 7 == 5) { certs.push_back({x.bad_digest, good}); want.push_back(false); }
+            else if (c == 20) { certs.push_back({x.digest, {}}); want.push_back(true); }
+            else { certs.push_back({x.digest, good}); want.push_back(true); }
+        }
+        const auto got = Signature::verify_batches(certs);
+        bool same = got.size() == want.size();
+        for (size_t c = 0; same && c < want.size(); c++) same = got[c].is_ok() == want[c] && got[c].is_ok() == Signature::verify_batch(certs[c].first, certs[c].second).is_ok();
+        CHECK("verify_batches: forty certificates in flight, each = its own verify_batch", same);
+    }
     CHECK("wrong key is Err", x.sig[3].verify(x.digest, x.pk[2]).is_err());
 
     // ---- messages_tests.rs

@@ -1,0 +1,155 @@
+"""Asynchronous host-pointer verification (hs_ed25519_submit / hs_ed25519_ticket_wait) and the launch-sharing of
+small host calls (HS_ED25519_SUBMIT_MORE): every verdict and bitmap vs the oracle."""
+import threading
+
+import pytest
+import torch
+
+import synth
+from conftest import bits, oracle_verify_many
+from hotstuff_amd import _lib
+
+pytestmark = pytest.mark.gpu
+CACHE = "/tmp/hs_synth"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    assert torch.cuda.is_available()
+    _lib.init(0, 8192)
+    yield
+
+
+def _case(n, shared, first, rate=40):
+    dg, pk, sg = synth.make_batch(n, shared=shared, first=first, cache_dir=CACHE)
+    if rate:
+        dg, pk, sg, _ = synth.corrupt(dg, pk, sg, n, shared, rate_byte=rate)
+    return dg, pk, sg
+
+
+def _check(oracle, case, n, shared, mode, got):
+    ok, bm = got
+    want = oracle_verify_many(oracle, case[0], 0 if shared else 32, case[1], case[2], n, _lib.STRICT if mode == _lib.STRICT else _lib.BATCH)
+    assert bits(bm, n) == want
+    assert ok == all(want)
+
+
+def test_bursts_share_launches_and_match_the_oracle(oracle):
+    """bursts of 1-5 small batches (MORE on all but the last; the fifth overflows into a second launch), different
+    sizes, digest forms and modes, some all-valid; then a lone ticket submitted with MORE and only waited on."""
+    shapes = [(1024, False, _lib.STRICT, 40), (1000, True, _lib.BATCH, 40), (1, False, _lib.STRICT, 0), (65, True, _lib.BATCH_RLC, 40),
+              (1024, False, _lib.STRICT, 0)]
+    first = 0
+    for burst in range(1, 6):
+        cases, tickets = [], []
+        for k in range(burst):
+            n, shared, mode, rate = shapes[(burst + k) % len(shapes)]
+            c = _case(n, shared, first, rate)
+            first += n
+            cases.append((c, n, shared, mode))
+            tickets.append(_lib.Ticket(c[0], c[1], c[2], n, mode=mode, shared=shared, more=k + 1 < burst))
+        for (c, n, shared, mode), t in reversed(list(zip(cases, tickets))):        # collect in another order than submitted
+            _check(oracle, c, n, shared, mode, t.wait())
+    c = _case(700, False, 90000)
+    t = _lib.Ticket(c[0], c[1], c[2], 700, more=True)        # nothing follows: the wait launches it
+    _check(oracle, c, 700, False, _lib.STRICT, t.wait())
+    c = _case(300, True, 91000)
+    t = _lib.Ticket(c[0], c[1], c[2], 300, shared=True, more=True)
+    while not t.ready():                                       # ... and so does polling
+        pass
+    _check(oracle, c, 300, True, _lib.STRICT, t.wait())
+
+
+def test_key_cache_and_cold_tickets_interleaved(oracle):
+    """a cold batch submitted with MORE followed by a key-cache batch: the cold launch must not wait for a successor of
+    its own kind; big batches (own context, RLC) ride along; an empty batch is Ok."""
+    nk = 200
+    _, kpk, _ = synth.make_batch(nk, shared=True, first=0, cache_dir=CACHE)
+    keys = [kpk[32 * i:32 * i + 32] for i in range(nk)]
+    ks = _lib.KeySet(keys)
+    cold = _case(512, False, 20000)
+    t_cold = _lib.Ticket(cold[0], cold[1], cold[2], 512, more=True)
+    dg, pk, sg = synth.make_batch(nk, shared=True, first=0, cache_dir=CACHE)
+    sgb = bytearray(sg); sgb[64 * 7 + 3] ^= 1; sgb[64 * 150 + 40] ^= 16
+    t_ks = _lib.Ticket(dg, list(range(nk)), bytes(sgb), nk, mode=_lib.BATCH, shared=True, keyset=ks, more=True)
+    t_ks2 = _lib.Ticket(dg, list(range(nk)), sg, nk, mode=_lib.STRICT, shared=True, keyset=ks)
+    big = _case(6667, True, 30000, rate=0)
+    t_big = _lib.Ticket(big[0], big[1], big[2], 6667, mode=_lib.BATCH_RLC, shared=True)
+    t_empty = _lib.Ticket(b"\0" * 32, b"", b"", 0, shared=True)
+    assert t_empty.wait() == (True, b"")
+    _check(oracle, big, 6667, True, _lib.BATCH, t_big.wait())
+    ok, bm = t_ks2.wait()
+    assert ok and bits(bm, nk) == bytes([1]) * nk
+    _check(oracle, (dg, pk, bytes(sgb)), nk, True, _lib.BATCH, t_ks.wait())
+    _check(oracle, cold, 512, False, _lib.STRICT, t_cold.wait())
+    ks.close()
+
+
+def test_pool_busy_is_reported_not_waited_for(oracle):
+    """more tickets than pool contexts from ONE thread: submit reports HS_ED25519_E_BUSY instead of deadlocking; after a
+    wait the submit succeeds; every verdict is still right."""
+    c = _case(256, False, 40000)
+    held = []
+    with pytest.raises(_lib.PoolBusy):
+        for _ in range(200):
+            held.append(_lib.Ticket(c[0], c[1], c[2], 256))
+    assert 4 <= len(held) < 200
+    _check(oracle, c, 256, False, _lib.STRICT, held.pop(0).wait())
+    held.append(_lib.Ticket(c[0], c[1], c[2], 256))
+    for t in held:
+        _check(oracle, c, 256, False, _lib.STRICT, t.wait())
+    with pytest.raises(_lib.EngineError):
+        _lib.Ticket(c[0], c[1], c[2], 256, mode=9)
+
+
+def test_tickets_from_many_threads(oracle):
+    """12 threads, each keeping 4 tickets in flight in bursts of 2, while 6 more use the synchronous calls: groups are
+    joined and launched across threads; all verdicts vs the oracle."""
+    cases = [(_case(n, shared, 50000 + 2000 * k), n, shared, mode)
+             for k, (n, shared, mode) in enumerate([(1024, False, _lib.STRICT), (333, True, _lib.BATCH), (64, False, _lib.STRICT), (1000, True, _lib.STRICT)])]
+    want = [oracle_verify_many(oracle, c[0], 0 if sh else 32, c[1], c[2], n, m) for c, n, sh, m in cases]
+    errors = []
+
+    def async_worker(seed):
+        try:
+            win = []
+            for it in range(12):
+                for k in range(2):
+                    j = (seed + it + k) % len(cases)
+                    c, n, sh, m = cases[j]
+                    while True:
+                        try:
+                            win.append((j, _lib.Ticket(c[0], c[1], c[2], n, mode=m, shared=sh, more=k == 0)))
+                            break
+                        except _lib.PoolBusy:
+                            if win:
+                                jj, t = win.pop(0)
+                                ok, bm = t.wait()
+                                assert bits(bm, cases[jj][1]) == want[jj] and ok == all(want[jj])
+                while len(win) > 2:
+                    jj, t = win.pop(0)
+                    ok, bm = t.wait()
+                    assert bits(bm, cases[jj][1]) == want[jj] and ok == all(want[jj])
+            for jj, t in win:
+                ok, bm = t.wait()
+                assert bits(bm, cases[jj][1]) == want[jj] and ok == all(want[jj])
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def sync_worker(seed):
+        try:
+            for it in range(20):
+                j = (seed + it) % len(cases)
+                c, n, sh, m = cases[j]
+                ok, bm = _lib.verify_packed(c[0], c[1], c[2], n, m, sh, want_bitmap=True)
+                assert bits(bm, n) == want[j] and ok == all(want[j])
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=async_worker, args=(i,)) for i in range(12)] + [threading.Thread(target=sync_worker, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not any(t.is_alive() for t in th), "deadlock"
+    assert not errors, errors[:3]

@@ -1,0 +1,27 @@
+"""End-to-end host-API rate (hs_ed25519_loadgen) over threads x tickets in flight, for the pool shape given by
+HS_ED25519_POOL_NARROW / HS_ED25519_POOL_PARTITIONS in the environment.  One line per shape."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synth  # noqa: E402
+from hotstuff_amd import _lib  # noqa: E402
+
+n, nb = 1024, 16
+_lib.init(0, 8192)
+lib = _lib.lib()
+batches = [synth.make_batch(n, shared=False, first=n * j, cache_dir="/tmp/hs_synth") for j in range(nb)]
+bufs = [ctypes.create_string_buffer(x, len(x)) for x in (b"".join(b[k] for b in batches) for k in range(3))]
+a = [ctypes.addressof(x) for x in bufs]
+# threads x tickets in flight per thread x batches per launch (HS_ED25519_SUBMIT_MORE bursts)
+shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
+                                                                          "4x8x2", "4x16x4", "1x8x2", "1x16x2", "1x32x2", "1x32x4"])]
+tag = "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "16"))
+for th, k, bpl in shapes:
+    calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.hs_ed25519_loadgen(a[0], 32, a[1], a[2], n, nb, _lib.STRICT, th, k, bpl, 0.5, ctypes.byref(calls), ctypes.byref(p50),
+                                      ctypes.byref(el)), "loadgen")
+    print("%s threads=%d in_flight=%d per_launch=%d  %.1f M verifies/s  p50 %.3f ms" % (tag, th, k, bpl, calls.value * n / el.value / 1e6, p50.value), flush=True)
