@@ -19,7 +19,7 @@ a = [ctypes.addressof(x) for x in bufs]
 # threads x tickets in flight per thread x batches per launch (HS_ED25519_SUBMIT_MORE bursts)
 shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
                                                                           "4x8x2", "4x16x4", "1x8x2", "1x16x2", "1x32x2", "1x32x4"])]
-tag = "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "16"))
+tag = "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "8"))
 for th, k, bpl in shapes:
     calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
     _lib.check(lib.hs_ed25519_loadgen(a[0], 32, a[1], a[2], n, nb, _lib.STRICT, th, k, bpl, 0.5, ctypes.byref(calls), ctypes.byref(p50),
