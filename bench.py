@@ -364,7 +364,7 @@ def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8, inflight
     shapes += [(th, k, bpl) for th, k, bpl in inflight]
     for th, k, bpl in shapes:
         calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.hs_ed25519_loadgen(a[0], stride, a[1], a[2], n, len(batches), mode, th, k, bpl, seconds if th == threads else seconds / 2,
+        _lib.check(lib.hs_ed25519_loadgen(None, a[0], stride, a[1], a[2], n, len(batches), mode, th, k, bpl, seconds if th == threads else seconds / 2,
                                           ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el)), "hs_ed25519_loadgen")
         row = {"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": bpl, "calls": calls.value, "seconds": round(el.value, 3),
                "call_p50_ms": round(p50.value, 4), "value": round(calls.value * n / el.value, 1)}

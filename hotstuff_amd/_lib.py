@@ -98,7 +98,7 @@ def lib():
                 l.hs_ed25519_ticket_ready.restype = ctypes.c_int
                 l.hs_ed25519_ticket_wait.argtypes = [vp, vp]
                 l.hs_ed25519_ticket_wait.restype = ctypes.c_int
-                l.hs_ed25519_loadgen.argtypes = [vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
+                l.hs_ed25519_loadgen.argtypes = [vp, vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                                  ctypes.POINTER(ctypes.c_double)]
                 l.hs_ed25519_loadgen.restype = ctypes.c_int

@@ -221,19 +221,13 @@ k_keyset_build(u32 *__restrict__ tab, const u32 *__restrict__ axy, u32 nkeys, u3
     keyset_build_window(tab + (size_t)k * HS_KS_KEY_PROJ_WORDS + (size_t)w * HS_KS_ENTRIES * HS_KS_PROJ_WORDS,
                         ax, ay, negate != 0, (int)w);
 }
-// registration pass 3: one lane per entry - projective scratch -> the affine 128-byte entry the verification kernels read
-__global__ void __launch_bounds__(64, 3)
-k_keyset_affine(const u32 *__restrict__ proj, u32 *__restrict__ tab, unsigned long long entries) {
-    const unsigned long long e = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
-    if (e >= entries) return;
-    u32 in[HS_KS_PROJ_WORDS], out[HS_KS_ENTRY_WORDS];
-    const uint4 *src = reinterpret_cast<const uint4 *>(proj + e * HS_KS_PROJ_WORDS);
-#pragma unroll
-    for (int i = 0; i < 10; i++) { const uint4 v = src[i]; in[4 * i] = v.x; in[4 * i + 1] = v.y; in[4 * i + 2] = v.z; in[4 * i + 3] = v.w; }
-    keyset_affine_entry(out, in);
-    uint4 *dst = reinterpret_cast<uint4 *>(tab + e * HS_KS_ENTRY_WORDS);
-#pragma unroll
-    for (int i = 0; i < 8; i++) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+// registration pass 3: one lane per group of eight entries - projective scratch -> the affine 128-byte entries the
+// verification kernels read, one inversion per group (keyset_affine_group)
+__global__ void __launch_bounds__(64, 2)
+k_keyset_affine(const u32 *__restrict__ proj, u32 *__restrict__ tab, unsigned long long groups) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (g >= groups) return;
+    keyset_affine_group(tab + g * (HS_KS_AFFINE_GROUP * HS_KS_ENTRY_WORDS), proj + g * (HS_KS_AFFINE_GROUP * HS_KS_PROJ_WORDS));
 }
 #ifdef HS_AB_VARIANTS
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
@@ -1000,9 +994,10 @@ static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate,
         hipError_t e = hipLaunchKernel((const void *)k_keyset_build, dim3(pad / 16 * HS_KS_WINDOWS), dim3(64), args, 0, st);
         if (e == hipSuccess) {
             const u32 *p_proj = d_proj; u32 *p_tab = d_tab + c0 * (size_t)HS_KS_KEY_WORDS;
-            unsigned long long entries = (unsigned long long)nc * HS_KS_WINDOWS * HS_KS_ENTRIES;
-            void *a2[] = { &p_proj, &p_tab, &entries };
-            e = hipLaunchKernel((const void *)k_keyset_affine, dim3((unsigned)((entries + 63) / 64)), dim3(64), a2, 0, st);
+            static_assert((HS_KS_WINDOWS * HS_KS_ENTRIES) % HS_KS_AFFINE_GROUP == 0, "a group of entries must not span two keys");
+            unsigned long long groups = (unsigned long long)nc * HS_KS_WINDOWS * HS_KS_ENTRIES / HS_KS_AFFINE_GROUP;
+            void *a2[] = { &p_proj, &p_tab, &groups };
+            e = hipLaunchKernel((const void *)k_keyset_affine, dim3((unsigned)((groups + 63) / 64)), dim3(64), a2, 0, st);
         }
         if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "launch k_keyset_build / k_keyset_affine", e);
     }

@@ -223,7 +223,7 @@ extern "C" int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *p
 // host-pointer API from interpreter threads measures the interpreter (a thread returning from a call waits
 // for the interpreter lock); this drives it from `threads` native threads instead: each loops over
 // hs_ed25519_verify_multi / _shared on its own batch (batch t of `nbatches`, round-robin) for `seconds`.
-extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
+extern "C" int hs_ed25519_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs,
                                   size_t n, size_t nbatches, uint32_t mode, unsigned threads, unsigned inflight, unsigned batches_per_launch,
                                   double seconds,
                                   uint64_t *calls_out, double *p50_ms_out, double *elapsed_s_out) {
@@ -239,7 +239,7 @@ extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, 
     for (unsigned t = 0; t < threads; t++)
         th.emplace_back([&, t] {
             const size_t b = t % nbatches;
-            const uint8_t *d = digests + b * dg_bytes, *p = pks + b * 32 * n, *s = sigs + b * 64 * n;
+            const uint8_t *d = digests + b * dg_bytes, *p = pks + b * (ks ? 4 : 32) * n, *s = sigs + b * 64 * n;
             lat[t].reserve(4096);
             while (!go.load()) std::this_thread::yield();
             if (inflight > 1) {          // a window of tickets: submit until full (or the pool is busy), then collect the oldest
@@ -261,7 +261,7 @@ extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, 
                         for (unsigned k = 0; k < burst; k++) {
                             hs_ed25519_ticket *tk = nullptr;
                             const auto t0 = std::chrono::steady_clock::now();
-                            const int rc = hs_ed25519_submit(&tk, nullptr, d, digest_stride, p, s, n, mode, k + 1 < burst ? HS_ED25519_SUBMIT_MORE : 0);
+                            const int rc = hs_ed25519_submit(&tk, ks, d, digest_stride, p, s, n, mode, k + 1 < burst ? HS_ED25519_SUBMIT_MORE : 0);
                             if (rc == 0) { win.emplace_back(tk, t0); sent++; continue; }
                             if (rc != HS_ED25519_E_BUSY) { bad.store(rc); ok = false; }
                             break;
@@ -277,8 +277,11 @@ extern "C" int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, 
             }
             while (!stop.load()) {
                 const auto t0 = std::chrono::steady_clock::now();
-                const int rc = digest_stride ? hs_ed25519_verify_multi(d, p, s, n, mode, nullptr)
-                                             : hs_ed25519_verify_shared(d, p, s, n, mode, nullptr);
+                int rc;
+                if (ks) rc = digest_stride ? hs_ed25519_verify_multi_cached(ks, d, (const uint32_t *)p, s, n, mode, nullptr)
+                                           : hs_ed25519_verify_shared_cached(ks, d, (const uint32_t *)p, s, n, mode, nullptr);
+                else rc = digest_stride ? hs_ed25519_verify_multi(d, p, s, n, mode, nullptr)
+                                        : hs_ed25519_verify_shared(d, p, s, n, mode, nullptr);
                 lat[t].push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 if (rc != 1) { bad.store(rc == 0 ? 1 : rc); return; }
                 calls[t]++;

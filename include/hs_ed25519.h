@@ -369,12 +369,13 @@ int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap);
 
 /* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or
  * hs_ed25519_verify_shared (0) in a loop for `seconds`, thread t on batch t mod nbatches of the caller's
- * packed host buffers (nbatches x n tuples, all valid).  Reports completed calls, the median call latency
+ * packed host buffers (nbatches x n tuples, all valid; with a key set `ks` the *_cached forms, `pks` then
+ * holding nbatches x n uint32 key indices).  Reports completed calls, the median call latency
  * and the elapsed time.  This is SURVEY.md 8d's end-to-end metric - host buffers in, host verdict out -
  * without an interpreter in the loop.  inflight <= 1: the synchronous calls; inflight = k > 1: every thread
  * keeps k tickets outstanding through hs_ed25519_submit / hs_ed25519_ticket_wait (latency = submit to verdict),
  * submitted in bursts of batches_per_launch (HS_ED25519_SUBMIT_MORE on all but the last of a burst). */
-int hs_ed25519_loadgen(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+int hs_ed25519_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
                        size_t nbatches, uint32_t mode, unsigned threads, unsigned inflight, unsigned batches_per_launch,
                        double seconds, uint64_t *calls_out, double *p50_ms_out, double *elapsed_s_out);
 

@@ -138,10 +138,10 @@ uint32_t emu_genuine_point_accepts(void) {
     return out;
 }
 // ---- committee key cache (verify_cached.h) ----
-// The device normalises every table entry with an inversion of its own (keyset_affine_entry, one lane per entry).
-// Doing the same 4,128 inversions per key serially on the CPU made this harness the slowest thing in the suite, so the
-// emulation normalises a window with Montgomery's trick (one inversion per 129 entries) - and emu_affine_forms_agree
-// checks that both forms give the same field elements.
+// The device normalises the table entries in groups of eight sharing one inversion (keyset_affine_group, one lane per
+// group).  516 inversions per key serially on the CPU would still make this harness the slowest thing in the suite, so
+// the emulation normalises a whole window with one inversion (129 entries) - and emu_affine_forms_agree checks that
+// this form, the device's group form and the plain per-entry form (keyset_affine_entry) give the same field elements.
 static void affine_window_batch(u32 *dst /* [129][32] */, const u32 *proj /* [129][40] */) {
     fe d[HS_KS_ENTRIES], pre[HS_KS_ENTRIES];
     for (int j = 0; j < HS_KS_ENTRIES; j++) for (int i = 0; i < 10; i++) d[j].v[i] = proj[(size_t)j * HS_KS_PROJ_WORDS + 30 + i];
@@ -167,6 +167,24 @@ int emu_affine_forms_agree(const uint8_t *pk32, int win) {
     keyset_build_window(proj.data(), p.X, p.Y, true, win);
     affine_window_batch(x.data(), proj.data());
     for (int j = 0; j < HS_KS_ENTRIES; j++) keyset_affine_entry(y.data() + (size_t)j * HS_KS_ENTRY_WORDS, proj.data() + (size_t)j * HS_KS_PROJ_WORDS);
+    // ... and the device's form: groups of HS_KS_AFFINE_GROUP entries sharing one inversion (the 129th entry of this
+    // window is covered as the first of a group made of it and seven copies of entry 0)
+    {
+        std::vector<u32> z(x.size());
+        for (int g = 0; g + HS_KS_AFFINE_GROUP <= HS_KS_ENTRIES; g += HS_KS_AFFINE_GROUP)
+            keyset_affine_group(z.data() + (size_t)g * HS_KS_ENTRY_WORDS, proj.data() + (size_t)g * HS_KS_PROJ_WORDS);
+        std::vector<u32> tail_in((size_t)HS_KS_AFFINE_GROUP * HS_KS_PROJ_WORDS), tail_out((size_t)HS_KS_AFFINE_GROUP * HS_KS_ENTRY_WORDS);
+        for (int t = 0; t < HS_KS_AFFINE_GROUP; t++)
+            memcpy(tail_in.data() + (size_t)t * HS_KS_PROJ_WORDS, proj.data() + (size_t)(t == 0 ? HS_KS_ENTRIES - 1 : 0) * HS_KS_PROJ_WORDS, HS_KS_PROJ_WORDS * 4);
+        keyset_affine_group(tail_out.data(), tail_in.data());
+        memcpy(z.data() + (size_t)(HS_KS_ENTRIES - 1) * HS_KS_ENTRY_WORDS, tail_out.data(), HS_KS_ENTRY_WORDS * 4);
+        for (int j = 0; j < HS_KS_ENTRIES; j++) for (int c = 0; c < 3; c++) {
+            fe f, g; u32 fw[8], gw[8];
+            for (int i = 0; i < 10; i++) { f.v[i] = z[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; g.v[i] = y[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; }
+            fe_to_words(fw, f); fe_to_words(gw, g);
+            if (memcmp(fw, gw, 32)) return 0;
+        }
+    }
     for (int j = 0; j < HS_KS_ENTRIES; j++) for (int c = 0; c < 3; c++) {
         fe f, g; u32 fw[8], gw[8];
         for (int i = 0; i < 10; i++) { f.v[i] = x[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; g.v[i] = y[(size_t)j * HS_KS_ENTRY_WORDS + 10 * c + i]; }

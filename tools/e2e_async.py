@@ -14,14 +14,18 @@ n, nb = 1024, 16
 _lib.init(0, 8192)
 lib = _lib.lib()
 batches = [synth.make_batch(n, shared=False, first=n * j, cache_dir="/tmp/hs_synth") for j in range(nb)]
+import struct  # noqa: E402
+cached = os.environ.get("HS_E2E_CACHED") == "1"      # the same batches through a key set holding their 16,384 signers
 bufs = [ctypes.create_string_buffer(x, len(x)) for x in (b"".join(b[k] for b in batches) for k in range(3))]
+bufs.append(ctypes.create_string_buffer(struct.pack("<%dI" % (n * nb), *range(n * nb)), 4 * n * nb))
 a = [ctypes.addressof(x) for x in bufs]
+ks = _lib.KeySet([b[1][32 * i:32 * i + 32] for b in batches for i in range(n)]) if cached else None
 # threads x tickets in flight per thread x batches per launch (HS_ED25519_SUBMIT_MORE bursts)
 shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
                                                                           "4x8x2", "4x16x4", "1x8x2", "1x16x2", "1x32x2", "1x32x4"])]
-tag = "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "8"))
+tag = ("key-cache " if cached else "") + "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "8"))
 for th, k, bpl in shapes:
     calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
-    _lib.check(lib.hs_ed25519_loadgen(a[0], 32, a[1], a[2], n, nb, _lib.STRICT, th, k, bpl, 0.5, ctypes.byref(calls), ctypes.byref(p50),
+    _lib.check(lib.hs_ed25519_loadgen(ks.handle if ks else None, a[0], 32, a[3] if ks else a[1], a[2], n, nb, _lib.STRICT, th, k, bpl, 0.5, ctypes.byref(calls), ctypes.byref(p50),
                                       ctypes.byref(el)), "loadgen")
     print("%s threads=%d in_flight=%d per_launch=%d  %.1f M verifies/s  p50 %.3f ms" % (tag, th, k, bpl, calls.value * n / el.value / 1e6, p50.value), flush=True)

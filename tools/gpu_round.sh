@@ -2,15 +2,16 @@
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5
-S="1x1x1 8x1x1 16x1x1 24x1x1 16x2x1 16x2x2 16x4x2 16x4x4 8x4x2 4x8x2 1x8x2 1x16x2 1x32x2"
-{
-echo "# hs_ed25519_loadgen: 1,024-signature strict batches, host buffers in, host verdict out (PCIe included), 0.5 s per row"
-echo "# threads x tickets in flight per thread x batches per launch; in_flight=1 = the synchronous hs_ed25519_verify_multi"
-echo "## default pool: 16 narrow contexts on 8 XCD-aligned partitions of 32 CUs"
-timeout 200 python tools/e2e_async.py $S 2>&1 | grep -v amdgpu.ids
-echo "## 16 partitions of 16 CUs, one context each (the round-1 / early round-2 shape)"
-HS_ED25519_POOL_PARTITIONS=16 timeout 200 python tools/e2e_async.py $S 2>&1 | grep -v amdgpu.ids
-} > gpurun_out/r2_e2e_async.txt
-cat gpurun_out/r2_e2e_async.txt
-timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json.txt 2>gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.err; wc -c gpurun_out/bench_default.json.txt
+python - <<'PY'
+import time, sys
+sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+import synth
+from hotstuff_amd import _lib
+_lib.init(0, 8192)
+for nk in (10000, 16384, 100000, 10000):
+    pk = _lib.public_keys(b"".join(synth.key_seed(7_000_000 + i) for i in range(nk)), nk)
+    ks0 = [pk[32 * i:32 * i + 32] for i in range(nk)]
+    t0 = time.perf_counter(); ks = _lib.KeySet(ks0); dt = time.perf_counter() - t0
+    print("keyset of %d keys: %.1f ms, %d bytes" % (nk, dt * 1e3, ks.hbm_bytes()), flush=True)
+    ks.close()
+PY
