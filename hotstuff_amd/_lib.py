@@ -96,6 +96,8 @@ def lib():
                 l.hs_ed25519_submit.restype = ctypes.c_int
                 l.hs_ed25519_ticket_ready.argtypes = [vp]
                 l.hs_ed25519_ticket_ready.restype = ctypes.c_int
+                l.hs_ed25519_ticket_device_slot.argtypes = [vp]
+                l.hs_ed25519_ticket_device_slot.restype = ctypes.c_int
                 l.hs_ed25519_ticket_wait.argtypes = [vp, vp]
                 l.hs_ed25519_ticket_wait.restype = ctypes.c_int
                 l.hs_ed25519_loadgen.argtypes = [vp, vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
@@ -448,6 +450,9 @@ class Ticket:
         rc = lib().hs_ed25519_ticket_ready(self._h)
         check(rc, "hs_ed25519_ticket_ready")
         return bool(rc)
+
+    def device_slot(self):
+        return check(lib().hs_ed25519_ticket_device_slot(self._h), "hs_ed25519_ticket_device_slot")
 
     def wait(self):
         """-> (verdict: bool, accept bitmap bytes); consumes the ticket"""

@@ -1313,10 +1313,17 @@ struct open_group_slot {
 };
 static thread_local open_group_slot t_open;
 
+// Host calls by key bytes can run on any device slot: with several GPUs open they go round the slots, one launch
+// (group or big call) at a time - the single node process of the reference then uses every GPU without sharding its
+// small certificates.  Calls through a key set run where the key set lives.
+static std::atomic<unsigned> g_cold_rr{0};
+static int next_cold_slot() {
+    const int n = hs::dev_slots();
+    return n > 1 ? (int)(g_cold_rr.fetch_add(1, std::memory_order_relaxed) % (unsigned)n) : 0;
+}
 // join this thread's open group or start one; stage; launch unless `more`.  *idx_out = the member's position.
 static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
                         const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool more, bool nowait) {
-    const int slot = ks ? ks->slot : 0;
     host_group *g = t_open.g;
     unsigned idx = 0;
     bool closer = false;
@@ -1324,7 +1331,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
         bool joined = false;
         {
             std::lock_guard<std::mutex> lk(g->mu);
-            if (!g->closed && g->ks == ks && g->slot == slot && g->members < kGroupMax) {
+            if (!g->closed && g->ks == ks && g->members < kGroupMax) {      // same kind (a key set pins its device slot, cold calls take any)
                 idx = g->members++; g->refs++; joined = true;
                 if (!more || g->members == kGroupMax) { g->closed = true; closer = true; }
             }
@@ -1332,6 +1339,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
         if (!joined) { t_open.drop(true); g = nullptr; }       // waited on meanwhile, or another kind of call: that group goes now
     }
     if (!g) {
+        const int slot = ks ? ks->slot : next_cold_slot();
         hs_ed25519_ctx *c = nullptr;
         int rc = pool_get(&c, slot, n, nowait);
         if (rc) return rc;
@@ -1400,7 +1408,7 @@ static int verify_host(const hs_ed25519_keyset *ks, const uint8_t *digests, size
         return group_finish(g, idx, n, bitmap);
     }
     host_job job;
-    int rc = host_submit(job, ks ? ks->slot : 0, ks, digests, digest_stride, keys, sigs, n, mode);
+    int rc = host_submit(job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, keys, sigs, n, mode);
     if (rc) { host_abandon(job); return rc; }
     return host_finish(job, bitmap);
 }
@@ -1424,7 +1432,7 @@ extern "C" int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyse
     t->n = n;
     int rc = 0;
     if (group_sized(n, mode)) rc = group_submit(&t->g, &t->idx, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, flags & HS_ED25519_SUBMIT_MORE, true);
-    else if (n) { rc = host_submit(t->job, ks ? ks->slot : 0, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true); if (rc) host_abandon(t->job); }
+    else if (n) { rc = host_submit(t->job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true); if (rc) host_abandon(t->job); }
     if (rc) { delete t; return rc; }
     *out = t;
     return 0;
@@ -1439,6 +1447,11 @@ extern "C" int hs_ed25519_ticket_ready(hs_ed25519_ticket *t) {
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
     return fail(HS_ED25519_E_DEVICE, hipGetErrorString(e));
+}
+extern "C" int hs_ed25519_ticket_device_slot(const hs_ed25519_ticket *t) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_device_slot: null ticket");
+    const hs_ed25519_ctx *c = t->g ? t->g->c : t->job.c;
+    return c ? c->slot : 0;
 }
 extern "C" int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap) {
     if (!t) return fail(HS_ED25519_E_ARG, "ticket_wait: null ticket");

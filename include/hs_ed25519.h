@@ -358,6 +358,8 @@ int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out);
  * submitted with the flag launches when its successor arrives, when a call of another kind (another key set, a
  * larger batch) follows, or when any ticket of its launch is waited on or polled - never later.  Bursts are per
  * thread (another thread's calls never join or delay them); tickets may be waited on from any thread.
+ * With several device slots open (hs_ed25519_init_devices) the host calls by key bytes - these and the synchronous
+ * ones - go round the slots, one launch at a time; calls through a key set run on the key set's device.
  * Replaces nothing in the reference (crypto/src/lib.rs:212-219 is synchronous); it is what lets one
  * tokio task keep several certificates in flight. */
 typedef struct hs_ed25519_ticket hs_ed25519_ticket;
@@ -365,6 +367,7 @@ typedef struct hs_ed25519_ticket hs_ed25519_ticket;
 int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
                       const void *pks_or_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint32_t flags);
 int hs_ed25519_ticket_ready(hs_ed25519_ticket *t);
+int hs_ed25519_ticket_device_slot(const hs_ed25519_ticket *t);  /* which device slot verifies it (diagnostics) */
 int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap);
 
 /* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or

@@ -101,3 +101,31 @@ def test_rccl_exchange_one_slot(oracle):
 def test_reinit_with_another_device_list_is_refused(three_slots):
     rc = _lib.lib().hs_ed25519_init(0, 1024)
     assert rc == -3 and "different device list" in _lib.last_error()
+
+
+def test_host_calls_by_key_bytes_go_round_the_device_slots(oracle, three_slots):
+    """With several device slots open, the small host calls (tickets and synchronous) and the big tickets take the
+    slots in turn - one launch at a time, a burst stays together - and every verdict still equals the oracle's."""
+    cases = []
+    for k, (n, shared) in enumerate([(1024, False), (300, True), (64, False), (1000, True), (5000, True), (17, False)]):
+        dg, pk, sg = synth.make_batch(n, shared=shared, first=70000 + 3000 * k, cache_dir=CACHE)
+        dg, pk, sg, _ = synth.corrupt(dg, pk, sg, n, shared, rate_byte=30)
+        cases.append((dg, pk, sg, n, shared, oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, _lib.STRICT)))
+    seen = set()
+    for rnd in range(4):
+        tickets = []
+        for j, (dg, pk, sg, n, shared, want) in enumerate(cases):
+            burst_more = n <= 1024 and j % 2 == 0
+            t = _lib.Ticket(dg, pk, sg, n, mode=_lib.STRICT, shared=shared, more=burst_more)
+            tickets.append((t, t.device_slot(), want, n))
+        for a, b in zip(tickets[0::2], tickets[1::2]):
+            if a[3] <= 1024 and b[3] <= 1024:
+                assert a[1] == b[1], "the two batches of a burst share a launch, hence a device"
+        for t, slot, want, n in tickets:
+            seen.add(slot)
+            ok, bm = t.wait()
+            assert bits(bm, n) == want and ok == all(want)
+    assert seen == {0, 1, 2}
+    for dg, pk, sg, n, shared, want in cases:            # the synchronous calls rotate as well; verdicts unchanged
+        ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.STRICT, shared, want_bitmap=True)
+        assert bits(bm, n) == want and ok == all(want)
