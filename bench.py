@@ -121,9 +121,15 @@ def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=14.0):
 
     one, r1 = run(1, n, dg, pk, sg, budget_s * 0.3)
     allc, rn = run(cores, big_n, big_dg, big_pk, big_sg, budget_s * 0.7)
+    try:        # the system OpenSSL's single verification on one core, a bracket independent of oracle/
+        import synth
+        openssl = round(synth.openssl_verify_rate(dg, pk, sg, n, stride, 0.5), 1)
+    except Exception as e:      # noqa: BLE001 - a bracket, not a result
+        openssl = "unavailable: %s" % e
     return {
         "value": round(allc, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
         "one_core": round(one, 1), "parallel_efficiency": round(allc / (cores * one), 3),
+        "openssl_evp_digestverify_one_core": openssl,
         "os_cpu_count": os.cpu_count(),
         "sample": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1 verify_strict, 51-bit limbs, "
                   "-O3 -march=native): the bench's own %d tuples tiled x%d = %d verifications per pass (>= 1,000 per "

@@ -163,3 +163,19 @@ def test_random_mutations_c_oracle_matches_bigint(oracle):
         assert bool(cl[i]) == E.verify_cofactorless(msgs[i], pks[i], sigs[i]), (i, kinds[i])
         accepted += strict[i]
     assert accepted == n // 6          # exactly the untouched ones verify
+
+
+def test_openssl_bracket_agrees_with_the_oracle_on_synthetic_batches(oracle):
+    """bench.py's `openssl_evp_digestverify_one_core` bracket: the system OpenSSL verifies the same
+    synthetic tuples the oracle accepts, and refuses a tampered one - a third implementation, independent of oracle/
+    and of the engine."""
+    import pytest
+    import synth
+    from conftest import oracle_verify_many
+    for shared in (False, True):
+        dg, pk, sg = synth.make_batch(24, shared=shared, first=400, cache_dir="/tmp/hs_synth")
+        assert all(oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, 24, 1))
+        assert synth.openssl_verify_rate(dg, pk, sg, 24, 0 if shared else 32, budget_s=0.05) > 100
+        bad = bytearray(sg); bad[64 * 3 + 5] ^= 2
+        with pytest.raises(RuntimeError):
+            synth.openssl_verify_rate(dg, pk, bytes(bad), 24, 0 if shared else 32, budget_s=0.05)

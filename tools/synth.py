@@ -71,6 +71,35 @@ def sign(seed, msg):
     return pk.raw, sig.raw
 
 
+def openssl_verify_rate(digests, pks, sigs, n, stride, budget_s=0.5):
+    """EVP_DigestVerify in a loop on one core over the first tuples of a packed batch (all must verify):
+    the sanity bracket of SURVEY.md 8d for single verifications.  Returns verifications per second.
+    (The ctypes call overhead, ~1 us per call, is inside the figure; a verification is ~50-100 us.)"""
+    import time
+    c = _libcrypto()
+    c.EVP_PKEY_new_raw_public_key.restype = ctypes.c_void_p
+    c.EVP_PKEY_new_raw_public_key.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    c.EVP_DigestVerifyInit.argtypes = [ctypes.c_void_p] * 5
+    c.EVP_DigestVerify.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    done, i = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        k = c.EVP_PKEY_new_raw_public_key(1087, None, pks[32 * i:32 * i + 32], 32)
+        ctx = c.EVP_MD_CTX_new()
+        c.EVP_DigestVerifyInit(ctx, None, None, None, k)
+        d = digests[32 * i:32 * i + 32] if stride else digests[:32]
+        ok = c.EVP_DigestVerify(ctx, sigs[64 * i:64 * i + 64], 64, d, 32)
+        c.EVP_MD_CTX_free(ctx)
+        c.EVP_PKEY_free(k)
+        if ok != 1:
+            raise RuntimeError("OpenSSL rejected synthetic signature %d" % i)
+        done += 1
+        i = (i + 1) % n
+        if done % 64 == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    return done / (time.perf_counter() - t0)
+
+
 def make_batch(n, shared, round_=1, first=0, cache_dir=None):
     """Returns (digests, pks, sigs) as packed bytes: digests is 32 bytes when `shared`
     else 32*n.  All signatures valid.  Cached under cache_dir when given."""
