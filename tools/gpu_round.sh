@@ -2,4 +2,4 @@
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 300 python tools/sharded_c_abi.py 1 2>/dev/null | grep "^{" | tail -1
+timeout 900 python -m pytest tests/test_gpu_fuzz_apis.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -30
