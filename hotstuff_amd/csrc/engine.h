@@ -1,5 +1,6 @@
 // engine.h - internal host-side declarations shared by the translation units of libhs_ed25519.so
-// (hs_ed25519.hip: kernels of the per-signature paths + contexts, key sets, host API, round ring;
+// (hs_ed25519.hip: kernels of the per-signature paths + init, contexts, key sets, device-pointer API;
+//  hs_host.hip: context pools, host-pointer API (synchronous, tickets), round ring;
 //  hs_rlc.hip: the batch random-linear-combination MSM path; hs_shard.hip: multi-GPU fan-out;
 //  hs_wire.hip: wire decode + batch signing).  Not installed; the public surface is include/hs_ed25519.h.
 #pragma once
@@ -7,6 +8,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 #include "verify.h"
 #include "../../include/hs_ed25519.h"
@@ -71,6 +74,25 @@ struct hs_ed25519_keyset {
 };
 
 namespace hs {
+// ---- process state (defined in hs_ed25519.hip; hs_host.hip serves the host-pointer API from it) -----------------
+struct dev_state {
+    int ordinal = -1;
+    u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
+    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one XCD-aligned slice of the CUs)
+    std::vector<hs_ed25519_ctx *> free_ctx[2];
+    int live[2] = {0, 0};
+    unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
+};
+extern std::mutex g_mu;
+extern std::condition_variable g_cv;
+extern std::atomic<bool> g_init;
+extern std::vector<dev_state> g_devs;
+extern std::atomic<size_t> g_max_batch;
+extern int kMaxPool[2];                      // contexts per pool: [0] wide, [1] narrow
+extern unsigned kPoolPartitions;             // CU slices the narrow pool's streams are spread over
+constexpr size_t kPartitionMaxBatch = 1024;  // host calls up to this many signatures are served by the narrow pool
+constexpr size_t kZeroCopyMax = 16384;       // host-pointer calls up to this size let the kernels read pinned memory directly
+int ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words);
 int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging);
 // a narrow (CU-partitioned) context for small n, a wide one above; nowait: HS_ED25519_E_BUSY instead of waiting for a free one
 int pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait = false);

@@ -1,0 +1,571 @@
+// hs_host.hip - the host-pointer side of libhs_ed25519.so (include/hs_ed25519.h): what the reference's shim binds.
+//   pools of stream contexts per device slot (wide / narrow = confined to an XCD-aligned slice of the CUs)
+//   hs_ed25519_verify_{shared,multi}[_cached], hs_ed25519_verify_tc[_cached]      synchronous, host buffers in, verdict out
+//   hs_ed25519_submit / ticket_ready / ticket_wait                                asynchronous; the small calls of a burst share a launch
+//   hs_ed25519_ring_*                                                             streamed rounds through pinned slots (BASELINE config 5)
+// Replaces the call sites of ed25519-dalek at /root/reference/crypto/src/lib.rs:200-219 as seen from the host;
+// the kernels and the device-pointer entry points it enqueues live in hs_ed25519.hip / hs_rlc.hip.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <new>
+#include <mutex>
+#include <condition_variable>
+#include <vector>
+#include "engine.h"
+
+using namespace hs;
+#define fail hs::hs_fail
+
+// ---- host-pointer API ----------------------------------------------------------------------
+// the call's verdict from the accept bitmap (the host forms pass no reject counter to the kernels);
+// the bitmap words of [0, n) are zeroed before every submit, so a launch that did not write them
+// can never be read as "all accepted"
+bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
+    const size_t words = n / 64;
+    for (size_t i = 0; i < words; i++) { uint64_t w; memcpy(&w, bm + 8 * i, 8); if (w != ~(uint64_t)0) return false; }
+    for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
+    return true;
+}
+int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
+    const int k = n <= kPartitionMaxBatch ? 1 : 0;
+    std::unique_lock<std::mutex> lk(g_mu);
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
+    for (;;) {
+        if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
+        dev_state &d = g_devs[slot];
+        if (!d.free_ctx[k].empty()) { *out = d.free_ctx[k].back(); d.free_ctx[k].pop_back(); return 0; }
+        if (d.live[k] < kMaxPool[k]) { d.live[k]++; break; }
+        if (nowait) return HS_ED25519_E_BUSY;       // not an error worth a message: the caller retries after a wait
+        g_cv.wait(lk);
+    }
+    const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
+    lk.unlock();
+    hs_ed25519_ctx *c = nullptr;
+    int rc = -1;
+    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the CUs
+        std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+        const unsigned lo = cus * part / kPoolPartitions, hi = cus * (part + 1) / kPoolPartitions;
+        for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
+        rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
+        if (rc) (void)hipGetLastError();          // CU masking unavailable: a plain stream serves as well
+    }
+    if (rc) rc = hs_ed25519_ctx_create_on(&c, 64, slot);
+    if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }
+    c->narrow = k == 1;
+    *out = c;
+    return 0;
+}
+void hs::pool_put(hs_ed25519_ctx *c) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
+    g_devs[c->slot].free_ctx[c->narrow ? 1 : 0].push_back(c);
+    g_cv.notify_all();
+}
+
+// One host-pointer verification on one device slot, split into submit (stage + enqueue, asynchronous)
+// and finish (wait + verdict) so that hs_shard.hip can have several devices in flight from one thread.
+// Up to kZeroCopyMax signatures the kernels read the pinned staging and write the pinned bitmap
+// directly over PCIe (hipHostMalloc memory is mapped on the device; every input byte is read
+// exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
+//   keys: n*32 key bytes (ks == NULL) or n uint32 indices into `ks`
+int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait) {
+    job.c = nullptr; job.n = n;
+    int rc = pool_get(&job.c, slot, n, nowait);
+    if (rc) return rc;
+    hs_ed25519_ctx *c = job.c;
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
+    rc = ctx_reserve(c, n > hint ? n : hint, true);
+    if (rc) return rc;
+    // staging layout: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n], each section 16-byte aligned
+    const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
+    memcpy(c->h_in, digests, dg_bytes);
+    memcpy(c->h_in + off_k, keys, key_bytes);
+    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    job.zc = n <= kZeroCopyMax;
+    uint8_t *in = job.zc ? c->h_in : c->d_in, *outp = job.zc ? c->h_out : c->d_out;
+    if (job.zc) memset(c->h_out, 0, bitmap_bytes(n));
+    else {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
+    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, c->stream);
+    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, c->stream);
+    if (rc) return rc;
+    if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
+    return 0;
+}
+// returns 1 / 0 / <0; always gives the context back.  bitmap (optional): ceil(n/8) bytes.
+int hs::host_finish(host_job &job, uint8_t *bitmap) {
+    hs_ed25519_ctx *c = job.c;
+    if (!c) return fail(HS_ED25519_E_ARG, "host_finish: nothing submitted");
+    job.c = nullptr;
+    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    if (bitmap) memcpy(bitmap, c->h_out, (job.n + 7) / 8);
+    return bitmap_all_ones(c->h_out, job.n) ? 1 : 0;
+}
+void hs::host_abandon(host_job &job) {
+    if (!job.c) return;
+    (void)hipSetDevice(job.c->device);
+    (void)hipStreamSynchronize(job.c->stream);
+    pool_put(job.c);
+    job.c = nullptr;
+}
+const uint8_t *hs::host_job_bitmap(const host_job &job) { return job.c ? job.c->h_out : nullptr; }
+
+// ---- small host calls: several per launch ------------------------------------------------------
+// One 1,024-signature batch is one wavefront per SIMD of its context's CU slice, and a lone
+// wavefront issues the 64-bit multiply-adds at half the rate two co-resident ones reach; the streams
+// cannot be multiplied instead (16 hardware queues).  So the small host calls (n <= kPartitionMaxBatch)
+// of one BURST - consecutive submits of one thread, all but the last flagged HS_ED25519_SUBMIT_MORE -
+// form a GROUP: one pool context, one launch (k_verify_fused_batches / k_verify_cached_lane2r_batches),
+// each member with its own slice of the pinned staging and its own bitmap.  A group launches when a
+// member arrives without the flag, when it is full, when a call of another kind follows, or when any
+// of its tickets is waited on or polled - never by a timer, and never later than that: a lone
+// synchronous call launches at once, exactly as before.  Groups are per thread (a burst is not
+// diluted by other threads' calls); tickets may be waited on from any thread.
+static const unsigned kGroupMax = 4;
+struct host_group {
+    std::mutex mu;
+    std::condition_variable cv;
+    hs_ed25519_ctx *c = nullptr;
+    const hs_ed25519_keyset *ks = nullptr;
+    int slot = 0;
+    // all under mu
+    unsigned members = 0, staged = 0, refs = 0;
+    bool closed = false, launched = false;
+    int launch_rc = 0;
+    hs_ed25519_batch desc[kGroupMax];
+};
+static const size_t kGroupInStride = 128 * kPartitionMaxBatch;       // staging bytes per member
+static size_t group_out_stride() { return bitmap_bytes(kPartitionMaxBatch); }
+
+// no more members; then on its stream (idempotent; waits until every member's bytes are staged)
+static int group_close_and_launch(host_group *g) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->closed = true;
+    if (g->launched) return g->launch_rc;
+    g->cv.wait(lk, [g] { return g->staged == g->members || g->launched; });
+    if (g->launched) return g->launch_rc;
+    int rc = 0;
+    if (hipSetDevice(g->c->device) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    else if (g->ks) rc = hs_ed25519_verify_device_batches_cached(g->c, g->ks, g->desc, g->members, g->c->stream);
+    else rc = hs_ed25519_verify_device_batches(g->c, g->desc, g->members, g->c->stream);
+    if (!rc && hipEventRecord(g->c->done, g->c->stream) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipEventRecord");
+    g->launch_rc = rc;
+    g->launched = true;
+    g->cv.notify_all();
+    return rc;
+}
+static void group_unref(host_group *g) {
+    bool last;
+    { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
+    if (last) { pool_put(g->c); delete g; }
+}
+// this thread's open group (it holds a reference); a thread that exits launches what it left open
+struct open_group_slot {
+    host_group *g = nullptr;
+    void drop(bool launch) { if (g) { if (launch) (void)group_close_and_launch(g); group_unref(g); g = nullptr; } }
+    ~open_group_slot() { drop(true); }
+};
+static thread_local open_group_slot t_open;
+
+// Host calls by key bytes can run on any device slot: with several GPUs open they go round the slots, one launch
+// (group or big call) at a time - the single node process of the reference then uses every GPU without sharding its
+// small certificates.  Calls through a key set run where the key set lives.
+static std::atomic<unsigned> g_cold_rr{0};
+static int next_cold_slot() {
+    const int n = hs::dev_slots();
+    return n > 1 ? (int)(g_cold_rr.fetch_add(1, std::memory_order_relaxed) % (unsigned)n) : 0;
+}
+// join this thread's open group or start one; stage; launch unless `more`.  *idx_out = the member's position.
+static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                        const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool more, bool nowait) {
+    host_group *g = t_open.g;
+    unsigned idx = 0;
+    bool closer = false;
+    if (g) {
+        bool joined = false;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (!g->closed && g->ks == ks && g->members < kGroupMax) {      // same kind (a key set pins its device slot, cold calls take any)
+                idx = g->members++; g->refs++; joined = true;
+                if (!more || g->members == kGroupMax) { g->closed = true; closer = true; }
+            }
+        }
+        if (!joined) { t_open.drop(true); g = nullptr; }       // waited on meanwhile, or another kind of call: that group goes now
+    }
+    if (!g) {
+        const int slot = ks ? ks->slot : next_cold_slot();
+        hs_ed25519_ctx *c = nullptr;
+        int rc = pool_get(&c, slot, n, nowait);
+        if (rc) return rc;
+        rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+        if (!rc) rc = ctx_reserve(c, kGroupMax * kPartitionMaxBatch, true);
+        if (!rc && !c->done && hipEventCreateWithFlags(&c->done, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+            rc = fail(HS_ED25519_E_DEVICE, "hipEventCreate");
+        if (!rc && !(g = new (std::nothrow) host_group())) rc = fail(HS_ED25519_E_NOMEM, "out of memory");
+        if (rc) { pool_put(c); return rc; }
+        g->c = c; g->ks = ks; g->slot = slot;
+        g->members = 1; g->refs = 1; idx = 0;
+        if (more) { g->refs++; t_open.g = g; }                  // the thread's reference to its open group
+        else { g->closed = true; closer = true; }
+    }
+    // this member's slice of the pinned staging: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n]
+    hs_ed25519_ctx *c = g->c;
+    uint8_t *in = c->h_in + idx * kGroupInStride, *outp = c->h_out + idx * group_out_stride();
+    const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16);
+    memcpy(in, digests, dg_bytes);
+    memcpy(in + off_k, keys, key_bytes);
+    memcpy(in + off_sig, sigs, 64 * n);
+    memset(outp, 0, bitmap_bytes(n));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        hs_ed25519_batch &d = g->desc[idx];
+        d.d_digests = in; d.digest_stride = digest_stride; d.d_pks = in + off_k; d.d_sigs = in + off_sig; d.n = n;
+        d.mode = mode == HS_ED25519_STRICT ? HS_ED25519_STRICT : HS_ED25519_BATCH;   // BATCH_RLC this small is the per-signature BATCH law
+        d.d_bitmap = outp; d.d_nreject = nullptr;
+        g->staged++;
+        g->cv.notify_all();
+    }
+    *g_out = g; *idx_out = idx;
+    if (closer) {
+        if (t_open.g == g) t_open.drop(false);
+        const int rc = group_close_and_launch(g);
+        if (rc) { group_unref(g); *g_out = nullptr; return rc; }
+    }
+    return 0;
+}
+// verdict of member idx; always drops the member's reference
+static int group_finish(host_group *g, unsigned idx, size_t n, uint8_t *bitmap) {
+    int rc = group_close_and_launch(g);
+    if (!rc && hipSetDevice(g->c->device) != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    if (!rc) { const hipError_t e = hipEventSynchronize(g->c->done); if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, hipGetErrorString(e)); }
+    int verdict = rc;
+    if (!rc) {
+        const uint8_t *outp = g->c->h_out + idx * group_out_stride();
+        if (bitmap) memcpy(bitmap, outp, (n + 7) / 8);
+        verdict = bitmap_all_ones(outp, n) ? 1 : 0;
+    } else if (g->launched) (void)hipStreamSynchronize(g->c->stream);      // nothing of this group may still run when the context goes back
+    group_unref(g);
+    return verdict;
+}
+static bool group_sized(size_t n, uint32_t mode) { return n && n <= kPartitionMaxBatch && mode <= HS_ED25519_BATCH_RLC; }
+
+static int verify_host(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const void *keys,
+                       const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "verify: bad mode");
+    if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "verify: null pointer");
+    if (group_sized(n, mode)) {
+        host_group *g = nullptr; unsigned idx = 0;
+        const int rc = group_submit(&g, &idx, ks, digests, digest_stride, keys, sigs, n, mode, false, false);
+        if (rc) return rc;
+        return group_finish(g, idx, n, bitmap);
+    }
+    host_job job;
+    int rc = host_submit(job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, keys, sigs, n, mode);
+    if (rc) { host_abandon(job); return rc; }
+    return host_finish(job, bitmap);
+}
+
+// ---- the same, asynchronous: submit now, collect the verdict later -------------------------------
+// A ticket owns a pool context (or a share of a group's) from submit to wait.  The reference is a
+// tokio program: its verify_batch call sites sit on async tasks (consensus/src/core.rs, mempool),
+// so the binding can submit from the task and await the ticket on a blocking-pool thread - or keep
+// several certificates in flight from one thread, which is what fills the GPU.
+struct hs_ed25519_ticket { host_job job; host_group *g = nullptr; unsigned idx = 0; size_t n = 0; };
+extern "C" int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
+                                 const void *pks_or_idx, const uint8_t *sigs, size_t n, uint32_t mode, uint32_t flags) {
+    if (!out) return fail(HS_ED25519_E_ARG, "submit: null ticket slot");
+    *out = nullptr;
+    if (mode > HS_ED25519_BATCH_RLC || (flags & ~(uint32_t)HS_ED25519_SUBMIT_MORE)) return fail(HS_ED25519_E_ARG, "submit: bad mode / flags");
+    if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "submit: digest_stride must be 0 or 32");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (n && (!digests || !pks_or_idx || !sigs)) return fail(HS_ED25519_E_ARG, "submit: null pointer");
+    hs_ed25519_ticket *t = new (std::nothrow) hs_ed25519_ticket();
+    if (!t) return fail(HS_ED25519_E_NOMEM, "submit: out of memory");
+    t->n = n;
+    int rc = 0;
+    if (group_sized(n, mode)) rc = group_submit(&t->g, &t->idx, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, flags & HS_ED25519_SUBMIT_MORE, true);
+    else if (n) { rc = host_submit(t->job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true); if (rc) host_abandon(t->job); }
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return 0;
+}
+extern "C" int hs_ed25519_ticket_ready(hs_ed25519_ticket *t) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_ready: null ticket");
+    hs_ed25519_ctx *c = t->g ? t->g->c : t->job.c;
+    if (!c) return 1;
+    if (t->g) { const int rc = group_close_and_launch(t->g); if (rc) return 1; }      // the error is reported by wait
+    if (hipSetDevice(c->device) != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+    const hipError_t e = t->g ? hipEventQuery(c->done) : hipStreamQuery(c->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(HS_ED25519_E_DEVICE, hipGetErrorString(e));
+}
+extern "C" int hs_ed25519_ticket_device_slot(const hs_ed25519_ticket *t) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_device_slot: null ticket");
+    const hs_ed25519_ctx *c = t->g ? t->g->c : t->job.c;
+    return c ? c->slot : 0;
+}
+extern "C" int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap) {
+    if (!t) return fail(HS_ED25519_E_ARG, "ticket_wait: null ticket");
+    int rc = 1;                                                        // an empty batch is Ok (crypto/src/lib.rs:212-219 on no votes)
+    if (t->g) rc = group_finish(t->g, t->idx, t->n, bitmap);
+    else if (t->job.c) rc = host_finish(t->job, bitmap);
+    delete t;
+    return rc;
+}
+
+extern "C" int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
+                                        size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host(nullptr, digest, 0, pks, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
+                                       size_t n, uint32_t mode, uint8_t *bitmap) {
+    return verify_host(nullptr, digests, 32, pks, sigs, n, mode, bitmap);
+}
+// host-pointer forms of the cached path: key_idx[i] indexes the key set
+extern "C" int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
+                                               const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
+    return verify_host(ks, digest, 0, key_idx, sigs, n, mode, bitmap);
+}
+extern "C" int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
+                                              const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap) {
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify: null key set");
+    return verify_host(ks, digests, 32, key_idx, sigs, n, mode, bitmap);
+}
+
+// TC::verify from host buffers: the per-vote digests SHA-512(round || high_qc_round)[..32]
+// (consensus/src/messages.rs:307-311) are built on the device; strict semantics.
+// ks == NULL: keys by bytes (pks_or_idx = n*32 key bytes); else pks_or_idx = n uint32 indices.
+static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *hq_rounds, const void *pks_or_idx,
+                          const uint8_t *sigs, size_t n, uint8_t *bitmap) {
+    if (n == 0) return g_init.load() ? 1 : fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (!hq_rounds || !pks_or_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_tc: null pointer");
+    hs_ed25519_ctx *c = nullptr;
+    int rc = pool_get(&c, ks ? ks->slot : 0, n);
+    if (rc) return rc;
+    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    HS_HIP(hipSetDevice(c->device), "hipSetDevice");
+    const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
+    rc = ctx_reserve(c, n > hint ? n : hint, true);
+    if (rc) return rc;
+    // staging (128 B per signature available): [hq: 8n][keys: 32n or 4n][sigs: 64n]
+    const size_t key_bytes = ks ? 4 * n : 32 * n;
+    const size_t off_k = round_up(8 * n, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
+    memcpy(c->h_in, hq_rounds, 8 * n);
+    memcpy(c->h_in + off_k, pks_or_idx, key_bytes);
+    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    const bool zc = n <= kZeroCopyMax;
+    uint8_t *in = zc ? c->h_in : c->d_in, *outp = zc ? c->h_out : c->d_out;
+    if (zc) memset(c->h_out, 0, bitmap_bytes(n));
+    else {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
+    if (ks)
+        rc = hs_ed25519_verify_device_tc_cached(c, ks, round, (const uint64_t *)in, (const uint32_t *)(in + off_k),
+                                                in + off_sig, n, outp, nullptr, c->stream);
+    else
+        rc = hs_ed25519_verify_device_tc(c, round, (const uint64_t *)in, in + off_k, in + off_sig, n, outp, nullptr, c->stream);
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
+    HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
+    return bitmap_all_ones(c->h_out, n) ? 1 : 0;
+}
+extern "C" int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const uint8_t *pks, const uint8_t *sigs,
+                                    size_t n, uint8_t *bitmap) {
+    return verify_host_tc(nullptr, round, high_qc_rounds, pks, sigs, n, bitmap);
+}
+extern "C" int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *high_qc_rounds,
+                                           const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint8_t *bitmap) {
+    if (!ks) return fail(HS_ED25519_E_ARG, "verify_tc_cached: null key set");
+    return verify_host_tc(ks, round, high_qc_rounds, key_idx, sigs, n, bitmap);
+}
+
+// ---- round ring: streamed rounds through pinned slots, one hipGraph launch per round -----------
+// BASELINE config 5.  A slot owns a stream, pinned host staging and device buffers.  The caller
+// writes a round's packed tuples straight into the slot's pinned memory (begin), submits it
+// (one hipGraphLaunch: H2D copy -> verification kernel(s) -> D2H copy of the bitmap) and collects
+// the verdict later (wait / poll); slots in flight overlap their copies and kernels on separate
+// streams.  The graph of a slot is captured once and re-launched while (n, digest form, mode) stay
+// the same - the steady state of a fixed committee, whose QCs carry exactly 2f+1 votes - and is
+// updated in place (hipGraphExecUpdate) when they change.
+struct ring_slot {
+    hs_ed25519_ctx *ctx = nullptr;
+    hipGraphExec_t exec = nullptr;
+    size_t g_n = 0, g_stride = 0; uint32_t g_mode = 0;                      // what `exec` was captured for
+    size_t n = 0, stride = 0, off_key = 0, off_sig = 0, in_bytes = 0;       // the round begun in this slot
+    bool begun = false, inflight = false;
+};
+struct hs_ed25519_ring {
+    std::vector<ring_slot> slots;
+    size_t cap = 0;
+    const hs_ed25519_keyset *ks = nullptr;
+    bool use_graph = false;
+    bool zero_copy = false;      // kernels read the pinned slot / write the pinned bitmap directly over PCIe
+    size_t captures = 0, launches = 0;
+};
+
+extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
+    if (!r) return;
+    for (ring_slot &s : r->slots) {
+        if (s.ctx) { (void)hipSetDevice(s.ctx->device); (void)hipStreamSynchronize(s.ctx->stream); }
+        if (s.exec) (void)hipGraphExecDestroy(s.exec);
+        if (s.ctx) hs_ed25519_ctx_destroy(s.ctx);
+    }
+    delete r;
+}
+
+extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, unsigned slots,
+                                      const hs_ed25519_keyset *ks, uint32_t flags) {
+    if (!out || slot_batch == 0 || slots == 0 || slots > 64 || slot_batch > 0x3fffffffu || flags > 3u)
+        return fail(HS_ED25519_E_ARG, "ring_create: bad arguments");
+    if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    hs_ed25519_ring *r = new (std::nothrow) hs_ed25519_ring();
+    if (!r) return fail(HS_ED25519_E_NOMEM, "ring_create: out of memory");
+    r->cap = round_up(slot_batch, 64); r->ks = ks;
+    // AUTO follows the measurements (profiles/r1_ring_sweep.md): zero-copy wins or ties up to QC-sized rounds of a
+    // 10,000-validator committee; above that the copy engines' bulk transfers are as good and plain stream
+    // operations overlap best.  The graph form never won on gfx950 / ROCm 7 and is kept selectable.
+    if (flags == HS_ED25519_RING_AUTO) flags = r->cap <= kZeroCopyMax ? HS_ED25519_RING_ZERO_COPY : HS_ED25519_RING_STREAM_OPS;
+    r->zero_copy = flags == HS_ED25519_RING_ZERO_COPY;
+    r->use_graph = flags == HS_ED25519_RING_GRAPH;
+    r->slots.resize(slots);
+    for (ring_slot &s : r->slots) {
+        int rc = hs_ed25519_ctx_create_on(&s.ctx, 64, ks ? ks->slot : 0);
+        if (!rc) rc = ctx_reserve(s.ctx, r->cap, true);      // all allocation happens here, none under capture
+        if (rc) { hs_ed25519_ring_destroy(r); return rc; }
+    }
+    *out = r;
+    return 0;
+}
+
+extern "C" int hs_ed25519_ring_begin(hs_ed25519_ring *r, unsigned slot, size_t n, size_t digest_stride,
+                                     uint8_t **digests, uint8_t **keys, uint8_t **sigs) {
+    if (!r || slot >= r->slots.size() || !digests || !keys || !sigs) return fail(HS_ED25519_E_ARG, "ring_begin: bad arguments");
+    if (n == 0 || n > r->cap) return fail(HS_ED25519_E_ARG, "ring_begin: n must be in [1, slot_batch]");
+    if (digest_stride != 0 && digest_stride != 32) return fail(HS_ED25519_E_ARG, "ring_begin: bad digest_stride");
+    ring_slot &s = r->slots[slot];
+    if (s.inflight) return fail(HS_ED25519_E_ARG, "ring_begin: slot still in flight (wait for it first)");
+    // one contiguous transfer: [digests][keys: 32n bytes, or 4n index bytes with a key set][sigs: 64n]
+    const size_t dg_bytes = digest_stride ? 32 * n : 32;
+    s.n = n; s.stride = digest_stride;
+    s.off_key = round_up(dg_bytes, 16);
+    s.off_sig = round_up(s.off_key + (r->ks ? 4 : 32) * n, 16);
+    s.in_bytes = s.off_sig + 64 * n;
+    s.begun = true;
+    *digests = s.ctx->h_in; *keys = s.ctx->h_in + s.off_key; *sigs = s.ctx->h_in + s.off_sig;
+    return 0;
+}
+
+static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
+    hs_ed25519_ctx *c = s.ctx;
+    // zero-copy: hipHostMalloc memory is mapped into the device's address space, so the kernels can
+    // take the slot's pinned buffers as they are - every input byte is read exactly once anyway
+    uint8_t *in = r->zero_copy ? c->h_in : c->d_in, *outp = r->zero_copy ? c->h_out : c->d_out;
+    if (!r->zero_copy) {
+        HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(s.n), c->stream), "ring clear bitmap");
+        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, s.in_bytes, hipMemcpyHostToDevice, c->stream), "ring H2D");
+    }
+    int rc;
+    if (r->ks)
+        rc = hs_ed25519_verify_device_cached(c, r->ks, in, s.stride, (const uint32_t *)(in + s.off_key),
+                                             in + s.off_sig, s.n, mode, outp, nullptr, c->stream);
+    else
+        rc = hs_ed25519_verify_device(c, in, s.stride, in + s.off_key, in + s.off_sig, s.n, mode,
+                                      outp, nullptr, c->stream);
+    if (rc) return rc;
+    if (!r->zero_copy)
+        HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(s.n), hipMemcpyDeviceToHost, c->stream), "ring D2H");
+    return 0;
+}
+
+extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_t mode) {
+    if (!r || slot >= r->slots.size() || mode > HS_ED25519_BATCH_RLC) return fail(HS_ED25519_E_ARG, "ring_submit: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.begun || s.inflight) return fail(HS_ED25519_E_ARG, "ring_submit: slot not begun / already in flight");
+    HS_HIP(hipSetDevice(s.ctx->device), "hipSetDevice");
+    if (mode == HS_ED25519_BATCH_RLC) {      // the MSM workspace is allocated here, never under graph capture
+        int rc = rlc_reserve(s.ctx, s.n);
+        if (rc) return rc;
+        if (!dev_base_table(s.ctx->slot)) return HS_ED25519_E_DEVICE;
+    }
+    hipStream_t st = s.ctx->stream;
+    // the verdict is read from the pinned bitmap: clear it so that a round whose kernels did not
+    // write it can never be read as accepted (the zero-copy kernels write this memory directly)
+    memset(s.ctx->h_out, 0, bitmap_bytes(s.n));
+    if (!r->use_graph) {
+        int rc = ring_enqueue(r, s, mode);
+        if (rc) return rc;
+    } else {
+        if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode) {
+            hipGraph_t g = nullptr;
+            HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            int rc = ring_enqueue(r, s, mode);
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipStreamEndCapture", e);
+            if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
+                hipGraphNode_t bad = nullptr;
+                hipGraphExecUpdateResult res;
+                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
+                    (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
+                    (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
+                }
+            }
+            if (!s.exec) {
+                e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
+                if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
+            }
+            (void)hipGraphDestroy(g);
+            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
+            r->captures++;
+        }
+        HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
+    }
+    r->launches++;
+    s.inflight = true; s.begun = false;
+    return 0;
+}
+
+// 1 = the slot's round has completed (or nothing is in flight), 0 = still running
+extern "C" int hs_ed25519_ring_poll(hs_ed25519_ring *r, unsigned slot) {
+    if (!r || slot >= r->slots.size()) return fail(HS_ED25519_E_ARG, "ring_poll: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.inflight) return 1;
+    hipError_t e = hipStreamQuery(s.ctx->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(HS_ED25519_E_DEVICE, "hipStreamQuery", e);
+}
+
+extern "C" int hs_ed25519_ring_wait(hs_ed25519_ring *r, unsigned slot, uint8_t *bitmap) {
+    if (!r || slot >= r->slots.size()) return fail(HS_ED25519_E_ARG, "ring_wait: bad arguments");
+    ring_slot &s = r->slots[slot];
+    if (!s.inflight) return fail(HS_ED25519_E_ARG, "ring_wait: nothing submitted in this slot");
+    hipError_t e = hipStreamSynchronize(s.ctx->stream);
+    s.inflight = false;
+    if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "ring stream sync", e);
+    if (bitmap) memcpy(bitmap, s.ctx->h_out, (s.n + 7) / 8);
+    return bitmap_all_ones(s.ctx->h_out, s.n) ? 1 : 0;
+}
+
+extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {
+    if (!r || !graph_captures || !launches) return fail(HS_ED25519_E_ARG, "ring_stats: null");
+    *graph_captures = r->captures; *launches = r->launches;
+    return 0;
+}
