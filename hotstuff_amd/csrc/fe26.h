@@ -87,6 +87,15 @@ HS_HD void fe_carry(fe &r) {
 }
 HS_HD void fe_neg(fe &r, const fe &a) { fe z; fe_0(z); fe_sub(r, z, a); fe_carry(r); }
 
+// the wrap of the last carry (c < 2^39) into limbs 0..2, shared by both forms
+HS_HD void fe_fold_top(fe &r, u64 c) {
+    u64 t = (u64)r.v[0] + 19 * c;
+    r.v[0] = (u32)t & HS_M26;
+    t = (t >> 26) + r.v[1];                    // t >> 26 < 2^18
+    r.v[1] = (u32)t & HS_M25;
+    r.v[2] += (u32)(t >> 25);
+}
+
 // carry ten 64-bit columns down to a reduced element
 HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
     u64 c;
@@ -97,11 +106,28 @@ HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
         h[i + 1] += c;
     }
     c = h[9] >> 25; r.v[9] = (u32)h[9] & HS_M25;
-    u64 t = (u64)r.v[0] + 19 * c;              // c < 2^39
-    r.v[0] = (u32)t & HS_M26;
-    t = (t >> 26) + r.v[1];                    // t >> 26 < 2^18
-    r.v[1] = (u32)t & HS_M25;
-    r.v[2] += (u32)(t >> 25);
+    fe_fold_top(r, c);                         // c < 2^39
+}
+
+// The carry out of column k enters column k + 1 as the ADDEND of that column's first multiply-add instead of through
+// a 64-bit add afterwards: v_mad_u64_u32 adds a 64-bit operand for free and a fully dependent chain of them issues as
+// fast as independent ones (profiles/r1_ubench_valu.txt: 10.4 / 5.5 cycles against 11.4 / 5.9), while the
+// v_lshl_add_u64 it replaces costs 6.6 / 5.3 cycles per column.  Same integers as fe_reduce_cols, bit for bit.
+// Measured (profiles/r2_sweeps.md section 4): +2 % on the headline, +3.5 % on the key-cache batches, -3.5 % QC latency.
+#ifndef HS_FE_SERIAL_CARRY
+#define HS_FE_SERIAL_CARRY 1
+#endif
+// acc + a * b with acc as the multiply-add's own 64-bit addend.  On the device this is spelled in assembly: left to
+// itself the compiler re-associates the sum, starts every column at zero and adds the carry afterwards with a
+// v_lshl_add_u64 of its own (ten per multiplication).
+HS_HD u64 fe_mad_carry(u32 a, u32 b, u64 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r, co;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(co) : "v"(a), "v"(b), "v"(acc));
+    return r;
+#else
+    return acc + (u64)a * b;
+#endif
 }
 
 HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
@@ -112,6 +138,28 @@ HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
         HS_CHECK((u64)2 * f.v[i] < (1ull << 32), "fe_mul: 2*f does not fit 32 bits");
         g19[i] = 19u * g.v[i]; f2[i] = 2u * f.v[i];
     }
+#if HS_FE_SERIAL_CARRY
+    u64 acc = 0;                               // carry into column k
+    fe out;                                    // r may alias f or g
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const bool wrap = i > k;
+            const u32 fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            const u32 gj = wrap ? g19[j] : g.v[j];
+            HS_CHECK(acc + (u64)fi * gj >= acc, "fe_mul: 64-bit column accumulator wrapped");
+            if (i == 0 && k > 0) acc = fe_mad_carry(fi, gj, acc);
+            else acc += (u64)fi * gj;
+        }
+        HS_CHECK(acc < (1ull << 63), "fe_mul: column too large for the carry chain");
+        if (k & 1) { out.v[k] = (u32)acc & HS_M25; acc >>= 25; }
+        else       { out.v[k] = (u32)acc & HS_M26; acc >>= 26; }
+    }
+    fe_fold_top(out, acc);
+    r = out;
+#else
     u64 h[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -129,6 +177,7 @@ HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
         h[k] = acc;
     }
     fe_reduce_cols(r, h);
+#endif
 }
 
 HS_HD void fe_sq(fe &r, const fe &f) {
@@ -142,9 +191,14 @@ HS_HD void fe_sq(fe &r, const fe &f) {
         f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i];
     }
     u64 h[10];
+#if HS_FE_SERIAL_CARRY
+    u64 acc = 0;
+#endif
 #pragma unroll
     for (int k = 0; k < 10; k++) {
+#if !HS_FE_SERIAL_CARRY
         u64 acc = 0;
+#endif
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
@@ -163,13 +217,28 @@ HS_HD void fe_sq(fe &r, const fe &f) {
                 const u32 a = f2[i];
                 const u32 b = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]);
                 HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
+#if HS_FE_SERIAL_CARRY
+                if (i == 0 && k > 0) acc = fe_mad_carry(a, b, acc);      // the column's first term takes the carry in
+                else
+#endif
                 acc += (u64)a * b;
             }
         }
         HS_CHECK(acc < (1ull << 63), "fe_sq: column too large for the carry chain");
+#if HS_FE_SERIAL_CARRY
+        if (k & 1) { h[k] = acc & HS_M25; acc >>= 25; }
+        else       { h[k] = acc & HS_M26; acc >>= 26; }
+#else
         h[k] = acc;
+#endif
     }
+#if HS_FE_SERIAL_CARRY
+#pragma unroll
+    for (int k = 0; k < 10; k++) r.v[k] = (u32)h[k];
+    fe_fold_top(r, acc);
+#else
     fe_reduce_cols(r, h);
+#endif
 }
 
 // r = a^(2^N).  Short runs are straight-line; long runs are a real loop (a 1- or 2-trip

@@ -3,4 +3,3 @@ mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
