@@ -117,16 +117,39 @@ HS_HD void fe_reduce_cols(fe &r, u64 h[10]) {
 #ifndef HS_FE_SERIAL_CARRY
 #define HS_FE_SERIAL_CARRY 1
 #endif
-// acc + a * b with acc as the multiply-add's own 64-bit addend.  On the device this is spelled in assembly: left to
-// itself the compiler re-associates the sum, starts every column at zero and adds the carry afterwards with a
-// v_lshl_add_u64 of its own (ten per multiplication).
-HS_HD u64 fe_mad_carry(u32 a, u32 b, u64 acc) {
+// One column of a product: acc += sum a[t] * b[t], the running 64-bit value being each multiply-add's own addend.
+// On the device the whole column is ONE assembly statement: left to itself the compiler re-associates the sum, starts
+// every column at zero and adds the carry afterwards with a v_lshl_add_u64 of its own (ten per multiplication), and
+// between separate assembly statements it must assume a forwarding hazard and pads every dependent pair with an s_nop.
+// A single accumulator instead of ten also frees ~18 registers (k_verify_cached_lane2r: 242 -> 166 VGPRs).
 #if defined(__HIP_DEVICE_COMPILE__)
-    u64 r, co;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(co) : "v"(a), "v"(b), "v"(acc));
-    return r;
+#define HS_MAD_LINE(a, b) "v_mad_u64_u32 %0, vcc, %" #a ", %" #b ", %0\n\t"
+HS_HD void fe_col5(u64 &acc, const u32 *a, const u32 *b) {
+    asm(HS_MAD_LINE(1, 6) HS_MAD_LINE(2, 7) HS_MAD_LINE(3, 8) HS_MAD_LINE(4, 9) HS_MAD_LINE(5, 10)
+        : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]) : "vcc");
+}
+HS_HD void fe_col6(u64 &acc, const u32 *a, const u32 *b) {
+    asm(HS_MAD_LINE(1, 7) HS_MAD_LINE(2, 8) HS_MAD_LINE(3, 9) HS_MAD_LINE(4, 10) HS_MAD_LINE(5, 11) HS_MAD_LINE(6, 12)
+        : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]),
+                      "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]) : "vcc");
+}
+HS_HD void fe_col10(u64 &acc, const u32 *a, const u32 *b) {
+    asm(HS_MAD_LINE(1, 11) HS_MAD_LINE(2, 12) HS_MAD_LINE(3, 13) HS_MAD_LINE(4, 14) HS_MAD_LINE(5, 15)
+        HS_MAD_LINE(6, 16) HS_MAD_LINE(7, 17) HS_MAD_LINE(8, 18) HS_MAD_LINE(9, 19) HS_MAD_LINE(10, 20)
+        : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+                      "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]) : "vcc");
+}
+#endif
+template <int N>
+HS_HD void fe_col(u64 &acc, const u32 (&a)[N], const u32 (&b)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N == 5 || N == 6 || N == 10, "column lengths of fe_sq (5, 6) and fe_mul (10)");
+    if (N == 5) fe_col5(acc, a, b); else if (N == 6) fe_col6(acc, a, b); else fe_col10(acc, a, b);
 #else
-    return acc + (u64)a * b;
+    for (int t = 0; t < N; t++) {
+        HS_CHECK(acc + (u64)a[t] * b[t] >= acc, "field multiplication: 64-bit column accumulator wrapped");
+        acc += (u64)a[t] * b[t];
+    }
 #endif
 }
 
@@ -143,16 +166,15 @@ HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
     fe out;                                    // r may alias f or g
 #pragma unroll
     for (int k = 0; k < 10; k++) {
+        u32 ca[10], cb[10];
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
             const bool wrap = i > k;
-            const u32 fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
-            const u32 gj = wrap ? g19[j] : g.v[j];
-            HS_CHECK(acc + (u64)fi * gj >= acc, "fe_mul: 64-bit column accumulator wrapped");
-            if (i == 0 && k > 0) acc = fe_mad_carry(fi, gj, acc);
-            else acc += (u64)fi * gj;
+            ca[i] = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            cb[i] = wrap ? g19[j] : g.v[j];
         }
+        fe_col<10>(acc, ca, cb);
         HS_CHECK(acc < (1ull << 63), "fe_mul: column too large for the carry chain");
         if (k & 1) { out.v[k] = (u32)acc & HS_M25; acc >>= 25; }
         else       { out.v[k] = (u32)acc & HS_M26; acc >>= 26; }
@@ -180,6 +202,26 @@ HS_HD void fe_mul(fe &r, const fe &f, const fe &g) {
 #endif
 }
 
+// the operands of term t of column k of a squaring (i <= j, i + j = k mod 10):
+//   diagonal  f_i^2 * (2 if i odd) * (19 if wrapped);  off-diagonal  2 f_i * f_j * (2 if both odd) * (19 if wrapped)
+template <int K>
+HS_HD void fe_sq_col(u64 &acc, const fe &f, const u32 (&f2)[10], const u32 (&f19)[10], const u32 (&f38)[10]) {
+    constexpr int N = (K & 1) ? 5 : 6;
+    u32 a[N], b[N];
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const int j = (K - i + 10) % 10;
+        if (i > j) continue;
+        const bool wrap = (i + j) >= 10;
+        const bool oo = (i & 1) && (j & 1);
+        if (i == j) { a[t] = oo ? f2[i] : f.v[i]; b[t] = wrap ? f19[i] : f.v[i]; }
+        else { a[t] = f2[i]; b[t] = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]); }    // each factor stays below 2^32
+        t++;
+    }
+    fe_col<N>(acc, a, b);
+}
+
 HS_HD void fe_sq(fe &r, const fe &f) {
     // column k = sum_{i<=j, i+j = k (mod 10)} c_ij f_i f_j, c = 2 off-diagonal,
     // x2 more when both odd, x19 when i+j >= 10.
@@ -190,53 +232,35 @@ HS_HD void fe_sq(fe &r, const fe &f) {
         HS_CHECK(!(i & 1) || (u64)38 * f.v[i] < (1ull << 32), "fe_sq: 38*f (odd limb) does not fit 32 bits");
         f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i];
     }
-    u64 h[10];
 #if HS_FE_SERIAL_CARRY
-    u64 acc = 0;
-#endif
+    u64 acc = 0;                               // carry into the next column
+    fe out;                                    // r may alias f
+#define HS_SQ_COL(K, M, S) fe_sq_col<K>(acc, f, f2, f19, f38); HS_CHECK(acc < (1ull << 63), "fe_sq: column too large for the carry chain"); \
+    out.v[K] = (u32)acc & M; acc >>= S;
+    HS_SQ_COL(0, HS_M26, 26) HS_SQ_COL(1, HS_M25, 25) HS_SQ_COL(2, HS_M26, 26) HS_SQ_COL(3, HS_M25, 25) HS_SQ_COL(4, HS_M26, 26)
+    HS_SQ_COL(5, HS_M25, 25) HS_SQ_COL(6, HS_M26, 26) HS_SQ_COL(7, HS_M25, 25) HS_SQ_COL(8, HS_M26, 26) HS_SQ_COL(9, HS_M25, 25)
+#undef HS_SQ_COL
+    fe_fold_top(out, acc);
+    r = out;
+#else
+    u64 h[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
-#if !HS_FE_SERIAL_CARRY
         u64 acc = 0;
-#endif
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
             if (i > j) continue;
             const bool wrap = (i + j) >= 10;
             const bool oo = (i & 1) && (j & 1);
-            if (i == j) {
-                // f_i^2 * (2 if odd) * (19 if wrap)
-                const u32 a = oo ? f2[i] : f.v[i];
-                const u32 b = wrap ? f19[i] : f.v[i];
-                HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
-                acc += (u64)a * b;
-            } else {
-                // 2 f_i f_j * (2 if both odd) * (19 if wrap); keep each factor < 2^32:
-                // a = 2 f_i ; b = f_j * (1 | 2 | 19 | 38)
-                const u32 a = f2[i];
-                const u32 b = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]);
-                HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
-#if HS_FE_SERIAL_CARRY
-                if (i == 0 && k > 0) acc = fe_mad_carry(a, b, acc);      // the column's first term takes the carry in
-                else
-#endif
-                acc += (u64)a * b;
-            }
+            const u32 a = i == j ? (oo ? f2[i] : f.v[i]) : f2[i];
+            const u32 b = i == j ? (wrap ? f19[i] : f.v[i]) : (wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f.v[j]));
+            HS_CHECK(acc + (u64)a * b >= acc, "fe_sq: 64-bit column accumulator wrapped");
+            acc += (u64)a * b;
         }
         HS_CHECK(acc < (1ull << 63), "fe_sq: column too large for the carry chain");
-#if HS_FE_SERIAL_CARRY
-        if (k & 1) { h[k] = acc & HS_M25; acc >>= 25; }
-        else       { h[k] = acc & HS_M26; acc >>= 26; }
-#else
         h[k] = acc;
-#endif
     }
-#if HS_FE_SERIAL_CARRY
-#pragma unroll
-    for (int k = 0; k < 10; k++) r.v[k] = (u32)h[k];
-    fe_fold_top(r, acc);
-#else
     fe_reduce_cols(r, h);
 #endif
 }
