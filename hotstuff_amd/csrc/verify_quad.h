@@ -55,7 +55,10 @@ template <int PA, int PB, int NEG, int ZERO>
 HS_Q qv q_comb(const qv &a, const qv &b) {
     const u32 lane = q_lane();
     u32 neg = ((NEG >> lane) & 1) ? 0xffffffffu : 0u;
-    const u32 keep = ((ZERO >> lane) & 1) ? 0u : 0xffffffffu;
+    u32 keep = ((ZERO >> lane) & 1) ? 0u : 0xffffffffu;
+    // keep it a mask in a register: known to be 0 / ~0 per lane, the compiler turns `qb & keep` into a v_cndmask_b32_e64
+    // on an SGPR-pair mask (4.9 cycles per wave64 instruction at two wavefronts per SIMD against 3.0 for the v_and_b32)
+    if (ZERO) asm("" : "+v"(keep));
     // NEVER write this as `pa + bias - qb`: the compiler folds the DPP move into the subtraction as
     // v_subrev_u32_dpp, and on gfx950 that instruction permutes its OTHER operand (measured:
     // tools/dpp_subrev_check.hip, profiles/r1_dpp_subrev.txt) - silently wrong lanes.  With every lane

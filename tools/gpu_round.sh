@@ -2,22 +2,19 @@
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_keyset.py tests/test_gpu_fuzz_apis.py -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5
 show() { python -c "
 import sys, json
 for l in sys.stdin:
     try: j = json.loads(l)
     except Exception: continue
     q = j.get('qc_verify_latency', {})
-    r = j.get('rlc_ab', {})
-    print('headline %.2f M  kernel %.4f ms  int_roofline %.3f | cached %.1f M  large %.4f ms | qc cold dev %.4f host %.4f cached dev %.4f | e2e %.1f M | rlc66667 p50 %.4f tput %.1f M  persig %.4f' % (
+    print('headline %.2f M  kernel %.4f ms  int_roofline %.3f | cached %.1f M  large %.4f ms | qc cold dev %.4f host %.4f cached dev %.4f | e2e %.1f M' % (
         j['value'] / 1e6, j['roofline']['avg_kernel_ms'], j['int_roofline']['frac'], j['committee_cached']['value'] / 1e6,
         j['committee_cached']['large_committee']['avg_kernel_ms'], q.get('p50_ms_device_resident', 0), q.get('p50_ms_host_api', 0),
-        q.get('committee_cached', {}).get('p50_ms_device_resident', 0), j['end_to_end']['value'] / 1e6,
-        r['66667']['rlc_msm']['p50_ms'], r['66667']['rlc_msm']['signatures_per_s_4_in_flight'] / 1e6, r['66667']['per_signature']['p50_ms']))
+        q.get('committee_cached', {}).get('p50_ms_device_resident', 0), j['end_to_end']['value'] / 1e6))
 "; }
 for rep in 1 2; do
-echo "== column chains in assembly (default)"; timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | show
-echo "== 64-bit add carry (variant)"; HS_ED25519_LIB=build/variant/libhs_ed25519.so timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | show
+echo "== default"; timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | show
 done
-for k in 2 4 8; do echo "== cached batches per launch $k"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-qc --cached-batches-per-launch $k 2>/dev/null | show; done
+for k in 2 3 4 8; do echo "== cached batches per launch $k"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --cached-batches-per-launch $k 2>/dev/null | show; done
