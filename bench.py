@@ -58,12 +58,16 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 #   (field mul = 100 mads, square = 55; quad kernels count all four lanes of the quad),
 # against the chip-wide issue rate measured by tools/ubench_valu.hip (profiles/r1_ubench_valu.txt).
 MAD_PER_VERIFY = {
-    # fused quad: per wavefront of 16 signatures 256 dbl x (55 + 100) + 96 add x 200 + table 7 x 300
-    # + decompress (255 sq + 21 mul) + small-order test, all x 64 lanes / 16 signatures
-    "k_verify_fused": (256 * 155 + 96 * 200 + 7 * 300 + 255 * 55 + 21 * 100 + 3 * 620) * 64 // 16,
-    "k_verify_quad": (256 * 155 + 96 * 200 + 7 * 300) * 64 // 16,
-    # lane: 1024 sq + ~1600 mul in k_verify (k_prepare adds 2 x (267 sq + 30 mul))
-    "k_verify": 1024 * 55 + 1600 * 100,
+    # fused quad: per wavefront of 16 signatures 252 dbl x (55 + 100) + (64 + 16) add x 200 + table 7 x 300
+    # + decompress (255 sq + 21 mul), all x 64 lanes / 16 signatures.  (r2: the strict small-order test became a
+    # comparison of the canonical y - no doublings; [s]B went from 32 additions on 8-bit windows to 16 on 16-bit
+    # windows; the four doublings of the identity at the start are skipped.  r1 counted 315,860.)
+    "k_verify_fused": (252 * 155 + 80 * 200 + 7 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
+    # pairs form: a wavefront carries 32 signatures; one decompression pass of all 64 lanes serves both window loops
+    "k_verify_fused_pairs": (2 * (252 * 155 + 80 * 200 + 7 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
+    "k_verify_quad": (252 * 155 + 80 * 200 + 7 * 300) * 64 // 16,
+    # lane: 1008 sq + ~1470 mul in k_verify (k_prepare adds 2 x (267 sq + 30 mul))
+    "k_verify": 1008 * 55 + 1470 * 100,
 }
 MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 
@@ -506,6 +510,9 @@ def main():
                     help="independent 1,024-tuple batches per step per GPU")
     ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "2")),
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
+    ap.add_argument("--kernel", choices=("auto", "fused", "pairs"), default=os.environ.get("HS_BENCH_KERNEL", "auto"),
+                    help="hs_ed25519_verify_device_batches kernel: the library's choice by batch count, one signature per quad, "
+                         "or the pairs form (two signatures per quad)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
     ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "2")),
@@ -576,6 +583,8 @@ def main():
     if ctxs is None:
         streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
+    for c in ctxs:
+        c.set_kernel({"auto": _lib.KERNEL_AUTO, "fused": _lib.KERNEL_FUSED, "pairs": _lib.KERNEL_FUSED_PAIRS}[args.kernel])
     bm_bytes = 8 * ((n + 63) // 64)
     K = max(1, min(16, args.batches_per_launch))
     B = (B + K - 1) // K * K               # whole launches
@@ -757,10 +766,11 @@ def main():
 
     # the headline's 16 stream contexts are done: release their streams before the extras create their own
     # (HIP multiplexes streams onto 16 hardware queues; leftover streams would share queues with the extras')
+    kernel_name = (_lib.lib().hs_ed25519_batches_kernel_for(ctxs[0]._h, K).decode() if (K > 1 and n <= 32768)
+                   else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode())
     for c in ctxs:
         c.close()
     traffic = traffic_src = None
-    kernel_name = "k_verify_fused_batches" if (K > 1 and n <= 32768) else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
         kname = kernel_name
         for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
@@ -830,7 +840,7 @@ def main():
                            "k_verify": round(avg_verify_ms, 4)},
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
-        kname = "k_verify_fused" if kernel_name == "k_verify_fused_batches" else kernel_name
+        kname = {"k_verify_fused_batches": "k_verify_fused", "k_verify_fused_pairs_batches": "k_verify_fused_pairs"}.get(kernel_name, kernel_name)
         if kname in MAD_PER_VERIFY:
             mad_s = value / world * MAD_PER_VERIFY[kname]
             out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,

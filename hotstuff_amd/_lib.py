@@ -58,6 +58,8 @@ def lib():
                 l.hs_ed25519_dominant_kernel_for.restype = ctypes.c_char_p
                 l.hs_ed25519_cached_kernel_for.argtypes = [sz]
                 l.hs_ed25519_cached_kernel_for.restype = ctypes.c_char_p
+                l.hs_ed25519_batches_kernel_for.argtypes = [vp, sz]
+                l.hs_ed25519_batches_kernel_for.restype = ctypes.c_char_p
                 l.hs_ed25519_verify_shared.argtypes = [vp, vp, vp, sz, u32, vp]
                 l.hs_ed25519_verify_shared.restype = ctypes.c_int
                 l.hs_ed25519_verify_multi.argtypes = [vp, vp, vp, sz, u32, vp]
@@ -314,9 +316,10 @@ def ensure_init():
 
 
 # DeviceContext.set_kernel: 0 = by batch size; 1 = one lane per signature (cold: k_prepare + k_verify,
-# key cache: k_verify_cached_lane); 3 = fused / two-lane kernels at any size.  Other variants exist
+# key cache: k_verify_cached_lane); 3 = fused / two-lane kernels at any size; 4 = the pairs form of the fused kernel
+# in verify_batches (two signatures per quad; elsewhere it behaves as 3).  Other variants exist
 # only in -DHS_AB_VARIANTS builds (2 quad stage 2 / two-lane inversion, 10, 13: four-lane cached forms).
-KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED = 0, 1, 3
+KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED, KERNEL_FUSED_PAIRS = 0, 1, 3, 4
 
 
 def _buf(b):

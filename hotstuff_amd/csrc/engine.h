@@ -38,7 +38,7 @@ bool engine_ready();
 }  // namespace hs
 
 // kernel choices of a context (hs_ed25519_ctx_set_kernel)
-enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3 };
+enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3, HS_K_FUSED_PAIRS = 4 };
 
 struct hs_ed25519_ctx {
     int slot = 0, device = 0;
@@ -77,7 +77,8 @@ namespace hs {
 // ---- process state (defined in hs_ed25519.hip; hs_host.hip serves the host-pointer API from it) -----------------
 struct dev_state {
     int ordinal = -1;
-    u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table
+    u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table (8-bit windows; also the RLC path's [b]B)
+    u32 *base_tab16 = nullptr;               // the base point's 16-bit window table (verify_cached.h: 16 x 32,769 x 128 B), built from base_tab
     // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one XCD-aligned slice of the CUs)
     std::vector<hs_ed25519_ctx *> free_ctx[2];
     int live[2] = {0, 0};

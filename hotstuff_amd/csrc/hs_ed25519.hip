@@ -40,7 +40,8 @@ using namespace hs;
 // ------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------
-__device__ ge_niels g_btab[HS_BTAB_ENTRIES];      // j*B, j = 0..128 (uploaded by hs_ed25519_init)
+__device__ const u32 *g_b16;                      // window 0 of the base point's 16-bit table: j*B, j <= 32,768, 128-byte entries
+                                                  // (verify_cached.h; built and set by hs_ed25519_init_devices)
 
 // (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
 __global__ void __launch_bounds__(64, 3)
@@ -67,7 +68,7 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     const bool active = i < n;
     // inactive tail lanes run lane min(i, n-1)'s data so the wavefront stays convergent
-    const bool ok = verify_lane(ws, active ? i : n - 1, mode, g_btab) && active;
+    const bool ok = verify_lane(ws, active ? i : n - 1, mode, g_b16) && active;
     const unsigned long long mask = __ballot(ok);
     if (threadIdx.x == 0) {
         bitmap[blockIdx.x] = mask;
@@ -94,7 +95,6 @@ k_tc_digests(unsigned long long round, const unsigned long long *__restrict__ hq
 
 // Four lanes per signature (verify_quad.h): a wavefront covers 16 signatures, so a
 // 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
-__device__ fe g_btab4[HS_BTAB_ENTRIES][4];        // cached j*B, [j][lane] = (Y-X, Y+X, 2dT, 2Z)
 
 #ifdef HS_AB_VARIANTS
 __global__ void __launch_bounds__(64)
@@ -104,7 +104,7 @@ k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap
     const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     bool flags_ok;
-    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_btab4, flags_ok, atab);
+    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_b16, flags_ok, atab);
     unsigned long long m = __ballot(f.f && flags_ok && active);
     // signature q accepted iff all four lanes of its quad agree; gather bit 4q -> bit q
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs
     const u32 j = active ? i : n - 1;
     u32 msg[8];
     load_msg(msg, msgs, j);
-    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_btab4, atab);
+    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
     m = (m | (m >> 3)) & 0x0303030303030303ull;
@@ -158,6 +158,40 @@ __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs
             if (bad) atomicAdd(nreject, bad);
         }
     }
+}
+// 16-bit ballot of a wavefront of quads: signature q accepted iff all four lanes of quad q agree
+__device__ __forceinline__ u32 quad_ballot16(bool ok) {
+    unsigned long long m = __ballot(ok);
+    m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    return (u32)m;
+}
+// The pairs form (verify_quad.h, quad_pair_*): `block` = this wavefront's index within its batch, 32 signatures per
+// wavefront - quad q verifies signature 32 block + q, then 32 block + 16 + q, so each pass fills one 16-bit bitmap word.
+__device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
+                                                  const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
+                                                  u32 *__restrict__ nreject) {
+    qtab atab; atab.lds = s_atab;
+    const u32 q = threadIdx.x >> 2;
+    const u32 i0 = block * 32 + q, i1 = i0 + 16;
+    const u32 j0 = i0 < n ? i0 : n - 1, j1 = i1 < n ? i1 : n - 1;
+    const quad_pair_points pp = quad_pair_decompress(pks, sigs, j0, j1, mode);
+    u32 bad = 0;
+#pragma nounroll
+    for (u32 h = 0; h < 2; h++) {
+        const u32 i = h ? i1 : i0, j = h ? j1 : j0;
+        u32 msg[8];
+        load_msg(msg, msgs, j);
+        const bool ok = quad_pair_pass(pp, h, pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab);
+        const u32 m = quad_ballot16(ok && i < n);
+        if (threadIdx.x == 0) bitmap16[2 * block + h] = (unsigned short)m;
+        const u32 first = block * 32 + 16 * h;
+        bad += (first < n ? min(16u, n - first) : 0u) - (u32)__popc(m);
+    }
+    if (threadIdx.x == 0 && nreject && bad) atomicAdd(nreject, bad);
 }
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
@@ -182,6 +216,16 @@ k_verify_fused_batches(fused_batch_list L) {
     const fused_batch &B = L.b[k];
     fused_block(s_atab, blockIdx.x - B.first_block, B.msgs, B.pks, B.sigs, B.n, B.mode, B.bitmap16, B.nreject, nullptr);
 }
+// The same list served by the pairs form: first_block counts 32-signature wavefronts.
+__global__ void __launch_bounds__(64, 2)
+k_verify_fused_pairs_batches(fused_batch_list L) {
+    __shared__ u32 s_atab[HS_QTAB_WORDS];
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const fused_batch &B = L.b[k];
+    fused_pairs_block(s_atab, blockIdx.x - B.first_block, B.msgs, B.pks, B.sigs, B.n, B.mode, B.bitmap16, B.nreject);
+}
 
 // ---- committee key cache (verify_cached.h) -------------------------------------------------
 // registration pass 1: one lane per key - decompress, flags, keep the key bytes
@@ -195,7 +239,7 @@ k_keyset_decompress(const u32 *__restrict__ pks, u32 nkeys, u32 *__restrict__ ax
     for (int j = 0; j < 8; j++) { enc[j] = pks[(size_t)8 * k + j]; pk_out[(size_t)8 * k + j] = enc[j]; }
     ge_p3 p;
     u32 fl = ge_decompress(p, enc) ? HS_F_ONCURVE : 0;
-    fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+    fl |= ge_is_small_order_affine(p.Y) ? HS_F_SMALL : 0;
     flag[k] = fl;
 #pragma unroll
     for (int j = 0; j < 10; j++) { axy[(size_t)20 * k + j] = p.X.v[j]; axy[(size_t)20 * k + 10 + j] = p.Y.v[j]; }
@@ -229,6 +273,14 @@ k_keyset_affine(const u32 *__restrict__ proj, u32 *__restrict__ tab, unsigned lo
     const unsigned long long g = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
     if (g >= groups) return;
     keyset_affine_group(tab + g * (HS_KS_AFFINE_GROUP * HS_KS_ENTRY_WORDS), proj + g * (HS_KS_AFFINE_GROUP * HS_KS_PROJ_WORDS));
+}
+// the base point's 16-bit table (verify_cached.h): one lane per entry, projective into the scratch; k_keyset_affine
+// then normalises it in groups of eight
+__global__ void __launch_bounds__(64)
+k_base16_build(const u32 *__restrict__ t8, u32 *__restrict__ proj) {
+    const u32 e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= HS_B16_WINDOWS * HS_B16_ENTRIES) return;
+    base16_entry_projective(proj + (size_t)e * HS_KS_PROJ_WORDS, t8, e / HS_B16_ENTRIES, e % HS_B16_ENTRIES);
 }
 #ifdef HS_AB_VARIANTS
 // verification against a key set: one quad per signature, 64 table additions + 1 inversion
@@ -291,7 +343,7 @@ k_verify_cached_5w(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_
         for (int t = 0; t < 8; t++) enc[t] = sigs[(size_t)16 * j + t];
         ge_p3 R;
         u32 fl = ge_decompress(R, enc) ? HS_F_ONCURVE : 0;
-        if (strict) fl |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+        if (strict) fl |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0;
 #pragma unroll
         for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
         s_r[20][lane] = fl;
@@ -382,7 +434,7 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
 // through LDS; the chains then finish with a projective comparison instead of an inversion that both
 // lanes of a pair would execute.  Per 64 signatures: 2 x 52 K + 36 K instructions instead of 2 x 82 K.
 // `block` = this workgroup's index within its batch (64 signatures per workgroup)
-__device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ btab,
+__device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16,
                                                     msg_src msgs, const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                                                     u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -403,7 +455,7 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
         for (int t = 0; t < 8; t++) enc[t] = sigs[(size_t)16 * j + t];
         ge_p3 R;
         u32 fl = ge_decompress(R, enc) ? HS_F_ONCURVE : 0;
-        if (strict) fl |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+        if (strict) fl |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0;
 #pragma unroll
         for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
         s_r[20][lane] = fl;
@@ -417,11 +469,11 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
         const u32 *sig = sigs + (size_t)16 * j;
         u32 kw[8], sw[8], msg[8];
         load_msg(msg, msgs, j);
-        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true, true);
         const u32 fl = ks.flag[ki];
         ok = ok && known && (fl & HS_F_ONCURVE);
         if (strict) ok = ok && !(fl & HS_F_SMALL);
-        cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw);
+        cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw);
     }
     __syncthreads();
     if (wave == 2) return;
@@ -449,29 +501,29 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
     }
 }
 __global__ void __launch_bounds__(192)
-k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
                        const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                        u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
-    cached_lane2r_block(s_r, blockIdx.x, ks, nkeys, btab, msgs, key_idx, sigs, n, mode, bitmap32, nreject, skip);
+    cached_lane2r_block(s_r, blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, bitmap32, nreject, skip);
 }
 // several independent small key-cache batches in one grid (hs_ed25519_verify_device_batches_cached): a 1,024-signature
 // batch is only 16 workgroups of three wavefronts here
 struct cached_batch { msg_src msgs; const u32 *key_idx, *sigs; u32 *bitmap32; u32 *nreject; u32 n, mode, first_block, pad; };
 struct cached_batch_list { cached_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
 __global__ void __launch_bounds__(192)
-k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, cached_batch_list L) {
+k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cached_batch_list L) {
     __shared__ u32 s_r[21][64];
     u32 k = 0;
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
     const cached_batch &B = L.b[k];
-    cached_lane2r_block(s_r, blockIdx.x - B.first_block, ks, nkeys, btab, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
+    cached_lane2r_block(s_r, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
 }
 
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches
 __global__ void __launch_bounds__(64)
-k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
+k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
                      const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                      unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     if (skip && *skip) {
@@ -490,11 +542,11 @@ k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, ms
 #pragma unroll
     for (int t = 0; t < 8; t++) renc[t] = sig[t];
     load_msg(msg, msgs, j);
-    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
+    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true, true);
     const u32 fl = ks.flag[ki];
     ok = ok && known && (fl & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
-    const bool curve = verify_cached_lane(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
+    const bool curve = verify_cached_lane(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
     const unsigned long long mask = __ballot(ok && curve && active);
     if (threadIdx.x == 0) {
         bitmap[blockIdx.x] = mask;
@@ -531,6 +583,9 @@ int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrid
 // kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
 // (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
 static const size_t kCachedLane1Min = 98304;
+// hs_ed25519_verify_device_batches switches to the pairs form from this many batches per call (measured, DESIGN.md
+// section 5); HS_ED25519_PAIRS_MIN_BATCHES overrides it for A/B runs (0 = never)
+static std::atomic<size_t> g_pairs_min_batches{4};
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
@@ -636,7 +691,7 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
 extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
     if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_kernel: null context");
     const int old = c->kernel;
-    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED
+    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED || which == HS_K_FUSED_PAIRS
 #ifdef HS_AB_VARIANTS
         || which == 2 || which == 10 || which == 12 || which == 13
 #endif
@@ -645,6 +700,46 @@ extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
     return old;
 }
 
+// The base point's tables on one device (called by hs_ed25519_init_devices with that device current): the 8-bit
+// key-cache table through the key-set registration kernels, then the 16-bit table from it - one addition per entry into
+// a projective scratch (84 MB, freed at once) and the shared-inversion normalisation the key tables get.
+static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate, hipStream_t st);
+static void free_base_tables(dev_state &d) {
+    if (d.base_tab || d.base_tab16) (void)hipSetDevice(d.ordinal);
+    if (d.base_tab) { (void)hipFree(d.base_tab); d.base_tab = nullptr; }
+    if (d.base_tab16) { (void)hipFree(d.base_tab16); d.base_tab16 = nullptr; }
+}
+static int build_base_tables(dev_state &d) {
+    ge_p3 b; ge_basepoint(b);
+    u32 h_axy[20];
+    for (int j = 0; j < 10; j++) { h_axy[j] = b.X.v[j]; h_axy[10 + j] = b.Y.v[j]; }
+    u32 *d_axy = nullptr, *d_t16 = nullptr, *d_proj = nullptr;
+    const size_t entries = (size_t)HS_B16_WINDOWS * HS_B16_ENTRIES;
+    hipError_t e = hipMalloc((void **)&d_axy, sizeof h_axy);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.base_tab, (size_t)HS_KS_KEY_WORDS * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_axy, h_axy, sizeof h_axy, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? build_tables(d.base_tab, d_axy, 1, false, nullptr) : 0;
+    if (e == hipSuccess && !rc) e = hipMalloc((void **)&d_t16, HS_B16_WORDS * 4);
+    if (e == hipSuccess && !rc) e = hipMalloc((void **)&d_proj, entries * HS_KS_PROJ_WORDS * 4);
+    if (e == hipSuccess && !rc) {
+        const u32 *p_t8 = d.base_tab;
+        void *a1[] = { &p_t8, &d_proj };
+        e = hipLaunchKernel((const void *)k_base16_build, dim3((unsigned)((entries + 63) / 64)), dim3(64), a1, 0, nullptr);
+    }
+    if (e == hipSuccess && !rc) {
+        const u32 *p_proj = d_proj;
+        unsigned long long groups = entries / HS_KS_AFFINE_GROUP;
+        void *a2[] = { &p_proj, &d_t16, &groups };
+        e = hipLaunchKernel((const void *)k_keyset_affine, dim3((unsigned)((groups + 63) / 64)), dim3(64), a2, 0, nullptr);
+    }
+    if (e == hipSuccess && !rc) e = hipDeviceSynchronize();
+    if (d_proj) (void)hipFree(d_proj);
+    if (d_axy) (void)hipFree(d_axy);
+    d.base_tab16 = d_t16;
+    if (e != hipSuccess && !rc) rc = fail(HS_ED25519_E_DEVICE, "base-point table build", e);
+    if (rc) free_base_tables(d);
+    return rc;
+}
 extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
     if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -662,22 +757,22 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     // runtime reads this when it initialises, so it only takes effect when this library is the
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
     int have = 0;
     HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");
     for (size_t i = 0; i < count; i++)
         if (ordinals[i] < 0 || ordinals[i] >= have) return fail(HS_ED25519_E_ARG, "hs_ed25519_init: no such device");
-    static ge_niels tab[HS_BTAB_ENTRIES];
-    make_base_table(tab, HS_BTAB_ENTRIES);
-    static fe tab4[HS_BTAB_ENTRIES][4];
-    make_base_table_quad(tab4, HS_BTAB_ENTRIES);
     std::vector<dev_state> devs(count);
     for (size_t i = 0; i < count; i++) {
         devs[i].ordinal = ordinals[i];
         HS_HIP(hipSetDevice(ordinals[i]), "hipSetDevice");
-        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab), tab, sizeof tab), "upload base-point table");
-        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_btab4), tab4, sizeof tab4), "upload base-point table (quad)");
+        // the base point's window tables (8-bit: key-cache layout, also the RLC path's; 16-bit: every verify kernel's [s]B)
+        int rc = build_base_tables(devs[i]);
+        if (rc) { for (size_t k = 0; k <= i; k++) free_base_tables(devs[k]); return rc; }
+        const u32 *b16 = devs[i].base_tab16;
+        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_b16), &b16, sizeof b16), "set the base-point table pointer");
         HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
         hipDeviceProp_t prop;
         HS_HIP(hipGetDeviceProperties(&prop, ordinals[i]), "hipGetDeviceProperties");
@@ -700,7 +795,7 @@ extern "C" void hs_ed25519_shutdown(void) {
             for (hs_ed25519_ctx *c : d.free_ctx[k]) hs_ed25519_ctx_destroy(c);
             d.free_ctx[k].clear(); d.live[k] = 0;
         }
-        if (d.base_tab) { (void)hipSetDevice(d.ordinal); (void)hipFree(d.base_tab); d.base_tab = nullptr; }
+        free_base_tables(d);
         // tickets still outstanding keep their group alive; its context is destroyed when they are waited on
     }
     g_devs.clear();
@@ -721,7 +816,7 @@ extern "C" size_t hs_ed25519_min_gpu_batch(int keys_registered) {
 static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     const int f = ctx ? ctx->kernel : HS_K_AUTO;
     if (f == HS_K_AUTO) return n <= kQuadMaxBatch ? HS_K_FUSED : HS_K_LANE;
-    return f;
+    return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
 }
 // diagnostics: how many workgroups of the fused kernel the runtime says fit one CU (LDS 20,480 B and ~250 VGPRs per wavefront)
 extern "C" int hs_ed25519_debug_fused_blocks_per_cu(void) {
@@ -731,6 +826,10 @@ extern "C" int hs_ed25519_debug_fused_blocks_per_cu(void) {
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
+extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
+    const int k = ctx ? ctx->kernel : HS_K_AUTO;
+    return k == HS_K_FUSED_PAIRS || (k == HS_K_AUTO && count >= g_pairs_min_batches.load()) ? "k_verify_fused_pairs_batches" : "k_verify_fused_batches";
+}
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) { return n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r"; }
 
 // One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's
@@ -844,6 +943,11 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     if (!ctx || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches: null context / list");
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // pairs form (two signatures per quad, 11 % less work, 1.85x a wavefront's latency) once the caller hands over
+    // enough batches per launch that the shorter form's extra wavefronts would only queue; HS_K_FUSED / HS_K_FUSED_PAIRS
+    // on the context force either
+    const bool pairs = ctx->kernel == HS_K_FUSED_PAIRS || (ctx->kernel == HS_K_AUTO && count >= g_pairs_min_batches.load());
+    const u32 per_block = pairs ? 32 : 16;
     size_t done = 0;
     while (done < count) {
         fused_batch_list L;
@@ -861,7 +965,7 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
             if (rc) return rc;
             f.pks = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap16 = (unsigned short *)b.d_bitmap;
             f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode; f.first_block = blocks; f.pad = 0;
-            blocks += (u32)(round_up(b.n, 64) / 16);
+            blocks += (u32)(round_up(b.n, 64) / per_block);
         }
         if (!L.count) continue;
         const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
@@ -869,8 +973,9 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
         hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
         if (ev) ctx->ev_mid[slot] = 0;
         void *a[] = { &L };
-        HS_HIP(launch1((const void *)k_verify_fused_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-               "launch k_verify_fused_batches");
+        HS_HIP(launch1(pairs ? (const void *)k_verify_fused_pairs_batches : (const void *)k_verify_fused_batches, dim3(blocks), dim3(64), a,
+                       st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               pairs ? "launch k_verify_fused_pairs_batches" : "launch k_verify_fused_batches");
     }
     return 0;
 }
@@ -884,7 +989,7 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
     u32 nkeys = (u32)ks->nkeys;
-    const u32 *p_bt = g_devs[ctx->slot].base_tab;
+    const u32 *p_bt = g_devs[ctx->slot].base_tab16;
     size_t done = 0;
     while (done < count) {
         cached_batch_list L;
@@ -997,24 +1102,9 @@ static int build_tables(u32 *d_tab, const u32 *d_axy, size_t nkeys, bool negate,
     if (!rc && es != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "table build", es);
     return rc;
 }
-static int ensure_base_table(int slot) {        // caller holds no lock; idempotent under g_mu
-    std::lock_guard<std::mutex> lk(g_mu);
+static int ensure_base_table(int slot) {        // the tables are built by hs_ed25519_init_devices; this only checks
     if (!g_init.load() || slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
-    dev_state &d = g_devs[slot];
-    if (d.base_tab) return 0;
-    HS_HIP(hipSetDevice(d.ordinal), "hipSetDevice");
-    ge_p3 b; ge_basepoint(b);
-    u32 h_axy[20];
-    for (int j = 0; j < 10; j++) { h_axy[j] = b.X.v[j]; h_axy[10 + j] = b.Y.v[j]; }
-    u32 *d_axy = nullptr, *d_tab = nullptr;
-    HS_HIP(hipMalloc((void **)&d_axy, sizeof h_axy), "hipMalloc");
-    HS_HIP(hipMalloc((void **)&d_tab, (size_t)HS_KS_KEY_WORDS * 4), "hipMalloc base table");
-    HS_HIP(hipMemcpy(d_axy, h_axy, sizeof h_axy, hipMemcpyHostToDevice), "H2D");
-    int rc = build_tables(d_tab, d_axy, 1, false, nullptr);
-    if (rc) return rc;
-    HS_HIP(hipDeviceSynchronize(), "base table build");
-    (void)hipFree(d_axy);
-    d.base_tab = d_tab;
+    if (!g_devs[slot].base_tab || !g_devs[slot].base_tab16) return fail(HS_ED25519_E_DEVICE, "the base point's tables are missing");
     return 0;
 }
 const u32 *hs::dev_base_table(int slot) {
@@ -1092,7 +1182,11 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
     const u32 np = (u32)round_up(n, 64);
     keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
     u32 nkeys = (u32)ks->nkeys, nn = (u32)n, mode_ = mode;
-    const u32 *p_bt = g_devs[ctx->slot].base_tab, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
+    // the default kernels read the base point's 16-bit table; the A/B variants below still take the 8-bit one
+    const u32 *p_bt = g_devs[ctx->slot].base_tab16, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
+#ifdef HS_AB_VARIANTS
+    if (ctx->kernel == 2 || ctx->kernel == 10 || ctx->kernel == 13) p_bt = g_devs[ctx->slot].base_tab;
+#endif
     unsigned short *p_bm = (unsigned short *)d_bitmap;
     u32 *p_nr = d_nreject;
     const u32 *p_skip = d_skip;

@@ -243,4 +243,16 @@ HS_HD void sc_recode256(u32 r[8], const u32 x[8]) {
     }
 }
 
+// Signed radix-65536 recoding for x < 2^253: r = x + 0x8000..8000; digit_i = halfword_i(r) - 32768
+// in [-32768, 32767] and sum digit_i 65536^i = x.
+HS_HD void sc_recode65536(u32 r[8], const u32 x[8]) {
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)x[i] + 0x80008000u + carry;
+        r[i] = (u32)t;
+        carry = t >> 32;
+    }
+}
+
 }  // namespace hs

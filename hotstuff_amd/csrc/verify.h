@@ -5,7 +5,7 @@
 //                            k = SHA-512(R||A||M) mod L, range-checks s and recodes both scalars.
 //   stage 2  verify_lane   : one lane per signature; [k](-A) + [s]B by a joint
 //                            fixed-window double-scalar multiplication (signed radix 16 on -A,
-//                            signed radix 256 on B from a 129-entry L2-resident table)
+//                            signed radix 65536 on B from the 32,769-entry table of verify_cached.h)
 //                            - lane-uniform control flow, table entries chosen per lane -
 //                            then the projective comparison with R.
 //
@@ -47,7 +47,7 @@ HS_HD void prepare_point(const workspace &ws, u32 i, bool is_r, const u32 *pk, c
     for (int j = 0; j < 8; j++) enc[j] = is_r ? sig[j] : pk[j];
     ge_p3 p;
     u32 fl = ge_decompress(p, enc) ? HS_F_ONCURVE : 0;
-    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order_affine(p.Y) ? HS_F_SMALL : 0;
     const u32 slot = is_r ? 1u : 0u;
     u32 *row = ws.pt + (size_t)slot * 20 * ws.np + i;
 #pragma unroll
@@ -85,7 +85,14 @@ HS_HD int sc_pop_digit8(u32 w[8]) {
     w[0] <<= 8;
     return d;
 }
-#define HS_BTAB_ENTRIES 129   // j*B, j = 0..128: 8-bit signed windows for the base point
+// take the top half-word of a 256-bit radix-65536 recoded scalar as a signed digit and shift left by 16
+HS_HD int sc_pop_digit16(u32 w[8]) {
+    const int d = (int)(w[7] >> 16) - 32768;
+#pragma unroll
+    for (int j = 7; j > 0; j--) w[j] = (w[j] << 16) | (w[j - 1] >> 16);
+    w[0] <<= 16;
+    return d;
+}
 
 // acc == (rx, ry) as points:  X == x_R Z  and  Y == y_R Z  and  Z != 0.
 // The complete formulas never produce Z = 0, so the last test changes no verdict; it makes the
@@ -99,8 +106,22 @@ HS_HD bool ge_match_point(ge_p3 acc, const fe &rx, const fe &ry) {
     return fe_eq(a, acc.X) && fe_eq(b, acc.Y) && !fe_iszero(acc.Z);
 }
 
-// btab: HS_BTAB_ENTRIES affine Niels entries j*B (entry 0 = identity), L2-resident.
-HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *btab) {
+// one stored table entry (y-x, y+x, 2dxy; 32 words = one 128-byte line, verify_cached.h) as an affine Niels point
+HS_HD void ge_load_niels(ge_niels &n, const u32 *entry) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    const uint4 *q = reinterpret_cast<const uint4 *>(entry);
+    u32 w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#else
+    const u32 *w = entry;
+#endif
+#pragma unroll
+    for (int i = 0; i < 10; i++) { n.ymx.v[i] = w[i]; n.ypx.v[i] = w[10 + i]; n.xy2d.v[i] = w[20 + i]; }
+}
+// b16: window 0 of the base point's 16-bit table (verify_cached.h): entry j = j B, j <= 32,768, 128 bytes each,
+// L2 / MALL-resident - one addition per 16 doublings for [s]B.
+HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
     bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
@@ -122,6 +143,11 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *bta
     u32 kw[8], sw[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
+    {   // stage 1 stored s + 0x80..80 (radix 256); 16-bit windows want s + 0x8000..8000: subtract 0x0080..0080
+        u64 borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 t = (u64)sw[j] - 0x00800080u - borrow; sw[j] = (u32)t; borrow = (t >> 32) & 1; }
+    }
 
     // per-lane table j * (-A), j = 0..8, in private memory (indexed per lane below)
     ge_cached atab[9];
@@ -143,19 +169,21 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const ge_niels *bta
 #pragma nounroll
     for (int w = 0; w < 64; w++) {
         ge_p1p1 t;
+        const int nd = w ? 4 : 0;       // the accumulator is still the identity in the first window
 #pragma nounroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < nd; d++) {
             ge_dbl(t, acc);
             ge_p1p1_to_p3(acc, t, d == 3);
         }
         const int dk = sc_pop_digit(kw);
         const int ik = dk < 0 ? -dk : dk;
         ge_add(t, acc, atab[ik], dk < 0);
-        if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
+        if ((w & 3) == 3) {     // [s]B: one 16-bit window per four 4-bit windows of k
             ge_p1p1_to_p3(acc, t, true);
-            const int ds = sc_pop_digit8(sw);
-            const int is = ds < 0 ? -ds : ds;
-            ge_madd(t, acc, btab[is], ds < 0);
+            const int ds = sc_pop_digit16(sw);
+            ge_niels eb;
+            ge_load_niels(eb, b16 + (size_t)(ds < 0 ? -ds : ds) * 32);
+            ge_madd(t, acc, eb, ds < 0);
         }
         ge_p1p1_to_p3(acc, t, false);
     }
@@ -175,20 +203,4 @@ HS_HD void ge_basepoint(ge_p3 &b) {
     const u32 bx[10] = FE26_BX, by[10] = FE26_BY, bt[10] = FE26_BT;
     b.X = fe_const(bx); b.Y = fe_const(by); fe_1(b.Z); b.T = fe_const(bt);
 }
-// tab[j] = j*B for j = 0..count-1
-inline void make_base_table(ge_niels *tab, int count) {
-    ge_p3 b, p;
-    ge_basepoint(b);
-    ge_cached bc;
-    ge_to_cached(bc, b);
-    fe_1(tab[0].ypx); fe_1(tab[0].ymx); fe_0(tab[0].xy2d);
-    p = b;
-    for (int j = 1; j < count; j++) {
-        ge_p3_to_niels(tab[j], p);
-        ge_p1p1 t;
-        ge_add(t, p, bc, false);
-        ge_p1p1_to_p3(p, t, true);
-    }
-}
-
 }  // namespace hs

@@ -38,6 +38,17 @@ namespace hs {
 #define HS_KS_PROJ_WORDS 40                                    // registration scratch: projective (Y-X, Y+X, 2dT, 2Z), 4 lanes x 10 limbs
 #define HS_KS_KEY_PROJ_WORDS (HS_KS_WINDOWS * HS_KS_ENTRIES * HS_KS_PROJ_WORDS)
 
+// The base point's half of the sum uses 16-bit windows: B is one fixed point, so its table may be as large as pays -
+//      [s]B = sum_w T_B16[w][s_w],   T_B16[w][j] = j * 2^(16w) * B,   w < 16, j <= 32,768
+// 16 additions instead of 32 for 16 x 32,769 x 128 bytes = 67 MB per GPU (MALL-resident; the per-key tables cannot
+// grow the same way: 528 KB per key already).  A verification against a registered key is then 32 + 16 = 48 table
+// additions.  The table is built on the device from the 8-bit one: j = 256 hi + lo with lo in [-127, 128], so
+// T_B16[w][j] = T_B[2w + 1][hi] +- T_B[2w][|lo|] - one addition per entry, then the shared-inversion normalisation.
+#define HS_B16_WINDOWS 16
+#define HS_B16_ENTRIES 32769
+#define HS_B16_WORDS ((size_t)HS_B16_WINDOWS * HS_B16_ENTRIES * HS_KS_ENTRY_WORDS)
+static_assert((HS_B16_WINDOWS * HS_B16_ENTRIES) % 8 == 0, "the 16-bit base table is normalised in groups of eight entries");
+
 // per-key header written by the registration pass
 struct keyset_view {
     const u32 *tab;      // [key][window][entry][32 words]
@@ -58,17 +69,6 @@ HS_Q bool q_quad_all(const qflags &f) {       // all four lanes set, uniform ove
     const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true), b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
     const int c = __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true), d = __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true);
     return a && b && c && d;
-}
-HS_Q qv q_load_entry(const u32 *entry) {      // this lane's coordinate of an affine entry: lanes 0-2 read, lane 3 is the constant 2Z = 2
-    const u32 l = q_lane();
-    const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * (l < 3 ? l : 2));
-    u32 m = l < 3 ? 0xffffffffu : 0u;
-    asm volatile("" : "+v"(m));              // a mask (v_and / v_bfi), not a VCC select
-    qv r;
-#pragma unroll
-    for (int i = 0; i < 5; i++) { const uint2 v = p[i]; r.v[2 * i] = v.x & m; r.v[2 * i + 1] = v.y & m; }
-    r.v[0] |= 2u & ~m;
-    return r;
 }
 HS_Q void q_store_entry(u32 *entry, const qv &e) {      // a PROJECTIVE entry of the registration scratch (40 words)
     uint2 *p = reinterpret_cast<uint2 *>(entry + 10 * q_lane());
@@ -103,10 +103,6 @@ HS_Q qflags q_identity_lanes(const qv &p) {
 HS_Q qv q_invert(const qv &z) { qv r; for (int i = 0; i < 4; i++) fe_invert(r.l[i], z.l[i]); return r; }
 HS_Q bool q_quad_and01(const qflags &f) { return f.f[0] && f.f[1]; }
 HS_Q bool q_quad_all(const qflags &f) { return f.f[0] && f.f[1] && f.f[2] && f.f[3]; }
-HS_Q qv q_load_entry(const u32 *entry) {
-    qv r; for (int l = 0; l < 3; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i];
-    r.l[3] = fe_small(2); return r;
-}
 HS_Q void q_store_entry(u32 *entry, const qv &e) {
     for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) entry[10 * l + i] = e.l[l].v[i];
 }
@@ -287,6 +283,41 @@ HS_HD void cached_chain(ge_p3 &acc, const u32 *tab, u32 dw[8]) {
         ge_add_tab(acc, acc, e, d < 0);
     }
 }
+// sum_w T_B16[w][d_w] over the 16 windows of the base point's 16-bit table and a radix-65536 recoded scalar
+HS_HD void cached_chain16(ge_p3 &acc, const u32 *b16, u32 dw[8]) {
+    ge_identity(acc);
+#pragma nounroll
+    for (int w = HS_B16_WINDOWS - 1; w >= 0; w--) {
+        const int d = sc_pop_digit16(dw);
+        const int id = d < 0 ? -d : d;
+        tab_entry e;
+        load_tab_entry(e, b16 + ((size_t)w * HS_B16_ENTRIES + id) * HS_KS_ENTRY_WORDS);
+        ge_add_tab(acc, acc, e, d < 0);
+    }
+}
+// Entry j of window w of the 16-bit base table, PROJECTIVE (Y-X, Y+X, 2dT, 2Z; 40 words - what keyset_affine_group
+// normalises), from the 8-bit table t8 of +B: the stored affine entry (y-x, y+x, 2dxy) of 2^(8(2w+1)) hi B becomes the
+// extended point (2x, 2y, 2, 2xy) - 2xy = 2dxy / d - and the entry of 2^(16w) |lo| B is added to or subtracted from it.
+HS_HD void base16_entry_projective(u32 *out /* 40 words */, const u32 *t8, u32 w, u32 j) {
+    u32 hi = j >> 8;
+    int lo = (int)(j & 255u);
+    if (lo > 128) { lo -= 256; hi += 1; }           // j <= 32,768, so hi <= 128 either way
+    tab_entry eh, el;
+    load_tab_entry(eh, t8 + ((size_t)(2 * w + 1) * HS_KS_ENTRIES + hi) * HS_KS_ENTRY_WORDS);
+    load_tab_entry(el, t8 + ((size_t)(2 * w) * HS_KS_ENTRIES + (u32)(lo < 0 ? -lo : lo)) * HS_KS_ENTRY_WORDS);
+    ge_p3 p, r;
+    fe_sub(p.X, eh.ypx, eh.ymx); fe_carry(p.X);
+    fe_add(p.Y, eh.ypx, eh.ymx); fe_carry(p.Y);
+    p.Z = fe_small(2);
+    const u32 dinv[10] = FE26_DINV;
+    fe_mul(p.T, eh.t2d, fe_const(dinv));
+    ge_add_tab(r, p, el, lo < 0);
+    ge_cached c;
+    ge_to_cached(c, r);
+    fe z2; fe_add(z2, c.Z, c.Z); fe_carry(z2);
+#pragma unroll
+    for (int i = 0; i < 10; i++) { out[i] = c.YmX.v[i]; out[10 + i] = c.YpX.v[i]; out[20 + i] = c.T2d.v[i]; out[30 + i] = z2.v[i]; }
+}
 // The check of R' = (X:Y:Z:T) against R's encoding (and the strict small-order test).
 HS_HD bool cached_finish(const ge_p3 &acc, const u32 renc[8], bool strict) {
     bool ok = true;
@@ -315,10 +346,11 @@ HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {
     ge_p1p1_to_p3(r, t, true);
 }
 // The curve part of one cached verification on ONE lane (both chains serially).
-HS_HD bool verify_cached_lane(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
+// b16: the base point's 16-bit table; sw: s recoded in radix 65536 (kw: k in radix 256) - 32 + 16 additions.
+HS_HD bool verify_cached_lane(const u32 *atab, const u32 *b16, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
     ge_p3 pa, pb, acc;
     cached_chain(pa, atab, kw);
-    cached_chain(pb, btab, sw);
+    cached_chain16(pb, b16, sw);
     ge_add_p3(acc, pa, pb);
     return cached_finish(acc, renc, strict);
 }
@@ -340,15 +372,49 @@ HS_Q bool verify_cached_lane2(const u32 *atab, const u32 *btab, u32 kw[8], u32 s
     ge_add_p3(acc, mine, other);          // both lanes of the pair now hold R' (addition commutes)
     return cached_finish(acc, renc, strict);
 }
-// The same chains, returning R' for a projective comparison against an R decompressed elsewhere.
-HS_Q void cached_lane2_chain(ge_p3 &acc, const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8]) {
-    const bool odd = threadIdx.x & 1u;
-    const u32 *tab = odd ? btab : atab;
-    u32 dw[8];
+#endif
+// The default two-lane form: the 32 + 16 additions of one signature split EVENLY, 24 per lane, returning R' for a
+// projective comparison against an R decompressed elsewhere.  The even lane sums the key's windows 31..8; the odd
+// lane the key's windows 7..0 and then the base point's sixteen 16-bit windows.  One instruction stream: every step
+// is "pop a digit, gather one 128-byte entry, add" with a per-lane table pointer, window stride and digit source.
+// kw: k recoded in radix 256, sw: s recoded in radix 65536 (both uniform over the pair).
+struct lane2_split { u32 d8[8], d16[8]; };
+// this lane's digit words: even = k as is (its top 24 digits are used), odd = k shifted up by 24 digits (its low 8
+// digits first) and s
+HS_HD void lane2_split_init(lane2_split &ls, const u32 kw[8], const u32 sw[8], bool odd) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) dw[i] = odd ? sw[i] : kw[i];
+    for (int i = 0; i < 8; i++) { ls.d8[i] = odd ? (i >= 6 ? kw[i - 6] : 0u) : kw[i]; ls.d16[i] = sw[i]; }
+}
+// step t = 0..23 of a lane's chain: the entry to add and its sign
+HS_HD const u32 *lane2_split_step(lane2_split &ls, int t, bool odd, const u32 *atab, const u32 *b16, bool &neg) {
+    const int d8 = sc_pop_digit8(ls.d8);
+    int d = d8;
+    size_t row = (size_t)((odd ? 7 : 31) - t) * HS_KS_ENTRIES;       // the key's window 31 - t (even) or 7 - t (odd, t < 8)
+    const u32 *tab = atab;
+    if (t >= 8) {                                                     // uniform over the wavefront
+        const int d16 = sc_pop_digit16(ls.d16);
+        if (odd) { d = d16; row = (size_t)(23 - t) * HS_B16_ENTRIES; tab = b16; }
+    }
+    neg = d < 0;
+    return tab + (row + (size_t)(d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS;
+}
+HS_HD void lane2_split_chain(ge_p3 &mine, const u32 *atab, const u32 *b16, const u32 kw[8], const u32 sw[8], bool odd) {
+    lane2_split ls;
+    lane2_split_init(ls, kw, sw, odd);
+    ge_identity(mine);
+#pragma nounroll
+    for (int t = 0; t < 24; t++) {
+        bool neg;
+        const u32 *p = lane2_split_step(ls, t, odd, atab, b16, neg);
+        tab_entry e;
+        load_tab_entry(e, p);
+        ge_add_tab(mine, mine, e, neg);
+    }
+}
+#if defined(__HIPCC__)
+HS_Q void cached_lane2_chain(ge_p3 &acc, const u32 *atab, const u32 *b16, u32 kw[8], u32 sw[8]) {
     ge_p3 mine, other;
-    cached_chain(mine, tab, dw);
+    lane2_split_chain(mine, atab, b16, kw, sw, (threadIdx.x & 1u) != 0);
     other.X = q_perm<1, 0, 3, 2>(mine.X); other.Y = q_perm<1, 0, 3, 2>(mine.Y);
     other.Z = q_perm<1, 0, 3, 2>(mine.Z); other.T = q_perm<1, 0, 3, 2>(mine.T);
     ge_add_p3(acc, mine, other);

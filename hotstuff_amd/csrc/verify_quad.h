@@ -149,6 +149,29 @@ HS_Q qflags q_eq_nz(const qv &a, const qv &b_reduced) {
 
 HS_HD fe fe_small(u32 c) { fe r; fe_0(r); r.v[0] = c; return r; }
 
+// A stored table entry: the AFFINE Niels point (y-x, y+x, 2dxy) in 32 words = 128 bytes = one cache line
+// (verify_cached.h builds the tables).  As a quad operand it is (y-x, y+x, 2dxy, 2): lanes 0-2 read their ten
+// limbs, lane 3 takes the constant 2Z = 2.
+#define HS_ENTRY_WORDS 32
+#if defined(__HIPCC__)
+HS_Q qv q_load_entry(const u32 *entry) {
+    const u32 l = q_lane();
+    const uint2 *p = reinterpret_cast<const uint2 *>(entry + 10 * (l < 3 ? l : 2));
+    u32 m = l < 3 ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));              // a mask (v_and / v_bfi), not a VCC select
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const uint2 v = p[i]; r.v[2 * i] = v.x & m; r.v[2 * i + 1] = v.y & m; }
+    r.v[0] |= 2u & ~m;
+    return r;
+}
+#else
+HS_Q qv q_load_entry(const u32 *entry) {
+    qv r; for (int l = 0; l < 3; l++) for (int i = 0; i < 10; i++) r.l[l].v[i] = entry[10 * l + i];
+    r.l[3] = fe_small(2); return r;
+}
+#endif
+
 // The per-signature table j*(-A), j = 1..8 (digit 0 takes the identity from a constant).  On the
 // GPU it lives in LDS, one 20,480-byte slab per wavefront laid out [entry][limb][lane]: whatever
 // entry each quad picks, the 32 lanes of a half-wave hit 32 different banks (bank = lane mod 32),
@@ -243,11 +266,13 @@ HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
 // The quad stage-2 core.  ax, ay, rx, ry (affine A and R) and the recoded scalars are uniform
 // across the four lanes of a quad.  atab entries are per lane: on the GPU each lane keeps its
 // own component in private memory.
-// btab: [HS_BTAB_ENTRIES][4] cached multiples j*B, lane order (Y-X, Y+X, 2dT, 2Z), L2-resident.
+// b16: window 0 of the base point's 16-bit table (verify_cached.h): entry j = the affine Niels form of j B, j <= 32,768,
+// 128 bytes each (4.2 MB, L2 / MALL-resident) - [s]B costs 16 additions, one per 16 doublings, where 8-bit windows and
+// a 129-entry table cost 32.  kw: k in signed radix 16, sw: s in signed radix 65536.
 // Returns, per lane, whether this lane's coordinate check passed (lanes 2, 3: always true);
 // the caller ANDs the four lanes of the quad with the signature-level flags.
 HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, u32 kw[8], u32 sw[8],
-                             const fe (*btab)[4], qtab &atab) {
+                             const u32 *b16, qtab &atab) {
     // -A = (-x, y, 1, -xy): one vector multiplication (-x, y, 1, -x) * (1, 1, 1, y)
     fe nax; fe_neg(nax, ax);
     qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
@@ -265,25 +290,28 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
 
     qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
 #pragma nounroll
-    for (int w = 0; w < 64; w++) {
+    for (int g = 0; g < 16; g++) {
+        // [s]B: one 16-bit window per four 4-bit windows of k; its entry is fetched now and added 16 doublings later
+        const int ds = sc_pop_digit16(sw);
+        const qv eb = q_load_entry(b16 + (size_t)(ds < 0 ? -ds : ds) * HS_ENTRY_WORDS);
 #pragma nounroll
-        for (int d = 0; d < 4; d++) acc = q_dbl(acc);
-        const int dk = sc_pop_digit(kw);
-        const int ik = dk < 0 ? -dk : dk;
-        const qv ea = qtab_pick(atab, ik);
-        acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
-        if (w & 1) {        // [s]B: one 8-bit window per two 4-bit windows of k
-            const int ds = sc_pop_digit8(sw);
-            const int is = ds < 0 ? -ds : ds;
-            const qv eb = q_load(btab, is);
-            acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
+        for (int w = 0; w < 4; w++) {
+            // the accumulator is still the identity in the very first window: its four doublings are skipped
+            const int nd = (g | w) ? 4 : 0;
+#pragma nounroll
+            for (int d = 0; d < nd; d++) acc = q_dbl(acc);
+            const int dk = sc_pop_digit(kw);
+            const int ik = dk < 0 ? -dk : dk;
+            const qv ea = qtab_pick(atab, ik);
+            acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
         }
+        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
     }
     return q_match_point(acc, rx, ry);
 }
 
 // stage 2 reading the workspace written by k_prepare
-HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4], bool &flags_ok, qtab &atab) {
+HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const u32 *b16, bool &flags_ok, qtab &atab) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
     bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
@@ -300,21 +328,28 @@ HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const fe (*btab)[4
     u32 kw[8], sw[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
-    return verify_quad_core(ax, ay, rx, ry, kw, sw, btab, atab);
+    {   // stage 1 stored s + 0x80..80 (radix 256); the core wants s + 0x8000..8000 (radix 65536): subtract 0x0080..0080
+        u64 borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 t = (u64)sw[j] - 0x00800080u - borrow; sw[j] = (u32)t; borrow = (t >> 32) & 1; }
+    }
+    return verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
 }
 
 // The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
 // computes it redundantly so no lane diverges.  Returns s < L.
 // k is recoded in signed radix 16 (cold path: 4-bit windows on -A) or, with k_radix256, in
 // signed radix 256 (cached path: 8-bit windows on both points).
-HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, const u32 *msg, bool k_radix256 = false) {
+// s is recoded in signed radix 256 or, with s_radix65536, in signed radix 65536 (the base point's 16-bit table).
+HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, const u32 *msg, bool k_radix256 = false,
+                           bool s_radix65536 = false) {
     u32 in[24], h[16], k[8], s[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
     sha512_96(h, in);
     sc_reduce512(k, h);
     if (k_radix256) sc_recode256(kw, k); else sc_recode16(kw, k);
-    sc_recode256(sw, s);
+    if (s_radix65536) sc_recode65536(sw, s); else sc_recode256(sw, s);
     return sc_is_canonical(s);
 }
 
@@ -322,43 +357,68 @@ HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, 
 // Fused stage 1 + stage 2 for one quad: lane 1 decompresses R, the other lanes decompress A
 // (one shared instruction stream), everybody hashes, DPP broadcasts hand A to the whole
 // quad, then the core.  One launch per batch and no workspace traffic.
-HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const fe (*btab)[4], qtab &atab) {
+HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const u32 *b16, qtab &atab) {
     const u32 lane = q_lane();
     u32 enc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) enc[j] = lane == 1 ? sig[j] : pk[j];
     ge_p3 pt;
     u32 fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
-    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order(pt) ? HS_F_SMALL : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
     const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
     const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
     u32 kw[8], sw[8];
-    bool ok = prepare_scalars(kw, sw, pk, sig, msg);
+    bool ok = prepare_scalars(kw, sw, pk, sig, msg, false, true);
     ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, btab, atab);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
+    return f.f && ok;
+}
+
+// Throughput form: TWO signatures per quad, one after the other.  In verify_quad_fused lanes 2, 3 of every quad only
+// shadow lane 0 through the decompression - a 251-squaring chain that is a fifth of the kernel's multiply-adds.  Here
+// the four lanes decompress A, R of the quad's first signature and A, R of its second at once (one instruction stream,
+// all lanes useful), then the quad runs the window loop twice: 11 % fewer multiply-adds per verification, 1.85x the
+// latency of a wavefront (which now carries 32 signatures).  Used where the caller hands over enough batches per
+// launch to fill the chip anyway (hs_ed25519_verify_device_batches).
+struct quad_pair_points { fe X, Y; u32 fl; };
+// lane 0: A of signature j0, lane 1: R of j0, lane 2: A of j1, lane 3: R of j1
+HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, u32 j0, u32 j1, u32 mode) {
+    const u32 lane = q_lane();
+    const u32 j = (lane & 2) ? j1 : j0;
+    const u32 *src = (lane & 1) ? sigs + (size_t)16 * j : pks + (size_t)8 * j;
+    u32 enc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) enc[t] = src[t];
+    ge_p3 pt;
+    quad_pair_points r;
+    r.fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
+    if (mode & HS_MODE_STRICT) r.fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
+    r.X = pt.X; r.Y = pt.Y;
+    return r;
+}
+// pass h (0 / 1, uniform over the wavefront) over signature j = j0 / j1
+HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, const u32 *pk, const u32 *sig, const u32 *msg, u32 mode,
+                         const u32 *b16, qtab &atab) {
+    fe sx = pp.X, sy = pp.Y;
+    u32 sf = pp.fl;
+    if (h) {        // bring lanes 2, 3 down to lanes 0, 1
+        sx = q_perm<2, 3, 2, 3>(pp.X); sy = q_perm<2, 3, 2, 3>(pp.Y);
+        sf = (u32)__builtin_amdgcn_mov_dpp((int)pp.fl, HS_QP(2, 3, 2, 3), 0xf, 0xf, true);
+    }
+    const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x00, 0xf, 0xf, true);
+    const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x55, 0xf, 0xf, true);
+    u32 kw[8], sw[8];
+    bool ok = prepare_scalars(kw, sw, pk, sig, msg, false, true);
+    ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+    const fe ax = q_perm<0, 0, 0, 0>(sx), ay = q_perm<0, 0, 0, 0>(sy);
+    const fe rx = q_perm<1, 1, 1, 1>(sx), ry = q_perm<1, 1, 1, 1>(sy);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
     return f.f && ok;
 }
 #endif
-
-// cached multiples of the base point for the quad kernel: tab[j][lane], j = 0..count-1
-inline void make_base_table_quad(fe (*tab)[4], int count) {
-    ge_p3 b, p;
-    ge_basepoint(b);
-    ge_cached bc;
-    ge_to_cached(bc, b);
-    tab[0][0] = fe_small(1); tab[0][1] = fe_small(1); tab[0][2] = fe_small(0); tab[0][3] = fe_small(2);
-    p = b;
-    for (int j = 1; j < count; j++) {
-        ge_niels n;
-        ge_p3_to_niels(n, p);
-        tab[j][0] = n.ymx; tab[j][1] = n.ypx; tab[j][2] = n.xy2d; tab[j][3] = fe_small(2);
-        ge_p1p1 t;
-        ge_add(t, p, bc, false);
-        ge_p1p1_to_p3(p, t, true);
-    }
-}
 
 }  // namespace hs

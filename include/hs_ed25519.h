@@ -149,7 +149,11 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
 /* Several INDEPENDENT small batches in one launch (up to 16 per grid; longer lists are cut into several
  * launches): a node under load has many certificates pending, and a 1,024-signature batch alone is only one
  * wavefront per SIMD of the slice of the chip its stream runs on.  Every batch keeps its own digests, bitmap and reject counter;
- * n <= 32,768 and mode BATCH or STRICT for each.  Pointer rules as for hs_ed25519_verify_device. */
+ * n <= 32,768 and mode BATCH or STRICT for each.  Pointer rules as for hs_ed25519_verify_device.
+ * From four batches per call on, the library runs the PAIRS form of the kernel (k_verify_fused_pairs_batches: every
+ * quad of lanes verifies two signatures one after the other, so the four lanes decompress A, R of both at once instead
+ * of two of them idling - 11 % less arithmetic per verification, 1.85x the latency of a launch); below, latency wins
+ * and the one-signature-per-quad form runs.  Same accept set. */
 typedef struct hs_ed25519_batch {
     const uint8_t *d_digests; size_t digest_stride;
     const uint8_t *d_pks, *d_sigs;
@@ -262,7 +266,8 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
  * the default): 0 = by batch size (cold: fused 4-lanes-per-signature kernel up to 32,768
  * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 98,304, the
  * one-lane kernel above), 1 = the one-lane-per-signature kernels, 3 = the fused / two-lane
- * kernels at any size.  All have the same accept set.  Returns the previous choice or
+ * kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
+ * the batch count (3 pins it to the one-signature-per-quad form).  All have the same accept set.  Returns the previous choice or
  * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
  * with -DHS_AB_VARIANTS and are not part of the shipped library.) */
 int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
@@ -271,6 +276,7 @@ int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 const char *hs_ed25519_cached_kernel_for(size_t n);        /* for an n-signature key-cache call */
+const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count);   /* hs_ed25519_verify_device_batches of `count` batches */
 
 /* ---- one call over several GPUs (BASELINE configs[3]: a 100,000-validator QC on 8 x MI355X) ----
  * After hs_ed25519_init_devices with k slots these cut the batch into k contiguous shards of

@@ -65,9 +65,11 @@ void emu_sc_digits(const uint8_t *s, int8_t *digits) {
 int emu_decompress(const uint8_t *s, uint8_t *x, uint8_t *y, int *small) {
     u32 w[8], wx[8], wy[8]; load_words(w, s, 8); ge_p3 p; bool ok = ge_decompress(p, w);
     fe_to_words(wx, p.X); fe_to_words(wy, p.Y); memcpy(x, wx, 32); memcpy(y, wy, 32);
-    *small = ok ? ge_is_small_order(p) : 0;
+    // bit 0: the canonical-y comparison the kernels use after a decompression; bit 1: [8]P == O by three doublings
+    *small = ok ? (int)ge_is_small_order_affine(p.Y) | ((int)ge_is_small_order(p) << 1) : 0;
     return ok;
 }
+const uint32_t *emu_base16(void);
 // out[i] = per-signature verdict.  msg_stride = 0 (shared digest) or 32.
 void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
                 uint32_t mode, uint8_t *out) {
@@ -75,7 +77,7 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
     workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
-    static ge_niels btab[HS_BTAB_ENTRIES]; make_base_table(btab, HS_BTAB_ENTRIES);
+    const u32 *btab = emu_base16();
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
         u32 pk[8], sig[16], msg[8];
@@ -84,6 +86,7 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
     }
     for (size_t i = 0; i < n; i++) out[i] = verify_lane(ws, (u32)i, mode, btab) ? 1 : 0;
 }
+const uint32_t *emu_base16(void);
 // the quad (4 lanes per signature) stage 2, same stage 1
 void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
                      uint32_t mode, uint8_t *out) {
@@ -91,7 +94,7 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
     workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
-    static fe btab[HS_BTAB_ENTRIES][4]; make_base_table_quad(btab, HS_BTAB_ENTRIES);
+    const u32 *btab = emu_base16();        // window 0 of the base point's 16-bit table: j B, j <= 32,768
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
         u32 pk[8], sig[16], msg[8];
@@ -200,7 +203,7 @@ void emu_keyset_build(const uint8_t *pks, size_t nkeys, uint32_t *tab, uint32_t 
     for (size_t k = 0; k < nkeys; k++) {
         u32 w[8]; load_words(w, pks + 32 * k, 8);
         ge_p3 p; u32 fl = ge_decompress(p, w) ? HS_F_ONCURVE : 0;
-        fl |= ge_is_small_order(p) ? HS_F_SMALL : 0;
+        fl |= ge_is_small_order_affine(p.Y) ? HS_F_SMALL : 0;
         flag[k] = fl;
         for (int win = 0; win < HS_KS_WINDOWS; win++) {
             std::vector<u32> proj((size_t)HS_KS_ENTRIES * HS_KS_PROJ_WORDS);
@@ -219,6 +222,41 @@ void emu_keyset_build_base(uint32_t *tab) {
         affine_window_batch(dst, proj.data());
     }
 }
+// The base point's 16-bit table from its 8-bit one (what k_base16_build + k_keyset_affine do on the device).
+size_t emu_base16_words(void) { return HS_B16_WORDS; }
+void emu_base16_build(const uint32_t *t8, uint32_t *b16) {
+    const size_t entries = (size_t)HS_B16_WINDOWS * HS_B16_ENTRIES;
+    u32 proj[HS_KS_AFFINE_GROUP * HS_KS_PROJ_WORDS];
+    for (size_t g = 0; g < entries / HS_KS_AFFINE_GROUP; g++) {
+        for (int t = 0; t < HS_KS_AFFINE_GROUP; t++) {
+            const size_t e = g * HS_KS_AFFINE_GROUP + t;
+            base16_entry_projective(proj + (size_t)t * HS_KS_PROJ_WORDS, t8, (u32)(e / HS_B16_ENTRIES), (u32)(e % HS_B16_ENTRIES));
+        }
+        keyset_affine_group(b16 + g * (HS_KS_AFFINE_GROUP * HS_KS_ENTRY_WORDS), proj);
+    }
+}
+static const uint32_t *g_b16 = nullptr;
+void emu_set_base16(const uint32_t *b16) { g_b16 = b16; }
+void emu_keyset_build_base(uint32_t *tab);
+// the table the verification paths below read: the one a test handed over, or one built here on first use
+const uint32_t *emu_base16(void) {
+    if (!g_b16) {
+        static std::vector<u32> t8((size_t)HS_KS_KEY_WORDS), b16(HS_B16_WORDS);
+        emu_keyset_build_base(t8.data());
+        emu_base16_build(t8.data(), b16.data());
+        g_b16 = b16.data();
+    }
+    return g_b16;
+}
+// canonical (y-x, y+x, 2dxy) of a stored 128-byte entry as 96 bytes
+void emu_entry_canonical(const uint32_t *entry, uint8_t *out96) {
+    for (int c = 0; c < 3; c++) { fe f; for (int i = 0; i < 10; i++) f.v[i] = entry[10 * c + i]; u32 w[8]; fe_to_words(w, f); memcpy(out96 + 32 * c, w, 32); }
+}
+// signed radix-65536 digits, most significant first
+void emu_sc_digits16(const uint8_t *s, int32_t *digits) {
+    u32 w[8], r[8]; load_words(w, s, 8); sc_recode65536(r, w);
+    for (int i = 0; i < 16; i++) digits[i] = sc_pop_digit16(r);
+}
 // lane_form = 1: the one-lane-per-signature core (verify_cached_lane), 0: the quad core
 static int g_cached_lane_form = 0;
 void emu_cached_set_lane_form(int v) { g_cached_lane_form = v; }
@@ -230,25 +268,28 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
         if (ki >= nkeys) { out[i] = 0; continue; }
         u32 pk[8], sig[16], msg[8], kw[8], sw[8];
         load_words(pk, pks + 32 * ki, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
-        bool ok = prepare_scalars(kw, sw, pk, sig, msg, true);
+        // forms 1 and 3 are the shipped kernels: s in radix 65536 against the base point's 16-bit table (emu_set_base16)
+        const bool s16 = g_cached_lane_form == 1 || g_cached_lane_form == 3;
+        bool ok = prepare_scalars(kw, sw, pk, sig, msg, true, s16);
+        if (s16) (void)emu_base16();
         const u32 fl = flag[ki];
         ok = ok && (fl & HS_F_ONCURVE);
         if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
         const bool strict = (mode & HS_MODE_STRICT) != 0;
         bool curve;
         if (g_cached_lane_form == 1) {
-            curve = verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw, sig, strict);
+            curve = verify_cached_lane(tab + ki * (size_t)HS_KS_KEY_WORDS, g_b16, kw, sw, sig, strict);
         } else if (g_cached_lane_form == 3) {      // one-lane chains + R decompressed separately (k_verify_cached_lane2r)
             ge_p3 R; u32 rf = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
-            if (strict) rf |= ge_is_small_order(R) ? HS_F_SMALL : 0;
-            ge_p3 pa, pb, acc;
-            cached_chain(pa, tab + ki * (size_t)HS_KS_KEY_WORDS, kw);
-            cached_chain(pb, btab, sw);
+            if (strict) rf |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0;
+            ge_p3 pa, pb, acc;      // the pair's two lanes: 24 additions each (lane2_split_chain), then the join
+            lane2_split_chain(pa, tab + ki * (size_t)HS_KS_KEY_WORDS, g_b16, kw, sw, false);
+            lane2_split_chain(pb, tab + ki * (size_t)HS_KS_KEY_WORDS, g_b16, kw, sw, true);
             ge_add_p3(acc, pa, pb);
             curve = cached_lane_match_point(acc, R.X, R.Y, rf, strict);
         } else if (g_cached_lane_form == 2) {      // chain + R decompressed separately (the 5-wavefront kernel)
             ge_p3 R; u32 rf = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
-            if (strict) rf |= ge_is_small_order(R) ? HS_F_SMALL : 0;
+            if (strict) rf |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0;
             const qv acc = cached_quad_chain(tab + ki * (size_t)HS_KS_KEY_WORDS, btab, kw, sw);
             curve = cached_quad_match_point(acc, R.X, R.Y, rf, strict);
         } else {

@@ -102,13 +102,27 @@ def test_decompress_matches_dalek_rules(emu, edge_vectors):
     x, y, sm = B(32), B(32), ctypes.c_int()
     encs = [os.urandom(32) for _ in range(80)]
     encs += [bytes.fromhex(v["pk"]) for v in edge_vectors] + [bytes.fromhex(v["sig"])[:32] for v in edge_vectors]
+    # every encoding of a small-order point, canonical or not (y, y + p where that fits 255 bits; either sign bit),
+    # and their neighbours: the kernels decide small order by comparing the canonical y with the five values a
+    # small-order point can have (ge_is_small_order_affine) - it must agree with [8]P == O everywhere
+    small_ys = sorted({t[1] * pow(t[2], -1, E.P) % E.P for t in E.eight_torsion()})
+    assert len(small_ys) == 5
+    for ys in small_ys:
+        for yy in (ys, ys + E.P, ys + 1, ys - 1, ys ^ (1 << 200)):
+            if 0 <= yy < (1 << 255):
+                for sign in (0, 1):
+                    encs.append((yy | (sign << 255)).to_bytes(32, "little"))
+    seen_small = 0
     for e in encs:
         ok = emu.emu_decompress(e, x, y, ctypes.byref(sm))
         p = E.decompress(e)
         assert bool(ok) == (p is not None)
         if ok:
             assert int.from_bytes(x.raw, "little") == p[0] and int.from_bytes(y.raw, "little") == p[1]
-            assert bool(sm.value) == E.pt_is_small_order(p)
+            want = E.pt_is_small_order(p)
+            assert sm.value == (3 if want else 0), (e.hex(), sm.value, want)
+            seen_small += want
+    assert seen_small >= 14      # 8 canonical + the non-canonical spellings of y = 0, 1 (and -0)
 
 
 @pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad"])
@@ -142,14 +156,56 @@ def test_verify_stages_vs_c_oracle_random(emu, oracle, fn):
             assert [i for i in range(n) if not out.raw[i]] == bad
 
 
+_BASE_TABLES = {}
+
+
+def _emu_base_tables(emu):
+    """(8-bit table, 16-bit table) of the base point, built once per session (the 16-bit one is 67 MB, ~2 s)."""
+    import numpy as np
+    if "t" not in _BASE_TABLES:
+        emu.emu_keyset_words.restype = ctypes.c_size_t
+        emu.emu_base16_words.restype = ctypes.c_size_t
+        btab = np.zeros(emu.emu_keyset_words(S(1)), dtype=np.uint32)
+        emu.emu_keyset_build_base(btab.ctypes.data_as(ctypes.c_void_p))
+        b16 = np.zeros(emu.emu_base16_words(), dtype=np.uint32)
+        emu.emu_base16_build(btab.ctypes.data_as(ctypes.c_void_p), b16.ctypes.data_as(ctypes.c_void_p))
+        emu.emu_set_base16(b16.ctypes.data_as(ctypes.c_void_p))
+        _BASE_TABLES["t"] = (btab, b16)
+    return _BASE_TABLES["t"]
+
+
+def test_base_point_16_bit_table(emu):
+    """T_B16[w][j] = j 2^(16w) B as the kernels read it (built from the 8-bit table by base16_entry_projective +
+    the shared-inversion normalisation): sampled entries incl. the ends of every window vs the big-int ground truth;
+    and the radix-65536 recoding sums back to the scalar with digits in [-32768, 32767]."""
+    _, b16 = _emu_base_tables(emu)
+    rng = random.Random(16)
+    out = B(96)
+    picks = [(w, j) for w in range(16) for j in (0, 1, 2, 127, 128, 129, 255, 256, 257, 384, 385, 32639, 32640, 32767, 32768)]
+    picks += [(rng.randrange(16), rng.randrange(32769)) for _ in range(300)]
+    for w, j in picks:
+        e = b16[(w * 32769 + j) * 32:(w * 32769 + j) * 32 + 32]
+        emu.emu_entry_canonical(e.ctypes.data_as(ctypes.c_void_p), out)
+        ymx, ypx, t2d = (int.from_bytes(out.raw[32 * c:32 * c + 32], "little") for c in range(3))
+        p = E.pt_mul(j << (16 * w), E.B)
+        zi = pow(p[2], -1, E.P)
+        x, y = p[0] * zi % E.P, p[1] * zi % E.P
+        assert (ymx, ypx, t2d) == ((y - x) % E.P, (y + x) % E.P, 2 * E.D * x * y % E.P), (w, j)
+    dg = (ctypes.c_int32 * 16)()
+    for _ in range(200):
+        sc = rng.randrange(E.L) if rng.random() < 0.8 else rng.choice([0, 1, E.L - 1, (1 << 252) - 1, 0x8000, 0x7fff, (1 << 253) - 1])
+        emu.emu_sc_digits16(sc.to_bytes(32, "little"), dg)
+        assert all(-32768 <= d <= 32767 for d in dg)
+        assert sum(d << (16 * (15 - i)) for i, d in enumerate(dg)) == sc
+
+
 def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode, lane_form=0):
     import numpy as np
     emu.emu_cached_set_lane_form(lane_form)
     emu.emu_keyset_words.restype = ctypes.c_size_t
     kw = emu.emu_keyset_words(S(1))
     nk = len(keys) // 32
-    btab = np.zeros(kw, dtype=np.uint32)
-    emu.emu_keyset_build_base(btab.ctypes.data_as(ctypes.c_void_p))
+    btab, _ = _emu_base_tables(emu)
     tab = np.zeros(kw * nk, dtype=np.uint32)
     flag = np.zeros(nk, dtype=np.uint32)
     emu.emu_keyset_build(keys, S(nk), tab.ctypes.data_as(ctypes.c_void_p), flag.ctypes.data_as(ctypes.c_void_p))

@@ -362,13 +362,16 @@ def test_lifecycle_shutdown_reinit_and_keyset_churn():
     ks.close()
 
 
-def test_several_batches_in_one_launch(oracle):
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS, _lib.KERNEL_AUTO])
+def test_several_batches_in_one_launch(oracle, kernel):
     """hs_ed25519_verify_device_batches: 19 independent batches of different sizes, digest forms and
-    modes (> 16, so two grids), each with its own bitmap and reject counter, vs the oracle."""
+    modes (> 16, so two grids), each with its own bitmap and reject counter, vs the oracle - through the
+    one-signature-per-quad kernel, the pairs form (two signatures per quad, 32 per wavefront) and the default."""
     dev = torch.device("cuda", 0)
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     sizes = [1, 16, 17, 63, 64, 65, 100, 333, 1024, 1000, 5, 128, 129, 700, 2, 1024, 31, 257, 64]
     ctx = _lib.DeviceContext(1024)
+    ctx.set_kernel(kernel)
     keep, entries, expect = [], [], []
     nr = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
     for k, n in enumerate(sizes):
@@ -391,6 +394,34 @@ def test_several_batches_in_one_launch(oracle):
     big = _lib.batch_array([(keep[0][0].data_ptr(), 0, keep[0][1].data_ptr(), keep[0][2].data_ptr(), 40000, 0, keep[0][3].data_ptr(), 0)])
     with pytest.raises(_lib.EngineError):
         ctx.verify_batches(big)
+    ctx.close()
+
+
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS])
+def test_edge_vectors_through_batches_per_launch(edge_vectors, torsion_fuzz, kernel):
+    """Every labelled edge vector and torsion-fuzz vector (tests/golden) through hs_ed25519_verify_device_batches in
+    both modes: five batches per call (the vectors in order, reversed, and rotated so that every vector lands in both
+    halves of a pairs-form quad), verdicts = the vectors' labels."""
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    vs = list(edge_vectors) + list(torsion_fuzz)
+    ctx = _lib.DeviceContext(1024)
+    ctx.set_kernel(kernel)
+    orders = [vs, vs[::-1], vs[16:] + vs[:16], vs[7:] + vs[:7], vs[:33]]
+    for mode, label in ((_lib.STRICT, "strict"), (_lib.BATCH, "cofactorless")):
+        keep, entries = [], []
+        for o in orders:
+            n = len(o)
+            d = [t(b"".join(bytes.fromhex(v["msg"]) for v in o)), t(b"".join(bytes.fromhex(v["pk"]) for v in o)),
+                 t(b"".join(bytes.fromhex(v["sig"]) for v in o)), torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)]
+            keep.append(d)
+            entries.append((d[0].data_ptr(), 32, d[1].data_ptr(), d[2].data_ptr(), n, mode, d[3].data_ptr(), 0))
+        torch.cuda.synchronize(dev)
+        ctx.verify_batches(_lib.batch_array(entries))
+        torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+        for o, d in zip(orders, keep):
+            got = bits(bytes(d[3].cpu().tolist()), len(o))
+            assert [bool(b) for b in got] == [v[label] for v in o]
     ctx.close()
 
 
