@@ -350,7 +350,8 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
     return out
 
 
-def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8, inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2))):
+def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
+               inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2), (16, 4, 4), (4, 8, 4), (1, 32, 4))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
     `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads would measure the interpreter lock) each
     verify their own 1,024-tuple batch in a loop; every call stages into pinned memory, launches on a pool context's
@@ -508,14 +509,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="signatures per batch (one verify call)")
     ap.add_argument("--batches-per-step", type=int, default=1024,
                     help="independent 1,024-tuple batches per step per GPU")
-    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "2")),
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "4")),
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
     ap.add_argument("--kernel", choices=("auto", "fused", "pairs"), default=os.environ.get("HS_BENCH_KERNEL", "auto"),
                     help="hs_ed25519_verify_device_batches kernel: the library's choice by batch count, one signature per quad, "
                          "or the pairs form (two signatures per quad)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
-    ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "2")),
+    ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "4")),
                     help="batches per hs_ed25519_verify_device_batches_cached launch in the committee_cached extra")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")

@@ -178,14 +178,12 @@ __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_sr
     const u32 q = threadIdx.x >> 2;
     const u32 i0 = block * 32 + q, i1 = i0 + 16;
     const u32 j0 = i0 < n ? i0 : n - 1, j1 = i1 < n ? i1 : n - 1;
-    const quad_pair_points pp = quad_pair_decompress(pks, sigs, j0, j1, mode);
+    const quad_pair_points pp = quad_pair_decompress(pks, sigs, msgs, j0, j1, mode);
     u32 bad = 0;
 #pragma nounroll
     for (u32 h = 0; h < 2; h++) {
-        const u32 i = h ? i1 : i0, j = h ? j1 : j0;
-        u32 msg[8];
-        load_msg(msg, msgs, j);
-        const bool ok = quad_pair_pass(pp, h, pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab);
+        const u32 i = h ? i1 : i0;
+        const bool ok = quad_pair_pass(pp, h, mode, g_b16, atab);
         const u32 m = quad_ballot16(ok && i < n);
         if (threadIdx.x == 0) bitmap16[2 * block + h] = (unsigned short)m;
         const u32 first = block * 32 + 16 * h;

@@ -37,8 +37,20 @@ HS_Q qv q_perm(const qv &a) {       // lane i <- lane P_i of the same quad
 }
 template <int MASK>
 HS_Q qv q_sel(const qv &a, const qv &b) {   // lane i takes b iff bit i of MASK
+#ifdef HS_QSEL_CNDMASK
     const bool pick = (MASK >> q_lane()) & 1;
     qv r; fe_select(r, a, b, pick); return r;
+#else
+    // a mask in a register, (b & m) | (a & ~m) = one v_bfi_b32 per limb; the compiler's own form is a v_cndmask_b32_e64
+    // on an SGPR-pair mask (4.9 cycles against ~3, as for q_comb's `keep`).  Measured A/B (-DHS_QSEL_CNDMASK): throughput
+    // equal within noise, a lone wavefront's chain 1 % shorter (cold QC p50 0.383 against 0.387 ms)
+    u32 m = ((MASK >> q_lane()) & 1) ? 0xffffffffu : 0u;
+    asm("" : "+v"(m));
+    qv r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = (b.v[i] & m) | (a.v[i] & ~m);
+    return r;
+#endif
 }
 HS_Q qv q_mul(const qv &f, const qv &g) { qv r; fe_mul(r, f, g); return r; }
 HS_Q qv q_sq(const qv &f) { qv r; fe_sq(r, f); return r; }
@@ -383,35 +395,49 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
 // all lanes useful), then the quad runs the window loop twice: 11 % fewer multiply-adds per verification, 1.85x the
 // latency of a wavefront (which now carries 32 signatures).  Used where the caller hands over enough batches per
 // launch to fill the chip anyway (hs_ed25519_verify_device_batches).
-struct quad_pair_points { fe X, Y; u32 fl; };
-// lane 0: A of signature j0, lane 1: R of j0, lane 2: A of j1, lane 3: R of j1
-HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, u32 j0, u32 j1, u32 mode) {
+struct quad_pair_points { fe X, Y; u32 fl; u32 kw[8], sw[8]; };
+// lane 0: A of signature j0, lane 1: R of j0, lane 2: A of j1, lane 3: R of j1; lanes 0, 1 also hash signature j0 and
+// lanes 2, 3 signature j1 (one SHA-512 pass for both; HS_F_SCANON in fl = s < L)
+HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, msg_src msgs, u32 j0, u32 j1, u32 mode) {
     const u32 lane = q_lane();
     const u32 j = (lane & 2) ? j1 : j0;
-    const u32 *src = (lane & 1) ? sigs + (size_t)16 * j : pks + (size_t)8 * j;
+    const u32 *pk = pks + (size_t)8 * j, *sig = sigs + (size_t)16 * j;
     u32 enc[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) enc[t] = src[t];
+    for (int t = 0; t < 8; t++) enc[t] = (lane & 1) ? sig[t] : pk[t];
     ge_p3 pt;
     quad_pair_points r;
     r.fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
     if (mode & HS_MODE_STRICT) r.fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
     r.X = pt.X; r.Y = pt.Y;
+    u32 msg[8];
+    load_msg(msg, msgs, j);
+    if (prepare_scalars(r.kw, r.sw, pk, sig, msg, false, true)) r.fl |= HS_F_SCANON;
     return r;
 }
-// pass h (0 / 1, uniform over the wavefront) over signature j = j0 / j1
-HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, const u32 *pk, const u32 *sig, const u32 *msg, u32 mode,
-                         const u32 *b16, qtab &atab) {
+// pass h (0 / 1, uniform over the wavefront): the quad's first / second signature
+HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 *b16, qtab &atab) {
     fe sx = pp.X, sy = pp.Y;
     u32 sf = pp.fl;
+    u32 kw[8], sw[8];
     if (h) {        // bring lanes 2, 3 down to lanes 0, 1
         sx = q_perm<2, 3, 2, 3>(pp.X); sy = q_perm<2, 3, 2, 3>(pp.Y);
         sf = (u32)__builtin_amdgcn_mov_dpp((int)pp.fl, HS_QP(2, 3, 2, 3), 0xf, 0xf, true);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            kw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.kw[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
+            sw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.sw[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            kw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.kw[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
+            sw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.sw[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
+        }
     }
     const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x00, 0xf, 0xf, true);
     const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x55, 0xf, 0xf, true);
-    u32 kw[8], sw[8];
-    bool ok = prepare_scalars(kw, sw, pk, sig, msg, false, true);
+    bool ok = (fa & HS_F_SCANON) != 0;
     ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(sx), ay = q_perm<0, 0, 0, 0>(sy);
