@@ -868,7 +868,17 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
     void *a3[] = { &msgs, &p_pk, &p_sg, &nn_, &mode_, &p_bm, &p_nr, &p_skip };
     // hipLaunchKernel returns its own status (hipGetLastError may carry another library's stale error)
     if (ev) ctx->ev_mid[slot] = kern != HS_K_FUSED;
-    if (kern == HS_K_FUSED) {
+    if (kern == HS_K_FUSED && ctx->kernel == HS_K_FUSED_PAIRS && !d_skip) {
+        // the pairs form forced on a single batch (A/B measurements, tools/r2_sweeps.py): a one-entry batch list
+        fused_batch_list L;
+        L.count = 1;
+        fused_batch &f = L.b[0];
+        f.msgs = msgs; f.pks = p_pk; f.sigs = p_sg; f.bitmap16 = (unsigned short *)d_bitmap; f.nreject = d_nreject;
+        f.n = nn; f.mode = mode; f.first_block = 0; f.pad = 0;
+        void *a[] = { &L };
+        HS_HIP(launch1((const void *)k_verify_fused_pairs_batches, dim3(np / 32), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+               "launch k_verify_fused_pairs_batches");
+    } else if (kern == HS_K_FUSED) {
         HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused");
     } else {

@@ -87,12 +87,13 @@ SKIP12 = os.environ.get("HS_SWEEP_ONLY") == "3"
 if os.environ.get("HS_SWEEP_SIZES"):
     sys.exit(0)
 print("## 2. Per-signature cold path (strict, one digest per signature): fused four-lane kernel vs one lane per signature\n")
-print("| signatures | k_verify_fused p50 ms | k_prepare + k_verify p50 ms | fused M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
-print("|---|---|---|---|---|")
-for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else (16384, 32768, 49152, 66667, 131072, 262144)):
+print("| signatures | k_verify_fused p50 ms | pairs form p50 ms | k_prepare + k_verify p50 ms | fused M sig/s (4 in flight) | pairs M sig/s | lane M sig/s |")
+print("|---|---|---|---|---|---|---|")
+for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else (8192, 16384, 32768, 49152, 66667, 131072, 262144)):
     a = measure(n, _lib.STRICT, _lib.KERNEL_FUSED, shared=False)
+    c = measure(n, _lib.STRICT, _lib.KERNEL_FUSED_PAIRS, shared=False)
     b = measure(n, _lib.STRICT, _lib.KERNEL_LANE, shared=False)
-    print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
+    print("| %d | %.3f | %.3f | %.3f | %.1f | %.1f | %.1f |" % (n, a[0], c[0], b[0], a[1], c[1], b[1]), flush=True)
 
 print("\n## 3. Key-cache path (batch semantics, shared digest, one key per signature): two-lane + R-wavefront kernel vs one-lane kernel\n")
 print("| signatures | lane2r p50 ms | lane p50 ms | lane2r M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
