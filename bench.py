@@ -702,7 +702,7 @@ def main():
                   "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": "k_verify_cached_lane2r_batches",
                   "avg_kernel_ms": round(k_ms, 4), "keys": n * ns, "keyset_hbm_bytes": ks.hbm_bytes(),
                   "keyset_build_ms": round(build_ms, 2),
-                  "table_bytes_read_per_verify": 64 * 128,
+                  "table_bytes_read_per_verify": (32 + 16) * 128,      # 32 lines of the key's table + 16 of the base point's 16-bit table
                   "note": "keys pre-registered (static committee); not comparable with `value`, which is the cold path"}
         ks.close()
         # large committee, one launch (BASELINE configs[3] on ONE GPU): N = 100,000 validators (66 GB of
@@ -733,7 +733,9 @@ def main():
             l_el = time.perf_counter() - t0
             assert int(l_nr.item()) == 0
             lk_ms = lctx.kernel_times()[1] / max(1, lctx.kernel_times()[2])
-            gather = 32 * 128 * nl                      # bytes of the keys' tables read per launch (one 128-byte affine entry per window)
+            # bytes of table lines read per launch: one 128-byte affine entry per 8-bit window of the key's table (32) and per
+            # 16-bit window of the base point's 67 MB table (16; larger than the L2s, so these come from MALL / HBM as well)
+            gather = (32 + 16) * 128 * nl
             l_traffic = None
             try:    # HBM bytes per launch from the committed rocprofv3 PMC pass (same kernel, same launch size)
                 lp = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json"))).get("large_committee", {})
@@ -750,7 +752,8 @@ def main():
                              "algorithmic_bytes_per_launch": gather, "traffic": l_traffic,
                              "traffic_source": "profiles/r2_pmc_traffic.json large_committee (rocprofv3 --pmc FETCH_SIZE, "
                                                "uncorrected)" if l_traffic else None,
-                             "note": "32 table entries x 128 B (one cache line each) per verification gathered from the key set"}}
+                             "note": "48 table entries x 128 B (one cache line each) per verification: 32 gathered from the key set, "
+                                     "16 from the base point's 16-bit table"}}
             lctx.close(); lks.close()
         except Exception as e:        # never let the extra break the headline
             cached["large_committee"] = {"error": str(e)}

@@ -104,6 +104,14 @@ def test_qc_structural_errors_precede_crypto(openssl_vectors):
     assert tc.vote_digest(3).b == hashlib.sha512(struct.pack("<QQ", 7, 3)).digest()[:32]   # messages.rs:307-311
 
 
+def test_batches_per_launch_kernel_policy():
+    """hs_ed25519_verify_device_batches picks its kernel by the batch count of the call (no GPU needed to ask):
+    up to three batches the one-signature-per-quad form (latency), from four the pairs form (throughput)."""
+    lib = _lib.lib()
+    names = [lib.hs_ed25519_batches_kernel_for(None, k).decode() for k in (1, 2, 3, 4, 5, 16)]
+    assert names == ["k_verify_fused_batches"] * 3 + ["k_verify_fused_pairs_batches"] * 3
+
+
 def test_code_object_has_no_reversed_subtract_with_dpp():
     """gfx950 applies the lane permutation of v_subrev_u32_dpp to the wrong operand
     (tools/dpp_subrev_check.hip, profiles/r1_dpp_subrev.txt) and LLVM's DPP combiner emits that

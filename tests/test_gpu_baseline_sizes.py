@@ -48,6 +48,21 @@ def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
     ks.close()
 
 
+@pytest.mark.parametrize("n", [6667, 8384, 66667])
+def test_pairs_form_vs_oracle_at_baseline_size(oracle, n):
+    """The pairs form of the fused kernel (two signatures per quad, 32 per wavefront) forced on one device-resident
+    batch of BASELINE size, ~3 % corrupted, both modes, shared and per-signature digests."""
+    from gpu_helpers import DeviceRunner
+    run = DeviceRunner(n, kernel=_lib.KERNEL_FUSED_PAIRS)
+    for shared in (True, False):
+        dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=8)
+        for mode in (_lib.BATCH, _lib.STRICT):
+            expect = oracle_verify_many(oracle, dg, 0 if shared else 32, pk, sg, n, mode)
+            assert run.bits(dg, pk, sg, n, mode, shared) == expect
+    run.close()
+
+
 def test_one_lane_cached_kernel_reached_by_size(oracle):
     """n = 197,632 > 98,304: hs_ed25519_verify_shared_cached dispatches k_verify_cached_lane by size.
     1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted individually."""

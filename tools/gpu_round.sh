@@ -2,5 +2,5 @@
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1200 python tools/r2_sweeps.py > gpurun_out/r2_sweeps.md 2> gpurun_out/r2_sweeps.err; echo rc=$?; tail -3 gpurun_out/r2_sweeps.err
-cat gpurun_out/r2_sweeps.md
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu_all.txt 2>&1; echo rc=$?
+grep -E "passed|failed|error" gpurun_out/pytest_gpu_all.txt | tail -5; grep -n -E "^(FAILED|ERROR)|Error|assert " gpurun_out/pytest_gpu_all.txt | head -20
