@@ -351,7 +351,7 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
-               inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2), (16, 4, 4), (4, 8, 4), (1, 32, 4))):
+               inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2), (16, 4, 4), (4, 16, 4), (1, 64, 4))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
     `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads would measure the interpreter lock) each
     verify their own 1,024-tuple batch in a loop; every call stages into pinned memory, launches on a pool context's
