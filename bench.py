@@ -66,8 +66,9 @@ MAD_PER_VERIFY = {
     # pairs form: a wavefront carries 32 signatures; one decompression pass of all 64 lanes serves both window loops
     "k_verify_fused_pairs": (2 * (252 * 155 + 80 * 200 + 7 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
     "k_verify_quad": (252 * 155 + 80 * 200 + 7 * 300) * 64 // 16,
-    # lane: 1008 sq + ~1470 mul in k_verify (k_prepare adds 2 x (267 sq + 30 mul))
-    "k_verify": 1008 * 55 + 1470 * 100,
+    # lane: 1008 sq + ~1450 mul in k_verify; k_prepare adds 2 x (255 sq + 21 mul)
+    "k_verify": 1008 * 55 + 1450 * 100,
+    "k_verify_batches": 1008 * 55 + 1450 * 100 + 2 * (255 * 55 + 21 * 100),
 }
 MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 
@@ -511,9 +512,10 @@ def main():
                     help="independent 1,024-tuple batches per step per GPU")
     ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "4")),
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
-    ap.add_argument("--kernel", choices=("auto", "fused", "pairs"), default=os.environ.get("HS_BENCH_KERNEL", "auto"),
+    ap.add_argument("--kernel", choices=("auto", "fused", "pairs", "lane"), default=os.environ.get("HS_BENCH_KERNEL", "auto"),
                     help="hs_ed25519_verify_device_batches kernel: the library's choice by batch count, one signature per quad, "
-                         "or the pairs form (two signatures per quad)")
+                         "the pairs form (two signatures per quad), or the one-lane pair over the batch list (throughput at "
+                         "several times the latency; wants --batches-per-launch 16 --partitions 0)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
     ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "4")),
@@ -585,7 +587,7 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         ctxs = [_lib.DeviceContext(n) for _ in range(ns)]
     for c in ctxs:
-        c.set_kernel({"auto": _lib.KERNEL_AUTO, "fused": _lib.KERNEL_FUSED, "pairs": _lib.KERNEL_FUSED_PAIRS}[args.kernel])
+        c.set_kernel({"auto": _lib.KERNEL_AUTO, "fused": _lib.KERNEL_FUSED, "pairs": _lib.KERNEL_FUSED_PAIRS, "lane": _lib.KERNEL_LANE}[args.kernel])
     bm_bytes = 8 * ((n + 63) // 64)
     K = max(1, min(16, args.batches_per_launch))
     B = (B + K - 1) // K * K               # whole launches

@@ -80,6 +80,48 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
     }
 }
 
+// The same pair over a list of independent batches (hs_ed25519_verify_device_batches from 16 batches per call): with
+// enough signatures per launch to fill the chip the one-lane kernels do the least work per verification
+// (profiles/r2_sweeps.md section 2: 74 M/s against the pairs form's 65), at several times the latency of a launch.
+// Every batch has its own workspace slice, digests, bitmap and reject counter.
+#define HS_MAX_BATCHES_PER_LAUNCH 16
+struct lane_batch { workspace ws; msg_src msgs; const u32 *pks, *sigs; unsigned long long *bitmap; u32 *nreject; u32 n, mode, first_p, first_v; };
+struct lane_batch_list { lane_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+__global__ void __launch_bounds__(64, 3)
+k_prepare_batches(lane_batch_list L) {
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_p) k = t;
+    const lane_batch &B = L.b[k];
+    const u32 t = (blockIdx.x - B.first_p) * 64 + threadIdx.x;
+    if (t >= 2 * B.n) return;
+    const bool is_r = t >= B.n;
+    const u32 i = is_r ? t - B.n : t;
+    u32 msg[8];
+    if (is_r) load_msg(msg, B.msgs, i);
+    prepare_point(B.ws, i, is_r, B.pks + (size_t)8 * i, B.sigs + (size_t)16 * i, msg, B.mode);
+}
+__global__ void __launch_bounds__(64)
+k_verify_batches(lane_batch_list L) {
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_v) k = t;
+    const lane_batch &B = L.b[k];
+    const u32 block = blockIdx.x - B.first_v;
+    const u32 i = block * 64 + threadIdx.x;
+    const bool active = i < B.n;
+    const bool ok = verify_lane(B.ws, active ? i : B.n - 1, B.mode, g_b16) && active;
+    const unsigned long long mask = __ballot(ok);
+    if (threadIdx.x == 0) {
+        B.bitmap[block] = mask;
+        if (B.nreject) {
+            const u32 lanes = min(64u, B.n - block * 64);
+            const u32 bad = lanes - (u32)__popcll(mask);
+            if (bad) atomicAdd(B.nreject, bad);
+        }
+    }
+}
+
 // TC::verify's per-vote digests SHA-512(round_le || high_qc_round_le)[..32]
 // (consensus/src/messages.rs:307-311), one lane per vote, ahead of the verify kernels.
 __global__ void __launch_bounds__(64)
@@ -202,7 +244,6 @@ k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict_
 // wavefront issues at about half the rate two co-resident ones reach (profiles/r1_ubench_valu.txt).
 // Back-to-back launches of one stream do not overlap and more than 16 streams collapse
 // (profiles/r1_stream_sweep.txt), so the way to more wavefronts per SIMD is more batches per launch.
-#define HS_MAX_BATCHES_PER_LAUNCH 16
 struct fused_batch { msg_src msgs; const u32 *pks, *sigs; unsigned short *bitmap16; u32 *nreject; u32 n, mode, first_block, pad; };
 struct fused_batch_list { fused_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
 __global__ void __launch_bounds__(64, 2)
@@ -582,7 +623,8 @@ int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrid
 // (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
 static const size_t kCachedLane1Min = 98304;
 // hs_ed25519_verify_device_batches switches to the pairs form from this many batches per call (measured, DESIGN.md
-// section 5); HS_ED25519_PAIRS_MIN_BATCHES overrides it for A/B runs (0 = never)
+// section 5); HS_ED25519_PAIRS_MIN_BATCHES overrides it for A/B runs (0 = never).  The one-lane kernels over a batch
+// list (k_prepare_batches + k_verify_batches) are never chosen by the library: HS_K_LANE on the context asks for them.
 static std::atomic<size_t> g_pairs_min_batches{4};
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
@@ -826,6 +868,7 @@ extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQ
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
     const int k = ctx ? ctx->kernel : HS_K_AUTO;
+    if (k == HS_K_LANE) return "k_verify_batches";
     return k == HS_K_FUSED_PAIRS || (k == HS_K_AUTO && count >= g_pairs_min_batches.load()) ? "k_verify_fused_pairs_batches" : "k_verify_fused_batches";
 }
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) { return n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r"; }
@@ -852,8 +895,7 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
     if (kern != HS_K_FUSED) { int rc = ctx_reserve(ctx, n, ctx->staging); if (rc) return rc; }
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const u32 np = (u32)round_up(n, 64);
-    workspace ws;
-    ws.np = np; ws.pt = ctx->d_ws; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    workspace ws = workspace_at(ctx->d_ws, np);
     const u32 nn = (u32)n;
     const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
     const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
@@ -945,6 +987,46 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     }
     return enqueue_cold(ctx, m, d_pks, d_sigs, n, mode, d_bitmap, d_nreject, stream);
 }
+// the one-lane form of hs_ed25519_verify_device_batches: two launches per 16 batches, workspace slices from the context
+static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, hipStream_t st) {
+    size_t total = 0;
+    for (size_t i = 0; i < count; i++) total += round_up(batches[i].n, 64);
+    if (total == 0) return 0;
+    int rc = ctx_reserve(ctx, total, ctx->staging);
+    if (rc) return rc;
+    size_t done = 0, ws_off = 0;            // ws_off: padded signatures already given a workspace slice
+    while (done < count) {
+        lane_batch_list L;
+        L.count = 0;
+        u32 pw = 0, vw = 0;
+        for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
+            const hs_ed25519_batch &b = batches[done];
+            if (b.n == 0) continue;
+            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches: mode must be BATCH / STRICT and n <= 32,768");
+            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches: null pointer");
+            if (misaligned(b.d_pks, 16) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
+                return fail(HS_ED25519_E_ARG, "verify_device_batches: misaligned pointer");
+            lane_batch &f = L.b[L.count++];
+            rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
+            if (rc) return rc;
+            const u32 np = (u32)round_up(b.n, 64);
+            f.ws = workspace_at(ctx->d_ws + workspace_words(ws_off), np);
+            ws_off += np;
+            f.pks = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap = (unsigned long long *)b.d_bitmap;
+            f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode; f.first_p = pw; f.first_v = vw;
+            pw += (2 * f.n + 63) / 64; vw += np / 64;
+        }
+        if (!L.count) continue;
+        const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+        const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+        hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
+        if (ev) ctx->ev_mid[slot] = 1;
+        void *a[] = { &L };
+        HS_HIP(launch1((const void *)k_prepare_batches, dim3(pw), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr), "launch k_prepare_batches");
+        HS_HIP(launch1((const void *)k_verify_batches, dim3(vw), dim3(64), a, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify_batches");
+    }
+    return 0;
+}
 // Several independent small batches (each <= 32,768 signatures, BATCH or STRICT) in one launch per 16 of them.
 extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, void *stream) {
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
@@ -954,6 +1036,7 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     // pairs form (two signatures per quad, 11 % less work, 1.85x a wavefront's latency) once the caller hands over
     // enough batches per launch that the shorter form's extra wavefronts would only queue; HS_K_FUSED / HS_K_FUSED_PAIRS
     // on the context force either
+    if (ctx->kernel == HS_K_LANE) return enqueue_lane_batches(ctx, batches, count, st);
     const bool pairs = ctx->kernel == HS_K_FUSED_PAIRS || (ctx->kernel == HS_K_AUTO && count >= g_pairs_min_batches.load());
     const u32 per_block = pairs ? 32 : 16;
     size_t done = 0;

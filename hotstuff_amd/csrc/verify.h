@@ -31,11 +31,45 @@ enum : u32 { HS_F_ONCURVE = 1, HS_F_SMALL = 2, HS_F_SCANON = 4 };
 //   pt   [2][20][np] u32   x,y limbs of A (slot 0) and R (slot 1)
 //   sc   [16][np]    u32   k recoded signed radix-16 (rows 0-7), s recoded signed radix-256 (rows 8-15)
 //   flag [2][np]     u32   HS_F_* bits per point
+//   tab  [np][9][40] u32   stage 2's per-signature table j * (-A), j = 0..8, cached form (Y+X, Y-X, Z, 2dT), one
+//                          160-byte entry after the other: a lane reads the entry its digit picks with ten 16-byte
+//                          loads (the compiler's private-memory layout of the same array interleaves the lanes' dwords,
+//                          so that every one of the 40 dwords of a lookup touched up to 64 cache lines)
 struct workspace {
-    u32 *pt, *sc, *flag;
+    u32 *pt, *sc, *flag, *tab;
     u32 np;
 };
-HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + 16 + 2); }
+#define HS_WS_TAB_WORDS (9 * 40)
+HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + 16 + 2 + HS_WS_TAB_WORDS); }
+HS_HD workspace workspace_at(u32 *base, size_t np) {
+    workspace ws;
+    ws.np = (u32)np; ws.pt = base; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np; ws.tab = ws.flag + (size_t)2 * np;
+    return ws;
+}
+HS_HD void ws_store_cached(u32 *p, const ge_cached &c) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z.v[i]; w[30 + i] = c.T2d.v[i]; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+#else
+    for (int i = 0; i < 10; i++) { p[i] = c.YpX.v[i]; p[10 + i] = c.YmX.v[i]; p[20 + i] = c.Z.v[i]; p[30 + i] = c.T2d.v[i]; }
+#endif
+}
+HS_HD void ws_load_cached(ge_cached &c, const u32 *p) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#else
+    const u32 *w = p;
+#endif
+#pragma unroll
+    for (int i = 0; i < 10; i++) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+}
 
 // ---- stage 1 ------------------------------------------------------------------------------
 // task in [0, n): A of signature `task`; task in [n, 2n): R of signature task - n.
@@ -149,18 +183,21 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
         for (int j = 0; j < 8; j++) { const u64 t = (u64)sw[j] - 0x00800080u - borrow; sw[j] = (u32)t; borrow = (t >> 32) & 1; }
     }
 
-    // per-lane table j * (-A), j = 0..8, in private memory (indexed per lane below)
-    ge_cached atab[9];
-    ge_cached_identity(atab[0]);
-    ge_to_cached(atab[1], p);
+    // per-lane table j * (-A), j = 0..8, in this signature's slice of the workspace (indexed per lane below)
+    u32 *atab = ws.tab + (size_t)i * HS_WS_TAB_WORDS;
     {
-        const ge_cached a1 = atab[1];
+        ge_cached a1, c;
+        ge_cached_identity(c);
+        ws_store_cached(atab, c);
+        ge_to_cached(a1, p);
+        ws_store_cached(atab + 40, a1);
 #pragma nounroll
         for (int j = 2; j <= 8; j++) {
             ge_p1p1 t;
             ge_add(t, p, a1, false);
             ge_p1p1_to_p3(p, t, true);
-            ge_to_cached(atab[j], p);
+            ge_to_cached(c, p);
+            ws_store_cached(atab + 40 * j, c);
         }
     }
 
@@ -177,7 +214,9 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
         }
         const int dk = sc_pop_digit(kw);
         const int ik = dk < 0 ? -dk : dk;
-        ge_add(t, acc, atab[ik], dk < 0);
+        ge_cached ea;
+        ws_load_cached(ea, atab + 40 * ik);
+        ge_add(t, acc, ea, dk < 0);
         if ((w & 3) == 3) {     // [s]B: one 16-bit window per four 4-bit windows of k
             ge_p1p1_to_p3(acc, t, true);
             const int ds = sc_pop_digit16(sw);

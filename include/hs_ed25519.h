@@ -88,7 +88,7 @@ int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch)
 int hs_ed25519_device_count(void);        /* device slots, 0 before init */
 void hs_ed25519_shutdown(void);
 /* The batch size below which a call should stay on the CPU path of the shim (dalek): the GPU round
- * trip costs one wavefront's serial chain (~0.4 ms cold, ~0.13 ms with registered keys) whatever n
+ * trip costs one wavefront's serial chain (~0.36-0.4 ms cold, ~0.09-0.12 ms with registered keys) whatever n
  * is.  keys_registered != 0: the caller would use a *_cached entry point.  bench.py measures the
  * crossover (`small_batch_crossover`); env HS_ED25519_MIN_GPU_BATCH overrides. */
 size_t hs_ed25519_min_gpu_batch(int keys_registered);
@@ -166,8 +166,9 @@ int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch
  * Every key the reference verifies belongs to the committee, which is static per epoch
  * (consensus/src/config.rs:39-43).  hs_ed25519_keyset_create decompresses the n_keys public
  * keys once and builds per-key window tables in HBM (528,420 bytes per key; see
- * hs_ed25519_keyset_bytes) so that a verification needs no doublings and no decompression:
- * 64 table additions + 1 inversion.  The *_cached calls take key_idx[i] = position of
+ * hs_ed25519_keyset_bytes) so that a verification needs no doublings and no decompression of A:
+ * 32 additions from the key's table + 16 from the base point's own 16-bit-window table (67 MB per
+ * GPU, built inside hs_ed25519_init) + 1 square root or inversion for R.  The *_cached calls take key_idx[i] = position of
  * signature i's key in the set instead of the key bytes (the Rust shim resolves it with the
  * same map QC::verify / TC::verify already use for the stake lookup,
  * consensus/src/messages.rs:182-194); an index >= n_keys rejects that signature.  Accept set,

@@ -76,7 +76,7 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
     if (!n) return;
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
-    workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    workspace ws = workspace_at(buf.data(), np);
     const u32 *btab = emu_base16();
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
@@ -93,7 +93,7 @@ void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks,
     if (!n) return;
     const u32 np = (u32)((n + 63) / 64 * 64);
     std::vector<u32> buf(workspace_words(np));
-    workspace ws; ws.np = np; ws.pt = buf.data(); ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np;
+    workspace ws = workspace_at(buf.data(), np);
     const u32 *btab = emu_base16();        // window 0 of the base point's 16-bit table: j B, j <= 32,768
     for (size_t t = 0; t < 2 * n; t++) {
         const bool is_r = t >= n; const size_t i = is_r ? t - n : t;

@@ -362,11 +362,12 @@ def test_lifecycle_shutdown_reinit_and_keyset_churn():
     ks.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS, _lib.KERNEL_AUTO])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS, _lib.KERNEL_LANE, _lib.KERNEL_AUTO])
 def test_several_batches_in_one_launch(oracle, kernel):
     """hs_ed25519_verify_device_batches: 19 independent batches of different sizes, digest forms and
     modes (> 16, so two grids), each with its own bitmap and reject counter, vs the oracle - through the
-    one-signature-per-quad kernel, the pairs form (two signatures per quad, 32 per wavefront) and the default."""
+    one-signature-per-quad kernel, the pairs form (two signatures per quad, 32 per wavefront), the one-lane pair
+    over the batch list (k_prepare_batches + k_verify_batches, workspace slices) and the default."""
     dev = torch.device("cuda", 0)
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     sizes = [1, 16, 17, 63, 64, 65, 100, 333, 1024, 1000, 5, 128, 129, 700, 2, 1024, 31, 257, 64]
@@ -397,7 +398,7 @@ def test_several_batches_in_one_launch(oracle, kernel):
     ctx.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_FUSED_PAIRS, _lib.KERNEL_LANE])
 def test_edge_vectors_through_batches_per_launch(edge_vectors, torsion_fuzz, kernel):
     """Every labelled edge vector and torsion-fuzz vector (tests/golden) through hs_ed25519_verify_device_batches in
     both modes: five batches per call (the vectors in order, reversed, and rotated so that every vector lands in both
