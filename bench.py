@@ -352,7 +352,7 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
-               inflight=((16, 2, 2), (4, 8, 2), (1, 32, 2), (16, 4, 4), (4, 16, 4), (1, 64, 4))):
+               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
     `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads would measure the interpreter lock) each
     verify their own 1,024-tuple batch in a loop; every call stages into pinned memory, launches on a pool context's
@@ -510,7 +510,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="signatures per batch (one verify call)")
     ap.add_argument("--batches-per-step", type=int, default=1024,
                     help="independent 1,024-tuple batches per step per GPU")
-    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "4")),
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_BPL", "16")),
                     help="independent batches handed to one hs_ed25519_verify_device_batches call (1 = hs_ed25519_verify_device)")
     ap.add_argument("--kernel", choices=("auto", "fused", "pairs", "lane"), default=os.environ.get("HS_BENCH_KERNEL", "auto"),
                     help="hs_ed25519_verify_device_batches kernel: the library's choice by batch count, one signature per quad, "
@@ -534,9 +534,11 @@ def main():
     args = ap.parse_args()
     if args.partitions is None:
         env = os.environ.get("HS_BENCH_PARTITIONS")
-        # 8 slices of 32 CUs = one XCD (its own L2) each, two stream contexts per slice: measured best
-        # (profiles/r2_partition_sweep.txt: 16 x 16 CUs 43.9 M/s, 8 x 32 CUs with two streams each 51.1 M/s)
-        args.partitions = int(env) if env is not None else (8 if args.batch <= 4096 else 0)
+        # 8 slices of 32 CUs = one XCD (its own L2) each, two stream contexts per slice: measured best for the quad kernels
+        # (profiles/r2_partition_sweep.txt: 16 x 16 CUs 43.9 M/s, 8 x 32 CUs with two streams each 51.1 M/s); the one-lane
+        # pair over sixteen batches per launch wants wider slices: 4 x 64 CUs 88.6 M/s, 2 x 128 85.3, none 86.6, 8 x 32 lower
+        lane_form = args.kernel == "lane" or (args.kernel == "auto" and args.batches_per_launch >= 8 and args.batches_per_launch * args.batch >= 8192)
+        args.partitions = int(env) if env is not None else ((4 if lane_form else 8) if args.batch <= 4096 else 0)
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to

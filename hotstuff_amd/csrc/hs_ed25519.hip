@@ -622,10 +622,13 @@ int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrid
 // kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
 // (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
 static const size_t kCachedLane1Min = 98304;
-// hs_ed25519_verify_device_batches switches to the pairs form from this many batches per call (measured, DESIGN.md
-// section 5); HS_ED25519_PAIRS_MIN_BATCHES overrides it for A/B runs (0 = never).  The one-lane kernels over a batch
-// list (k_prepare_batches + k_verify_batches) are never chosen by the library: HS_K_LANE on the context asks for them.
-static std::atomic<size_t> g_pairs_min_batches{4};
+// hs_ed25519_verify_device_batches picks its kernel by what the caller hands over at once (measured, DESIGN.md
+// section 5): up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight
+// batches that total 8,192 signatures the one-lane pair over the batch list (k_prepare_batches + k_verify_batches: the
+// least work per verification once the chip is full, at 2-3x the latency of a launch).
+// HS_ED25519_PAIRS_MIN_BATCHES / HS_ED25519_LANE_MIN_BATCHES override the counts for A/B runs (0 = never).
+static std::atomic<size_t> g_pairs_min_batches{4}, g_lane_min_batches{8};
+static const size_t kLaneMinTotal = 8192;
 static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
@@ -798,6 +801,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
     int have = 0;
@@ -866,9 +870,10 @@ extern "C" int hs_ed25519_debug_fused_blocks_per_cu(void) {
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
+// (for `count` batches of 1,024 signatures each: the lane form also wants 8,192 signatures in the call)
 extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
     const int k = ctx ? ctx->kernel : HS_K_AUTO;
-    if (k == HS_K_LANE) return "k_verify_batches";
+    if (k == HS_K_LANE || (k == HS_K_AUTO && count >= g_lane_min_batches.load() && count * 1024 >= kLaneMinTotal)) return "k_verify_batches";
     return k == HS_K_FUSED_PAIRS || (k == HS_K_AUTO && count >= g_pairs_min_batches.load()) ? "k_verify_fused_pairs_batches" : "k_verify_fused_batches";
 }
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) { return n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r"; }
@@ -1036,7 +1041,13 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     // pairs form (two signatures per quad, 11 % less work, 1.85x a wavefront's latency) once the caller hands over
     // enough batches per launch that the shorter form's extra wavefronts would only queue; HS_K_FUSED / HS_K_FUSED_PAIRS
     // on the context force either
-    if (ctx->kernel == HS_K_LANE) return enqueue_lane_batches(ctx, batches, count, st);
+    bool lane = ctx->kernel == HS_K_LANE;
+    if (ctx->kernel == HS_K_AUTO && count >= g_lane_min_batches.load()) {
+        size_t total = 0;
+        for (size_t i = 0; i < count; i++) total += batches[i].n;
+        lane = total >= kLaneMinTotal;
+    }
+    if (lane) return enqueue_lane_batches(ctx, batches, count, st);
     const bool pairs = ctx->kernel == HS_K_FUSED_PAIRS || (ctx->kernel == HS_K_AUTO && count >= g_pairs_min_batches.load());
     const u32 per_block = pairs ? 32 : 16;
     size_t done = 0;

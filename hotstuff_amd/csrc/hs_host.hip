@@ -126,13 +126,14 @@ const uint8_t *hs::host_job_bitmap(const host_job &job) { return job.c ? job.c->
 // wavefront issues the 64-bit multiply-adds at half the rate two co-resident ones reach; the streams
 // cannot be multiplied instead (16 hardware queues).  So the small host calls (n <= kPartitionMaxBatch)
 // of one BURST - consecutive submits of one thread, all but the last flagged HS_ED25519_SUBMIT_MORE -
-// form a GROUP: one pool context, one launch (k_verify_fused_batches / k_verify_cached_lane2r_batches),
+// form a GROUP: one pool context, one launch (hs_ed25519_verify_device_batches[_cached], which picks its kernel by the
+// group's size: one signature per quad, the pairs form, or the one-lane pair from eight members),
 // each member with its own slice of the pinned staging and its own bitmap.  A group launches when a
 // member arrives without the flag, when it is full, when a call of another kind follows, or when any
 // of its tickets is waited on or polled - never by a timer, and never later than that: a lone
 // synchronous call launches at once, exactly as before.  Groups are per thread (a burst is not
 // diluted by other threads' calls); tickets may be waited on from any thread.
-static const unsigned kGroupMax = 4;
+static const unsigned kGroupMax = 16;       // = HS_MAX_BATCHES_PER_LAUNCH: one launch of hs_ed25519_verify_device_batches[_cached]
 struct host_group {
     std::mutex mu;
     std::condition_variable cv;
