@@ -150,10 +150,14 @@ int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size
  * launches): a node under load has many certificates pending, and a 1,024-signature batch alone is only one
  * wavefront per SIMD of the slice of the chip its stream runs on.  Every batch keeps its own digests, bitmap and reject counter;
  * n <= 32,768 and mode BATCH or STRICT for each.  Pointer rules as for hs_ed25519_verify_device.
- * From four batches per call on, the library runs the PAIRS form of the kernel (k_verify_fused_pairs_batches: every
- * quad of lanes verifies two signatures one after the other, so the four lanes decompress A, R of both at once instead
- * of two of them idling - 11 % less arithmetic per verification, 1.85x the latency of a launch); below, latency wins
- * and the one-signature-per-quad form runs.  Same accept set. */
+ * The library picks the kernel by what one call hands over (hs_ed25519_batches_kernel_for): up to three batches the
+ * one-signature-per-quad form (latency: 0.56 ms per two 1,024-signature batches); from four the PAIRS form
+ * (k_verify_fused_pairs_batches: every quad of lanes verifies two signatures one after the other, so the four lanes
+ * decompress A, R of both at once instead of two of them idling - 11 % less arithmetic, 1 ms per four batches); from
+ * eight batches totalling 8,192 signatures the ONE-LANE pair over the batch list (k_prepare_batches +
+ * k_verify_batches: no lane algebra, the least work per verification - 72 M verifies/s at eight, 86-88 M at sixteen
+ * batches per launch against 64 M and 57 M for the forms above - at 1.7 / 3 ms per launch pair; it uses the context's
+ * workspace, which grows on first use).  Same accept set in every form. */
 typedef struct hs_ed25519_batch {
     const uint8_t *d_digests; size_t digest_stride;
     const uint8_t *d_pks, *d_sigs;
@@ -268,7 +272,8 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
  * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 98,304, the
  * one-lane kernel above), 1 = the one-lane-per-signature kernels, 3 = the fused / two-lane
  * kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
- * the batch count (3 pins it to the one-signature-per-quad form).  All have the same accept set.  Returns the previous choice or
+ * the batch count (3 pins it to the one-signature-per-quad form, 1 to the one-lane pair over the
+ * batch list).  All have the same accept set.  Returns the previous choice or
  * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
  * with -DHS_AB_VARIANTS and are not part of the shipped library.) */
 int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
