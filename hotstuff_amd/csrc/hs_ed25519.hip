@@ -560,17 +560,17 @@ k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict_
     cached_lane2r_block(s_r, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
 }
 
-// the throughput form: one lane per signature (verify_cached_lane), for the largest batches
-__global__ void __launch_bounds__(64)
-k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
-                     const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+// the throughput form: one lane per signature (verify_cached_lane), for the largest batches and for long batch lists
+// `block` = this wavefront's index within its batch (64 signatures per wavefront)
+__device__ __forceinline__ void cached_lane_block(u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
+                                                  const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                                                  unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     if (skip && *skip) {
-        const u32 lanes = min(64u, n - blockIdx.x * 64);
-        if (threadIdx.x == 0) bitmap[blockIdx.x] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
+        const u32 lanes = min(64u, n - block * 64);
+        if (threadIdx.x == 0) bitmap[block] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
         return;
     }
-    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    const u32 i = block * 64 + threadIdx.x;
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
     const u32 ki_raw = key_idx[j];
@@ -588,13 +588,29 @@ k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg
     const bool curve = verify_cached_lane(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
     const unsigned long long mask = __ballot(ok && curve && active);
     if (threadIdx.x == 0) {
-        bitmap[blockIdx.x] = mask;
+        bitmap[block] = mask;
         if (nreject) {
-            const u32 lanes = min(64u, n - blockIdx.x * 64);
+            const u32 lanes = min(64u, n - block * 64);
             const u32 bad = lanes - (u32)__popcll(mask);
             if (bad) atomicAdd(nreject, bad);
         }
     }
+}
+__global__ void __launch_bounds__(64)
+k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
+                     const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    cached_lane_block(blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, bitmap, nreject, skip);
+}
+// the same over a list of batches (hs_ed25519_verify_device_batches_cached with HS_K_LANE on the context)
+__global__ void __launch_bounds__(64)
+k_verify_cached_lane_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cached_batch_list L) {
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const cached_batch &B = L.b[k];
+    cached_lane_block(blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode,
+                      (unsigned long long *)B.bitmap32, B.nreject, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1117,6 +1133,10 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
         hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
         if (ev) ctx->ev_mid[slot] = 0;
         void *a[] = { &kv, &nkeys, &p_bt, &L };
+        if (ctx->kernel == HS_K_LANE)
+            HS_HIP(launch1((const void *)k_verify_cached_lane_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+                   "launch k_verify_cached_lane_batches");
+        else
         HS_HIP(launch1((const void *)k_verify_cached_lane2r_batches, dim3(blocks), dim3(192), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane2r_batches");
     }

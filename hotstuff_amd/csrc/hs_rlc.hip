@@ -51,7 +51,12 @@ struct rlc_keys_src {            // where signature i's key bytes / curve flag c
 // (two SHA-512 blocks, two 256 x 256-bit products mod L, 64 digit bytes) is as long a chain as a decompression: on
 // the lane that also decompressed R it made k_rlc_prepare 0.29 ms at 66,667 signatures, of which only 0.04 ms went
 // away when the A decompressions did.
-__global__ void __launch_bounds__(64, 3)
+// (64, 2), not (64, 3): asked for three wavefronts per SIMD the compiler pins 168 VGPRs and spills 252 B per lane; asked
+// for two it needs 159 and spills nothing - three still fit a SIMD.  Same speed (A/B: -DHS_RLC_PREPARE_WAVES=3), no scratch.
+#ifndef HS_RLC_PREPARE_WAVES
+#define HS_RLC_PREPARE_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, HS_RLC_PREPARE_WAVES)
 k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u32 *__restrict__ sigs, u32 n) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) rlc_store_identity_record(v.rec + (size_t)HS_RLC_REC_WORDS * 2 * v.np);

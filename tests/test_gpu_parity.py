@@ -426,10 +426,12 @@ def test_edge_vectors_through_batches_per_launch(edge_vectors, torsion_fuzz, ker
     ctx.close()
 
 
-def test_several_key_cache_batches_in_one_launch(oracle):
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_AUTO, _lib.KERNEL_LANE])
+def test_several_key_cache_batches_in_one_launch(oracle, kernel):
     """hs_ed25519_verify_device_batches_cached: 18 independent batches (two grids) against one key set - different
     sizes, digest forms and modes, permuted / repeated / unknown key indices, corrupted signatures - each with its
-    own bitmap and reject counter; verdicts vs the oracle (an unknown index is a rejected signature)."""
+    own bitmap and reject counter; verdicts vs the oracle (an unknown index is a rejected signature).  Through the
+    default kernel (two lanes per signature + R wavefront) and the one-lane kernel over the batch list."""
     import random
     dev = torch.device("cuda", 0)
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
@@ -439,6 +441,7 @@ def test_several_key_cache_batches_in_one_launch(oracle):
     ks = _lib.KeySet(keys)
     sizes = [1, 2, 31, 32, 33, 63, 64, 65, 127, 200, 300, 1024, 1000, 5, 129, 700, 257, 64]
     ctx = _lib.DeviceContext(1024)
+    ctx.set_kernel(kernel)
     rng = random.Random(11)
     keep, entries, expect = [], [], []
     nr = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
