@@ -85,13 +85,16 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
 // (profiles/r2_sweeps.md section 2: 74 M/s against the pairs form's 65), at several times the latency of a launch.
 // Every batch has its own workspace slice, digests, bitmap and reject counter.
 #define HS_MAX_BATCHES_PER_LAUNCH 16
+#ifndef HS_MAX_LANE_BATCHES
+#define HS_MAX_LANE_BATCHES 16          // measured with 32 (3 KB of kernel arguments): 87.5 M verifies/s against 87.2 at 16 - saturated
+#endif
 struct lane_batch { workspace ws; msg_src msgs; const u32 *pks, *sigs; unsigned long long *bitmap; u32 *nreject; u32 n, mode, first_p, first_v; };
-struct lane_batch_list { lane_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+struct lane_batch_list { lane_batch b[HS_MAX_LANE_BATCHES]; u32 count; };
 __global__ void __launch_bounds__(64, 3)
 k_prepare_batches(lane_batch_list L) {
     u32 k = 0;
 #pragma unroll
-    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_p) k = t;
+    for (u32 t = 1; t < HS_MAX_LANE_BATCHES; t++) if (t < L.count && blockIdx.x >= L.b[t].first_p) k = t;
     const lane_batch &B = L.b[k];
     const u32 t = (blockIdx.x - B.first_p) * 64 + threadIdx.x;
     if (t >= 2 * B.n) return;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(64)
 k_verify_batches(lane_batch_list L) {
     u32 k = 0;
 #pragma unroll
-    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_v) k = t;
+    for (u32 t = 1; t < HS_MAX_LANE_BATCHES; t++) if (t < L.count && blockIdx.x >= L.b[t].first_v) k = t;
     const lane_batch &B = L.b[k];
     const u32 block = blockIdx.x - B.first_v;
     const u32 i = block * 64 + threadIdx.x;
@@ -1020,7 +1023,7 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
         lane_batch_list L;
         L.count = 0;
         u32 pw = 0, vw = 0;
-        for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
+        for (; done < count && L.count < HS_MAX_LANE_BATCHES; done++) {
             const hs_ed25519_batch &b = batches[done];
             if (b.n == 0) continue;
             if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches: mode must be BATCH / STRICT and n <= 32,768");
