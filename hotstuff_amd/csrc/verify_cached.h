@@ -271,28 +271,64 @@ HS_HD void ge_add_tab(ge_p3 &r, const ge_p3 &p, const tab_entry &e, bool neg) {
     fe_select(G, zs, zd, neg);                    // G = D +- C
     fe_mul(r.X, E, F); fe_mul(r.Y, G, H); fe_mul(r.Z, F, G); fe_mul(r.T, E, H);
 }
+// The same addition in two halves, so that a chain can fetch its NEXT entry between them: the first half is the only
+// one that reads the entry (three multiplications), the second (four multiplications, ~600 instructions) then covers
+// the gather's latency - a table line is a first touch in a multi-GB table, 1-2 us away.  Left to the compiler the ten
+// loads of an entry sit ~50 instructions ahead of their first use.
+struct add_tab_half { fe a, b, c; };
+HS_HD void ge_add_tab_first(add_tab_half &h, const ge_p3 &p, const tab_entry &e, bool neg) {
+    fe qa, qb, t;
+    fe_select(qa, e.ymx, e.ypx, neg);
+    fe_select(qb, e.ypx, e.ymx, neg);
+    fe_sub(t, p.Y, p.X); fe_mul(h.a, t, qa);
+    fe_add(t, p.Y, p.X); fe_mul(h.b, t, qb);
+    fe_mul(h.c, p.T, e.t2d);
+}
+HS_HD void ge_add_tab_second(ge_p3 &r, const ge_p3 &p, const add_tab_half &h, bool neg) {
+    fe d, E, H, zs, zd, F, G;
+    fe_add(d, p.Z, p.Z); fe_carry(d);
+    fe_sub(E, h.b, h.a);
+    fe_add(H, h.b, h.a);
+    fe_add(zs, d, h.c);
+    fe_sub(zd, d, h.c);
+    fe_select(F, zd, zs, neg);
+    fe_select(G, zs, zd, neg);
+    fe_mul(r.X, E, F); fe_mul(r.Y, G, H); fe_mul(r.Z, F, G); fe_mul(r.T, E, H);
+}
 // sum_w T[w][d_w] over the 32 windows of one table and one radix-256 recoded scalar
 HS_HD void cached_chain(ge_p3 &acc, const u32 *tab, u32 dw[8]) {
     ge_identity(acc);
+    tab_entry e;
+    int d = sc_pop_digit8(dw);
+    load_tab_entry(e, tab + ((size_t)(HS_KS_WINDOWS - 1) * HS_KS_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
 #pragma nounroll
     for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
-        const int d = sc_pop_digit8(dw);
-        const int id = d < 0 ? -d : d;
-        tab_entry e;
-        load_tab_entry(e, tab + ((size_t)w * HS_KS_ENTRIES + id) * HS_KS_ENTRY_WORDS);
-        ge_add_tab(acc, acc, e, d < 0);
+        const bool neg = d < 0;
+        add_tab_half h;
+        ge_add_tab_first(h, acc, e, neg);
+        if (w > 0) {            // the next window's entry, fetched behind the second half
+            d = sc_pop_digit8(dw);
+            load_tab_entry(e, tab + ((size_t)(w - 1) * HS_KS_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
+        }
+        ge_add_tab_second(acc, acc, h, neg);
     }
 }
 // sum_w T_B16[w][d_w] over the 16 windows of the base point's 16-bit table and a radix-65536 recoded scalar
 HS_HD void cached_chain16(ge_p3 &acc, const u32 *b16, u32 dw[8]) {
     ge_identity(acc);
+    tab_entry e;
+    int d = sc_pop_digit16(dw);
+    load_tab_entry(e, b16 + ((size_t)(HS_B16_WINDOWS - 1) * HS_B16_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
 #pragma nounroll
     for (int w = HS_B16_WINDOWS - 1; w >= 0; w--) {
-        const int d = sc_pop_digit16(dw);
-        const int id = d < 0 ? -d : d;
-        tab_entry e;
-        load_tab_entry(e, b16 + ((size_t)w * HS_B16_ENTRIES + id) * HS_KS_ENTRY_WORDS);
-        ge_add_tab(acc, acc, e, d < 0);
+        const bool neg = d < 0;
+        add_tab_half h;
+        ge_add_tab_first(h, acc, e, neg);
+        if (w > 0) {
+            d = sc_pop_digit16(dw);
+            load_tab_entry(e, b16 + ((size_t)(w - 1) * HS_B16_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
+        }
+        ge_add_tab_second(acc, acc, h, neg);
     }
 }
 // Entry j of window w of the 16-bit base table, PROJECTIVE (Y-X, Y+X, 2dT, 2Z; 40 words - what keyset_affine_group
@@ -402,13 +438,17 @@ HS_HD void lane2_split_chain(ge_p3 &mine, const u32 *atab, const u32 *b16, const
     lane2_split ls;
     lane2_split_init(ls, kw, sw, odd);
     ge_identity(mine);
+    tab_entry e;
+    bool neg;
+    load_tab_entry(e, lane2_split_step(ls, 0, odd, atab, b16, neg));
 #pragma nounroll
     for (int t = 0; t < 24; t++) {
-        bool neg;
-        const u32 *p = lane2_split_step(ls, t, odd, atab, b16, neg);
-        tab_entry e;
-        load_tab_entry(e, p);
-        ge_add_tab(mine, mine, e, neg);
+        add_tab_half h;
+        ge_add_tab_first(h, mine, e, neg);
+        bool neg_next = false;
+        if (t + 1 < 24) load_tab_entry(e, lane2_split_step(ls, t + 1, odd, atab, b16, neg_next));   // fetched behind the second half
+        ge_add_tab_second(mine, mine, h, neg);
+        neg = neg_next;
     }
 }
 #if defined(__HIPCC__)
