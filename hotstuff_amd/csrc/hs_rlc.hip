@@ -39,6 +39,7 @@ using namespace hs;
 #define fail hs::hs_fail
 
 // ------------------------------------------------------------------------------------------ device
+#define HS_RLC_CSUM_SLOTS 64
 struct rlc_keys_src {            // where signature i's key bytes / curve flag come from
     const u32 *pks;              // cold: n x 8 words (and the A points are decompressed here)
     const u32 *key_idx;          // key set: n indices ...
@@ -60,8 +61,12 @@ __global__ void __launch_bounds__(64, HS_RLC_PREPARE_WAVES)
 k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u32 *__restrict__ sigs, u32 n) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) rlc_store_identity_record(v.rec + (size_t)HS_RLC_REC_WORDS * 2 * v.np);
-    const u32 kind = t / v.np, i0 = t - kind * v.np;         // np lanes per kind: whole wavefronts are of one kind
+    u32 kind = t / v.np;                                     // np lanes per kind: whole wavefronts are of one kind
+    const u32 i0 = t - kind * v.np;
     if (kind >= (keys.pks ? 3u : 2u)) return;
+    // launch order R, A, scalars: the scalar tasks are ~0.4 of a decompression long, so the wavefronts that do not fit the
+    // chip's first round (3,126 against 3,072 slots at 66,667 signatures) are short ones: k_rlc_prepare 270 -> 234 us there
+    if (keys.pks) kind = kind == 1 ? 2u : (kind == 2 ? 1u : 0u);
     const bool active = i0 < n;
     if (kind != 1 && !active) return;
     const u32 i = active ? i0 : n - 1;                       // idle lanes of a scalar wavefront shadow the last signature (shuffles below)
@@ -88,7 +93,9 @@ k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u3
             for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
             c64[j] = x;
         }
-        if (threadIdx.x == 0) rlc_add_csum(v.csum, c64);
+        // one of HS_RLC_CSUM_SLOTS copies of the eight limb sums, by wavefront: 1,042 wavefronts adding into the SAME eight
+        // addresses cost 70 of k_rlc_prepare's 270 us at 66,667 signatures (same-address atomics serialise in the L2)
+        if (threadIdx.x == 0) rlc_add_csum(v.csum + 8 * (blockIdx.x % HS_RLC_CSUM_SLOTS), c64);
     } else {
         u32 enc[8];
 #pragma unroll
@@ -282,7 +289,13 @@ k_rlc_reduce(const u32 *__restrict__ part, const u32 *__restrict__ segoff, u32 L
     const u32 w = blockIdx.x, j = threadIdx.x, wave = j >> 6, lane = j & 63u;
     if (w == HS_RLC_WINDOWS) {         // [b]B on one quad: 32 table additions of two vector multiplications each
         if (j >= 4) return;
-        const qv bb = rlc_b_point_quad(btab, csum);
+        unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // fold the slot copies (64-bit lazy sums: 2^20 signatures of 2^32 fit)
+#pragma nounroll
+        for (u32 sl = 0; sl < HS_RLC_CSUM_SLOTS; sl++) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) tot[t] += csum[8 * sl + t];
+        }
+        const qv bb = rlc_b_point_quad(btab, tot);
         rlc_store_wsum_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS, bb);
         return;
     }
@@ -345,7 +358,7 @@ struct rlc_ws {
     size_t np = 0;                 // capacity in (padded) signatures
     u32 *rec = nullptr; uint8_t *dig = nullptr; u32 *sorted = nullptr, *part = nullptr, *wsum = nullptr;
     u32 *tabs = nullptr;           // ghist | boff | segoff | gcur, each [32][129]
-    uint8_t *small = nullptr;      // csum[8] (64 B) | failed (4) | ok (4) | pad
+    uint8_t *small = nullptr;      // failed (4) | ok (4) | pad to 64 | csum[HS_RLC_CSUM_SLOTS][8] (64 B each)
     size_t min_batch = 0;          // 0 = the library default
     size_t calls = 0;
 };
@@ -358,6 +371,7 @@ bool g_key_set = false;
 // throughput from ~12,000 signatures and latency from ~20,000 (0.67 vs 0.73 ms at 24,576; 0.91 vs 1.76 ms at 66,667).
 const size_t kRlcMinBatch = 20480;
 const u32 kTabWords = HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1);
+const size_t kSmallBytes = 64 + (size_t)HS_RLC_CSUM_SLOTS * 64;
 const u32 kMinChunk = 8;
 
 void ws_free(rlc_ws *w) {
@@ -405,7 +419,7 @@ int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream) {
     HS_HIP(hipMalloc((void **)&w->part, (size_t)HS_RLC_WINDOWS * lane_cap(np, kMinChunk) * 160), "hipMalloc rlc partials");
     HS_HIP(hipMalloc((void **)&w->wsum, (size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS * 4), "hipMalloc rlc window sums");
     HS_HIP(hipMalloc((void **)&w->tabs, (size_t)4 * kTabWords * 4), "hipMalloc rlc offsets");
-    HS_HIP(hipMalloc((void **)&w->small, 128), "hipMalloc rlc flags");
+    HS_HIP(hipMalloc((void **)&w->small, kSmallBytes), "hipMalloc rlc flags");
     w->np = np;
     return 0;
 }
@@ -448,7 +462,7 @@ extern "C" int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls) {
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(ctx->stream), "stream sync");
     u32 flags[2] = {0, 0};
-    HS_HIP(hipMemcpy(flags, w->small + 64, 8, hipMemcpyDeviceToHost), "read rlc flags");
+    HS_HIP(hipMemcpy(flags, w->small, 8, hipMemcpyDeviceToHost), "read rlc flags");        // failed, ok
     return flags[1] ? 1 : 0;
 }
 
@@ -474,10 +488,10 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     const u32 np = (u32)round_up(n, 64), NP = 2 * np, nn = (u32)n, C = chunk_for(n), Lcap = lane_cap(np, C);
     u32 G = NP / 16384; G = G < 1 ? 1 : (G > 16 ? 16 : G);
     rlc_view v;
-    v.rec = w->rec; v.dig = w->dig; v.csum = (unsigned long long *)w->small; v.failed = (u32 *)(w->small + 64); v.np = np;
-    u32 *ok_flag = (u32 *)(w->small + 68);
+    v.rec = w->rec; v.dig = w->dig; v.csum = (unsigned long long *)(w->small + 64); v.failed = (u32 *)w->small; v.np = np;
+    u32 *ok_flag = (u32 *)(w->small + 4);
     u32 *ghist = w->tabs, *boff = w->tabs + kTabWords, *segoff = w->tabs + 2 * kTabWords, *gcur = w->tabs + 3 * kTabWords;
-    HS_HIP(hipMemsetAsync(w->small, 0, 128, st), "rlc clear flags");
+    HS_HIP(hipMemsetAsync(w->small, 0, kSmallBytes, st), "rlc clear flags");
     HS_HIP(hipMemsetAsync(ghist, 0, (size_t)kTabWords * 4, st), "rlc clear histograms");
     HS_HIP(hipMemsetAsync(w->dig, 0x80, (size_t)HS_RLC_WINDOWS * NP, st), "rlc clear digits");
     rlc_keys_src keys;
