@@ -7,7 +7,8 @@
 //      [k](-A) + [s]B == R
 // can be tabled per key once per epoch.  With signed 8-bit windows
 //      [k](-A) = sum_w T_A[w][k_w],   T_A[w][j] = j * 2^(8w) * (-A),   w < 32, j <= 128
-// a verification is 32 + 32 table additions: no doublings, no decompression of A.  R' = sum is
+// and the base point's half on 16-bit windows (further down) a verification is 32 + 16 table additions: no
+// doublings, no decompression of A.  R' = sum is
 // then compared with R in one of two ways.  (a) Without decompressing R: invert Z once, compare
 // y' with the encoded y and the parity of x' with the sign bit (equivalent to dalek's "decompress
 // R, compare points": if y' = y_R the encoding is on the curve and decodes to (+-x', y'); the sign
@@ -15,7 +16,7 @@
 // wavefront of the workgroup decompressed meanwhile, as points: X == x_R Z, Y == y_R Z, Z != 0 -
 // the form the default kernels use, because it takes the 254-squaring chain off the addition chains.
 //
-// Cost: 64 additions + 1 inversion or square root, against 252 doublings + 96 additions + 2
+// Cost: 48 additions + 1 inversion or square root, against 252 doublings + 80 additions + 2
 // square roots for the cold path.  Price: 129 * 32 entries of 128 bytes = 528,384 bytes of HBM per key
 // (5.3 GB for 10,000 validators, 53 GB for 100,000 - MI355X has 288 GB).
 //
