@@ -257,6 +257,26 @@ void emu_sc_digits16(const uint8_t *s, int32_t *digits) {
     u32 w[8], r[8]; load_words(w, s, 8); sc_recode65536(r, w);
     for (int i = 0; i < 16; i++) digits[i] = sc_pop_digit16(r);
 }
+// The two-lane split of a key-cache verification (lane2_split_*): for lane `odd` and step t = 0..23 write
+// (table: 0 = the key's, 1 = the base point's 16-bit table; window; signed digit) as three int32 each - recovered from
+// the entry pointer the step returns, exactly as the kernel would dereference it.
+void emu_lane2_split_trace(const uint8_t *k32, const uint8_t *s32, int odd, int32_t *out /* 24 x 3 */) {
+    u32 k[8], sc[8], kw[8], sw[8];
+    load_words(k, k32, 8); load_words(sc, s32, 8);
+    sc_recode256(kw, k); sc_recode65536(sw, sc);
+    const uintptr_t A = 0x1000000000ull, Bq = 0x9000000000ull;       // two far-apart fake table bases: only pointer arithmetic happens
+    lane2_split ls;
+    lane2_split_init(ls, kw, sw, odd != 0);
+    for (int t = 0; t < 24; t++) {
+        bool neg;
+        const u32 *p = lane2_split_step(ls, t, odd != 0, (const u32 *)A, (const u32 *)Bq, neg);
+        const uintptr_t a = (uintptr_t)p;
+        const bool base = a >= Bq;
+        const uint64_t idx = (a - (base ? Bq : A)) / (4 * HS_KS_ENTRY_WORDS);
+        const uint64_t per = base ? HS_B16_ENTRIES : HS_KS_ENTRIES;
+        out[3 * t] = base ? 1 : 0; out[3 * t + 1] = (int32_t)(idx / per); out[3 * t + 2] = (int32_t)(idx % per) * (neg ? -1 : 1);
+    }
+}
 // lane_form = 1: the one-lane-per-signature core (verify_cached_lane), 0: the quad core
 static int g_cached_lane_form = 0;
 void emu_cached_set_lane_form(int v) { g_cached_lane_form = v; }

@@ -199,6 +199,29 @@ def test_base_point_16_bit_table(emu):
         assert sum(d << (16 * (15 - i)) for i, d in enumerate(dg)) == sc
 
 
+def test_two_lane_split_covers_every_window_once(emu):
+    """lane2_split_* (the default key-cache kernel's work split): over the two lanes' 24 steps each of the key's 32
+    8-bit windows and each of the base point's 16 16-bit windows appears exactly once, with the digit of k resp. s that
+    belongs to it - so that sum_w T_A[w][k_w] + sum_w T_B16[w][s_w] = [k](-A) + [s]B."""
+    rng = random.Random(24)
+    tr = (ctypes.c_int32 * 72)()
+    for _ in range(100):
+        k = rng.randrange(E.L) if rng.random() < 0.8 else rng.choice([0, 1, E.L - 1, (1 << 252) - 1, 128, 0x8000, (1 << 253) - 1])
+        sc = rng.randrange(E.L) if rng.random() < 0.8 else rng.choice([0, 1, E.L - 1, 0x7fff, 0x8000, (1 << 252) + 5])
+        key_digits, base_digits = {}, {}
+        for odd in (0, 1):
+            emu.emu_lane2_split_trace(k.to_bytes(32, "little"), sc.to_bytes(32, "little"), odd, tr)
+            for t in range(24):
+                tab, w, d = tr[3 * t], tr[3 * t + 1], tr[3 * t + 2]
+                dst = base_digits if tab else key_digits
+                assert w not in dst, (odd, t, tab, w)
+                dst[w] = d
+        assert sorted(key_digits) == list(range(32)) and sorted(base_digits) == list(range(16))
+        assert all(-128 <= d <= 128 for d in key_digits.values()) and all(-32768 <= d <= 32768 for d in base_digits.values())
+        assert sum(d << (8 * w) for w, d in key_digits.items()) == k
+        assert sum(d << (16 * w) for w, d in base_digits.items()) == sc
+
+
 def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode, lane_form=0):
     import numpy as np
     emu.emu_cached_set_lane_form(lane_form)
