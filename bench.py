@@ -319,7 +319,8 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
     out = {"n_validators": validators, "signatures": n, "ranks": world, "signatures_per_shard": S,
-           "exchange": "RCCL all-gather of %d-byte accept bitmaps, one per QC" % (S // 8), "calls": iters}
+           "exchange": "%s all-gather of %d-byte accept bitmaps, one per QC"
+                       % ("RCCL" if dist.get_backend() == "nccl" else "gloo (ranks share a device: rehearsal)", S // 8), "calls": iters}
     for cached in (False, True):
         ks = d_ki = None
         if cached:
@@ -339,7 +340,7 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
             ok, _bm = sharding.verify_sharded(v, n)
             times.append(time.perf_counter() - t0)
             assert ok, "sharded QC rejected"
-        tot = torch.tensor([sum(times)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([sum(times)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tot, op=dist.ReduceOp.MAX)
         times.sort()
         out["key_cache" if cached else "cold"] = {
@@ -352,14 +353,17 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
-               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16))):
+               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16)),
+               pinned_shapes=((1, 64, 16), (1, 32, 8), (1, 64, 4), (4, 32, 16))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
-    `threads` NATIVE host threads (hs_ed25519_loadgen - interpreter threads would measure the interpreter lock) each
-    verify their own 1,024-tuple batch in a loop; every call stages into pinned memory, launches on a pool context's
-    CU-partitioned stream and waits for its verdict.  PCIe-inclusive.  Rows: the synchronous calls
-    (hs_ed25519_verify_multi) from 1, threads/2 and threads threads, then the asynchronous form
-    (hs_ed25519_submit / hs_ed25519_ticket_wait) as (threads, tickets in flight per thread, batches per launch)."""
-    lib = _lib.lib()
+    `threads` NATIVE host threads (tools/libhs_loadgen.so, a client of the public ABI - interpreter threads would measure
+    the interpreter lock) each verify their own 1,024-tuple batch in a loop; every call stages into pinned memory,
+    launches on a pool context's CU-partitioned stream and waits for its verdict.  PCIe-inclusive.  Rows: the synchronous
+    calls (hs_ed25519_verify_multi) from 1, threads/2 and threads threads, then the asynchronous form
+    (hs_ed25519_submit / hs_ed25519_ticket_wait) as (threads, tickets in flight per thread, batches per launch).
+    `caller_pinned` rows: the same calls on buffers the caller allocated with hs_ed25519_host_alloc - the engine then reads
+    them in place instead of copying them into its staging (what the shim's packing of Vec<(PublicKey, Signature)> straight
+    into such memory gives): the reference's caller is ONE task, and one thread's bursts of sixteen are bound by that copy."""
     dg = b"".join(b[0] for b in batches)
     pk = b"".join(b[1] for b in batches)
     sg = b"".join(b[2] for b in batches)
@@ -374,16 +378,78 @@ def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
     # the asynchronous form (hs_ed25519_submit / hs_ed25519_ticket_wait) with the same threads
     shapes = [(th, 1, 1) for th in sorted({1, threads // 2, threads}) if th >= 1]
     shapes += [(th, k, bpl) for th, k, bpl in inflight]
+
+    def run(ptrs, th, k, bpl):
+        calls, p50, el = _lib.loadgen(None, ptrs[0], stride, ptrs[1], ptrs[2], n, len(batches), mode, th, k, bpl,
+                                      seconds if th == threads else seconds / 2)
+        return {"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": bpl, "calls": calls, "seconds": round(el, 3),
+                "call_p50_ms": round(p50, 4), "value": round(calls * n / el, 1)}
     for th, k, bpl in shapes:
-        calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.hs_ed25519_loadgen(None, a[0], stride, a[1], a[2], n, len(batches), mode, th, k, bpl, seconds if th == threads else seconds / 2,
-                                          ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el)), "hs_ed25519_loadgen")
-        row = {"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": bpl, "calls": calls.value, "seconds": round(el.value, 3),
-               "call_p50_ms": round(p50.value, 4), "value": round(calls.value * n / el.value, 1)}
+        row = run(a, th, k, bpl)
         out.setdefault("by_threads", []).append(row)
         if best is None or row["value"] > best["value"]:
             best = row
     out.update(best)
+    try:
+        pin = [_lib.PinnedBuffer(x) for x in (dg, pk, sg)]
+        pa = [x.addr for x in pin]
+        out["caller_pinned"] = {"buffers": "hs_ed25519_host_alloc (pinned, device-mapped): read in place, no staging copy",
+                                "rows": [run(pa, th, k, bpl) for th, k, bpl in pinned_shapes]}
+        for x in pin:
+            x.close()
+    except Exception as e:
+        out["caller_pinned"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def multi_process(n=1024, procs=(1, 2, 4), seconds=1.0, timeout_s=120):
+    """several node processes share one GPU (the reference's `fab local` starts four node processes on one
+    host, benchmark/benchmark/local.py:94-104).  k independent PROCESSES (tools/mp_worker.py, each its own HIP context,
+    pools and streams on device 0) run the end-to-end host-buffer load at once - ticket bursts of four 1,024-signature
+    batches from 4 native threads each - started together; aggregate verifies/s and the median call latency, without and
+    with the tenancy hint (hs_ed25519_set_tenancy: each process 1/k of the stream budget and its own slice of the CUs)."""
+    out = {"signatures_per_call": n, "seconds": seconds, "worker": "tools/mp_worker.py: 4 native threads x 8 tickets, bursts of four",
+           "rows": []}
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                              "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    for k in procs:
+        for tenancy in ((False,) if k == 1 else (False, True)):
+            ps = []
+            try:
+                for i in range(k):
+                    env = dict(env0)
+                    if tenancy:
+                        env["HS_ED25519_TENANTS"], env["HS_ED25519_TENANT_INDEX"] = str(k), str(i)
+                    ps.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "mp_worker.py"), str(n), str(seconds), str(i)],
+                                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env))
+                t_end = time.time() + timeout_s
+                for p in ps:            # every worker has initialised, registered nothing else, and waits for the start signal
+                    line = p.stdout.readline()
+                    if not line.startswith("ready"):
+                        raise RuntimeError("worker did not come up: %r" % line[:200])
+                for p in ps:
+                    p.stdin.write("go\n"); p.stdin.flush()
+                res = []
+                for p in ps:
+                    o, _ = p.communicate(timeout=max(1.0, t_end - time.time()))
+                    res.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+                if any("error" in r for r in res):
+                    raise RuntimeError(str([r["error"] for r in res if "error" in r][:2]))
+                out["rows"].append({"processes": k, "tenancy_hint": tenancy, "value": round(sum(r["verifies_per_s"] for r in res), 1),
+                                    "per_process": [round(r["verifies_per_s"], 1) for r in res],
+                                    "call_p50_ms": round(sorted(r["p50_ms"] for r in res)[len(res) // 2], 4),
+                                    "verdict_errors": sum(r.get("verdict_errors", 0) for r in res)})
+            except Exception as e:
+                out["rows"].append({"processes": k, "tenancy_hint": tenancy, "error": "%s: %s" % (type(e).__name__, e)})
+            finally:
+                for p in ps:
+                    if p.poll() is None:
+                        p.kill()
+    one = [r["value"] for r in out["rows"] if r.get("processes") == 1 and "value" in r]
+    if one:
+        for r in out["rows"]:
+            if "value" in r:
+                r["vs_one_process"] = round(r["value"] / one[0], 3)
     return out
 
 
@@ -484,7 +550,7 @@ def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
     return out
 
 
-def sharded_c_abi(ngpus, validators=100000, timeout_s=150):
+def sharded_c_abi(ngpus, ndev, validators=100000, timeout_s=150):
     """BASELINE configs[3] from ONE process through the C ABI (hs_ed25519_init_devices +
     hs_ed25519_verify_shared_sharded; host and in-process RCCL exchange; per-signature and RLC): tools/sharded_c_abi.py,
     run in a SUBPROCESS with a timeout - this path has never run on multi-GPU hardware, and a fault or a hang there
@@ -492,7 +558,7 @@ def sharded_c_abi(ngpus, validators=100000, timeout_s=150):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                               "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_c_abi.py"), str(ngpus), str(validators)],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_c_abi.py"), str(ngpus), str(validators), "30", str(ndev)],
                            capture_output=True, text=True, timeout=timeout_s, env=env)
     except subprocess.TimeoutExpired:
         return {"error": "tools/sharded_c_abi.py did not finish within %d s" % timeout_s}
@@ -500,6 +566,50 @@ def sharded_c_abi(ngpus, validators=100000, timeout_s=150):
     if r.returncode != 0 or not lines:
         return {"error": "tools/sharded_c_abi.py exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
     return json.loads(lines[-1])
+
+
+def launcher_command(ngpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when it was started WITHOUT a launcher
+    (WORLD_SIZE unset): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container's
+    host name may not resolve).  The driver's own launch line is the same command, so both invocations run the
+    same ranks."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+class line_watchdog:
+    """Multi-GPU extras run AFTER the headline has been measured.  A collective that hangs there (this path has
+    never seen a second device before the driver's SCALE run) blocks the main thread inside the runtime, and the
+    process-group watchdog then aborts the process - with the headline unprinted.  Armed with the finished
+    headline line, this prints it (with the extra marked as timed out) and ends the process when `seconds` pass
+    without disarm()."""
+
+    def __init__(self, fd):
+        import threading
+        self.fd, self.ev, self.th, self.threading = fd, None, None, threading
+
+    def arm(self, make_line, seconds):
+        self.disarm()
+        ev = self.ev = self.threading.Event()
+
+        def run():
+            if not ev.wait(seconds):
+                try:
+                    os.write(self.fd, (make_line() + "\n").encode())
+                finally:
+                    os._exit(0)
+        self.th = self.threading.Thread(target=run, daemon=True)
+        self.th.start()
+
+    def disarm(self):
+        if self.ev is not None:
+            self.ev.set()
+            self.ev = None
 
 
 def main():
@@ -532,6 +642,11 @@ def main():
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
                          "default 8 (one XCD each, two stream contexts per slice) for batches up to 4,096 signatures, 0 above)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become one (same ranks the driver's torch.distributed.run line starts)
+        cmd = launcher_command(args.gpus, sys.argv[1:])
+        print("bench: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.execv(cmd[0], cmd)
     if args.partitions is None:
         env = os.environ.get("HS_BENCH_PARTITIONS")
         # 8 slices of 32 CUs = one XCD (its own L2) each, two stream contexts per slice: measured best for the quad kernels
@@ -554,17 +669,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        print("bench: --gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` (it launches its own ranks) or "
+              "torch.distributed.run --nproc-per-node N" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()
+    print("bench: rank %d/%d up, %d GPU(s) visible" % (rank, world, ndev), file=sys.stderr, flush=True)
+    if ndev == 0:
+        print("bench: rank %d: no GPU visible - the engine has no CPU path" % rank, file=sys.stderr, flush=True)
+        sys.exit(3)
+    # fewer GPUs than ranks (a 1-GPU rehearsal of `--gpus N`): ranks share devices, and since RCCL refuses two ranks on
+    # one device the control plane (barrier, max over ranks, the bitmaps' all-gather) runs over gloo; the line says so
+    virtual = ndev < world
+    device_index = local % ndev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     exchange = world > 1 or os.environ.get("HS_BENCH_FORCE_EXCHANGE") == "1"
+    backend = "gloo" if virtual else "nccl"
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                timeout=datetime.timedelta(seconds=180))
-    _lib.init(local, args.batch)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    _lib.init(device_index, args.batch)
 
     n = args.batch
     shared = args.shared
@@ -643,7 +774,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if exchange:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -792,14 +923,6 @@ def main():
                 break
     except Exception:
         pass
-    # ---- the workload that has an exchange step: one very large committee sharded over the GPUs
-    sharded = None
-    if exchange and not args.no_sharded:
-        try:        # an extra must never cost the headline line (a rank that fails here leaves the others to the
-            # process group's 180 s timeout, after which they report the error too)
-            sharded = sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, validators=args.large_committee)
-        except Exception as e:
-            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
     e2e = None
     if world == 1 and not args.no_extras:
         try:
@@ -856,15 +979,14 @@ def main():
                                    "mad_per_verify": MAD_PER_VERIFY[kname]}
         if e2e is not None:
             out["end_to_end"] = e2e
-        if sharded is not None:
-            out["sharded_committee"] = sharded
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
             for key, fn in (("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
-                            ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth))):
+                            ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
+                            ("multi_process", lambda: multi_process(n))):
                 try:
                     out[key] = fn()
                 except Exception as e:        # extras never cost the headline line
@@ -875,20 +997,50 @@ def main():
                 out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
             except Exception as e:
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    # ---- the same sharded workload from ONE process through the C ABI (rank 0 drives every GPU; the other
-    # ranks have released their contexts and wait at the barrier)
+    # ---- multi-GPU extras, AFTER the headline is complete.  Each runs under a deadline on rank 0: if a collective or
+    # a device hangs there, the finished headline is printed with the extra marked as timed out (line_watchdog).
+    dog = line_watchdog(real_stdout)
+    if rank == 0:
+        out["config"]["ranks"] = {"world": world, "gpus_visible": ndev, "control_plane": backend if exchange else "none",
+                                  "virtual_ranks": virtual,
+                                  "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}
+
+    def guarded(key, seconds, fn, every_rank):
+        """run extra `key` (on every rank, or on rank 0 while the others wait at the next barrier) under rank 0's deadline"""
+        if rank == 0:
+            def late():
+                o = dict(out)
+                o[key] = {"error": "did not finish within %d s; the line was printed by the watchdog, the ranks were abandoned" % seconds}
+                return json.dumps(o)
+            dog.arm(late, seconds)
+        res = None
+        try:
+            if every_rank or rank == 0:
+                res = fn()
+        except Exception as e:
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            dog.disarm()
+            out[key] = res
+
+    # the workload that has an exchange step: one very large committee sharded over the GPUs, one process per GPU,
+    # all-gather of the per-shard accept bitmaps (RCCL over xGMI; gloo when ranks share a device)
+    if exchange and not args.no_sharded:
+        guarded("sharded_committee", 150,
+                lambda: sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, validators=args.large_committee), True)
+    # the same sharded workload from ONE process through the C ABI (rank 0's subprocess drives every GPU; the other
+    # ranks have released their contexts and wait at the barrier below)
     if not args.no_sharded and (exchange or os.environ.get("HS_BENCH_SHARDED_C_ABI") == "1"):
         if exchange:
             dist.barrier()
-        if rank == 0:
-            try:
-                out["sharded_c_abi"] = sharded_c_abi(world, validators=args.large_committee)
-            except Exception as e:
-                out["sharded_c_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        guarded("sharded_c_abi", 170, lambda: sharded_c_abi(world, ndev, validators=args.large_committee), False)
     line = json.dumps(out) if rank == 0 else None
     if exchange:
+        if rank == 0:
+            dog.arm(lambda: line, 60)
         dist.barrier()
         dist.destroy_process_group()
+        dog.disarm()
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)     # C stdio buffers (still pointing at stderr)

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("HS_ED25519_LIB") or os.path.join(_HERE, "libhs_ed2551
 BATCH = 0
 STRICT = 1
 BATCH_RLC = 2          # dalek's verify_batch as computed: one random linear combination, per-signature fallback
+RLC_NOT_RUN = 2        # hs_ed25519_ctx_rlc_last: the RLC stage has not run on this context
 EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 KEYS_REPLICATE, KEYS_BY_OWNER = 0, 1
 
@@ -102,10 +103,14 @@ def lib():
                 l.hs_ed25519_ticket_device_slot.restype = ctypes.c_int
                 l.hs_ed25519_ticket_wait.argtypes = [vp, vp]
                 l.hs_ed25519_ticket_wait.restype = ctypes.c_int
-                l.hs_ed25519_loadgen.argtypes = [vp, vp, sz, vp, vp, sz, sz, u32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
-                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
-                                                 ctypes.POINTER(ctypes.c_double)]
-                l.hs_ed25519_loadgen.restype = ctypes.c_int
+                l.hs_ed25519_set_tenancy.argtypes = [ctypes.c_uint, ctypes.c_uint]
+                l.hs_ed25519_set_tenancy.restype = ctypes.c_int
+                l.hs_ed25519_host_alloc.argtypes = [sz]
+                l.hs_ed25519_host_alloc.restype = ctypes.c_void_p
+                l.hs_ed25519_host_free.argtypes = [vp]
+                l.hs_ed25519_host_free.restype = None
+                l.hs_ed25519_shard_rccl_ranks.argtypes = []
+                l.hs_ed25519_shard_rccl_ranks.restype = ctypes.c_int
                 l.hs_ed25519_verify_wire_shared.argtypes = [vp, vp, sz, u32, vp]
                 l.hs_ed25519_verify_wire_shared.restype = ctypes.c_int
                 l.hs_ed25519_verify_wire_tc.argtypes = [u64, vp, sz, vp]
@@ -236,6 +241,61 @@ def shard_plan(n, nshards, shard):
     lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
     check(lib().hs_ed25519_shard_plan(int(n), int(nshards), int(shard), ctypes.byref(lo), ctypes.byref(hi)), "hs_ed25519_shard_plan")
     return lo.value, hi.value
+
+
+def set_tenancy(tenants, index):
+    """This process is tenant `index` of `tenants` on its GPU (before init; include/hs_ed25519.h)."""
+    check(lib().hs_ed25519_set_tenancy(int(tenants), int(index)), "hs_ed25519_set_tenancy")
+
+
+class PinnedBuffer:
+    """hs_ed25519_host_alloc memory holding `data`: host calls on buffers that all live in such memory are read in
+    place by the kernels (no staging copy).  .addr is what to pass as a pointer."""
+
+    def __init__(self, data):
+        ensure_init()
+        self.n = len(data)
+        self.addr = lib().hs_ed25519_host_alloc(max(1, self.n))
+        if not self.addr:
+            raise EngineError("hs_ed25519_host_alloc failed: " + last_error())
+        ctypes.memmove(self.addr, bytes(data), self.n)
+
+    def close(self):
+        if getattr(self, "addr", None):
+            lib().hs_ed25519_host_free(self.addr)
+            self.addr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_loadgen = None
+
+
+def loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, inflight, batches_per_launch, seconds):
+    """tools/libhs_loadgen.so (a measurement aid over the public C ABI, not part of the product library): native
+    host threads drive the host-pointer API.  Pointers are raw addresses.  Returns (calls, p50_ms, elapsed_s)."""
+    global _loadgen
+    if _loadgen is None:
+        path = os.path.join(os.path.dirname(_HERE), "tools", "libhs_loadgen.so")
+        if not os.path.exists(path):
+            raise EngineError("tools/libhs_loadgen.so is missing: run __graft_entry__.build()")
+        lib()                                  # the product library first: the tool resolves its symbols against it
+        g = ctypes.CDLL(path)
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        g.hs_loadgen.argtypes = [vp, vp, sz, vp, vp, sz, sz, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_double,
+                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        g.hs_loadgen.restype = ctypes.c_int
+        _loadgen = g
+    calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+    rc = _loadgen.hs_loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, inflight, batches_per_launch, seconds,
+                             ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el))
+    if rc != 0:
+        raise EngineError("hs_loadgen failed (%d): %s" % (rc, last_error()))
+    return calls.value, p50.value, el.value
 
 
 def set_rlc_key(key):
@@ -597,11 +657,9 @@ class DeviceContext:
 
     def rlc_last(self):
         """(verdict of the RLC stage of the last BATCH_RLC call: 1 accepted outright, 0 fell through to the
-        per-signature kernels, -1 not run; calls that ran it).  Synchronises the context's stream."""
+        per-signature kernels, RLC_NOT_RUN (2) not run; calls that ran it).  Synchronises the context's stream."""
         c = ctypes.c_size_t()
-        r = lib().hs_ed25519_ctx_rlc_last(self._h, ctypes.byref(c))
-        if r < -1:          # -1 = "not run"; below that an engine error code
-            check(r, "hs_ed25519_ctx_rlc_last")
+        r = check(lib().hs_ed25519_ctx_rlc_last(self._h, ctypes.byref(c)), "hs_ed25519_ctx_rlc_last")
         return r, c.value
 
     def set_profiling(self, slots, every=1):

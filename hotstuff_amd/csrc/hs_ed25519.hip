@@ -659,6 +659,21 @@ static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (la
 // wavefronts of a SIMD then come from ONE launch and run 18 % longer; profiles/r2_e2e_async.txt).  The synchronous
 // calls pay for it at 16 concurrent callers (21.5 against 26.8 M verifies/s; equal up to 8 callers).
 unsigned hs::kPoolPartitions = 8;               // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
+// Several node processes on one GPU (the reference's `fab local` runs four node processes on one host,
+// benchmark/benchmark/local.py:94-104).  Every process brings its own pools - 16 narrow + 4 wide stream contexts - and
+// the device multiplexes all of them; past ~16 streams in flight throughput collapses (profiles/r1_stream_sweep.txt).
+// A process that knows it is tenant `index` of `tenants` on its GPU takes 1/tenants of the stream budget and confines its
+// narrow pool to its own 1/tenants of the CUs (XCD-aligned for 2, 4, 8 tenants), so co-tenants neither share hardware
+// queues nor stack their small batches on the same CUs.  hs_ed25519_set_tenancy before init, or the environment
+// (HS_ED25519_TENANTS / HS_ED25519_TENANT_INDEX); default 1 / 0 = the whole chip.
+unsigned hs::kTenants = 1, hs::kTenantIndex = 0;
+extern "C" int hs_ed25519_set_tenancy(unsigned tenants, unsigned index) {
+    if (tenants == 0 || tenants > 8 || index >= tenants) return hs::hs_fail(HS_ED25519_E_ARG, "set_tenancy: tenants in [1, 8], index < tenants");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init.load()) return hs::hs_fail(HS_ED25519_E_ARG, "set_tenancy: call it before hs_ed25519_init (or after hs_ed25519_shutdown)");
+    kTenants = tenants; kTenantIndex = index;
+    return 0;
+}
 
 int hs::dev_slots() { return g_init.load() ? (int)g_devs.size() : 0; }
 int hs::dev_ordinal(int slot) { return (slot >= 0 && slot < hs::dev_slots()) ? g_devs[slot].ordinal : -1; }
@@ -818,7 +833,21 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     // own; HIP's default of 4 multiplexes them (streamed rounds: 22 vs 34 M signatures/s).  The
     // runtime reads this when it initialises, so it only takes effect when this library is the
     // process's first HIP user (the Rust node); an explicit setting by the host is respected.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // HS_ED25519_KEEP_ENV=1: the host process does not want its environment touched at all.
+    if (const char *e = getenv("HS_ED25519_TENANTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) { kTenants = (unsigned)v; if (kTenantIndex >= kTenants) kTenantIndex = 0; } }
+    if (const char *e = getenv("HS_ED25519_TENANT_INDEX")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < kTenants) kTenantIndex = (unsigned)v; }
+    kMaxPool[0] = 4; kMaxPool[1] = 16; kPoolPartitions = 8;
+    if (kTenants > 1) {
+        kMaxPool[1] = (int)(16 / kTenants) < 2 ? 2 : (int)(16 / kTenants);
+        kMaxPool[0] = (int)(4 / kTenants) < 1 ? 1 : (int)(4 / kTenants);
+        kPoolPartitions = 8 / kTenants < 1 ? 1 : 8 / kTenants;
+    }
+    const char *keep = getenv("HS_ED25519_KEEP_ENV");
+    if (!(keep && keep[0] == '1')) {
+        char q[8];
+        snprintf(q, sizeof q, "%d", kMaxPool[0] + kMaxPool[1] < 16 ? kMaxPool[0] + kMaxPool[1] + 2 : 16);
+        setenv("GPU_MAX_HW_QUEUES", q, 0);
+    }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
@@ -880,12 +909,6 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     const int f = ctx ? ctx->kernel : HS_K_AUTO;
     if (f == HS_K_AUTO) return n <= kQuadMaxBatch ? HS_K_FUSED : HS_K_LANE;
     return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
-}
-// diagnostics: how many workgroups of the fused kernel the runtime says fit one CU (LDS 20,480 B and ~250 VGPRs per wavefront)
-extern "C" int hs_ed25519_debug_fused_blocks_per_cu(void) {
-    int nb = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_verify_fused_batches, 64, 0) != hipSuccess) return -1;
-    return nb;
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
@@ -1011,6 +1034,23 @@ extern "C" int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_di
     }
     return enqueue_cold(ctx, m, d_pks, d_sigs, n, mode, d_bitmap, d_nreject, stream);
 }
+// Every entry of a batch list is checked BEFORE the first launch: with more than 16 entries the list is cut into several
+// launches, and an error found in a later chunk must not leave earlier chunks running on the caller's buffers.
+static int check_batch_list(const hs_ed25519_batch *batches, size_t count, size_t key_align, const char *who) {
+    static thread_local char msg[160];
+    for (size_t i = 0; i < count; i++) {
+        const hs_ed25519_batch &b = batches[i];
+        if (b.n == 0) continue;
+        const char *what = nullptr;
+        if (b.mode > 1 || b.n > 32768) what = "mode must be BATCH / STRICT and n <= 32,768";
+        else if (!b.d_pks || !b.d_sigs || !b.d_bitmap || !b.d_digests) what = "null pointer";
+        else if (misaligned(b.d_pks, key_align) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4) ||
+                 misaligned(b.d_digests, 16)) what = "misaligned pointer";
+        else if (b.digest_stride != 0 && b.digest_stride != 32) what = "digest_stride must be 0 or 32";
+        if (what) { snprintf(msg, sizeof msg, "%s: entry %zu: %s", who, i, what); return hs::hs_fail(HS_ED25519_E_ARG, msg); }
+    }
+    return 0;
+}
 // the one-lane form of hs_ed25519_verify_device_batches: two launches per 16 batches, workspace slices from the context
 static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, hipStream_t st) {
     size_t total = 0;
@@ -1026,10 +1066,6 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
         for (; done < count && L.count < HS_MAX_LANE_BATCHES; done++) {
             const hs_ed25519_batch &b = batches[done];
             if (b.n == 0) continue;
-            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches: mode must be BATCH / STRICT and n <= 32,768");
-            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches: null pointer");
-            if (misaligned(b.d_pks, 16) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
-                return fail(HS_ED25519_E_ARG, "verify_device_batches: misaligned pointer");
             lane_batch &f = L.b[L.count++];
             rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
             if (rc) return rc;
@@ -1055,6 +1091,7 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
 extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, void *stream) {
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches: null context / list");
+    { const int rc = check_batch_list(batches, count, 16, "verify_device_batches"); if (rc) return rc; }
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     // pairs form (two signatures per quad, 11 % less work, 1.85x a wavefront's latency) once the caller hands over
@@ -1077,10 +1114,6 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
         for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
             const hs_ed25519_batch &b = batches[done];
             if (b.n == 0) continue;
-            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches: mode must be BATCH / STRICT and n <= 32,768");
-            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches: null pointer");
-            if (misaligned(b.d_pks, 16) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
-                return fail(HS_ED25519_E_ARG, "verify_device_batches: misaligned pointer");
             fused_batch &f = L.b[L.count++];
             int rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
             if (rc) return rc;
@@ -1106,6 +1139,7 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || !ks || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: null context / key set / list");
     if (ks->slot != ctx->slot) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: the key set lives on another device slot than the context");
+    { const int rc = check_batch_list(batches, count, 4, "verify_device_batches_cached"); if (rc) return rc; }
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
@@ -1119,10 +1153,6 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
         for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
             const hs_ed25519_batch &b = batches[done];
             if (b.n == 0) continue;
-            if (b.mode > 1 || b.n > kQuadMaxBatch) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: mode must be BATCH / STRICT and n <= 32,768");
-            if (!b.d_pks || !b.d_sigs || !b.d_bitmap) return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: null pointer");
-            if (misaligned(b.d_pks, 4) || misaligned(b.d_sigs, 16) || misaligned(b.d_bitmap, 8) || misaligned(b.d_nreject, 4))
-                return fail(HS_ED25519_E_ARG, "verify_device_batches_cached: misaligned pointer");
             cached_batch &f = L.b[L.count++];
             int rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
             if (rc) return rc;

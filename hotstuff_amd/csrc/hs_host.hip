@@ -12,6 +12,8 @@
 #include <atomic>
 #include <new>
 #include <mutex>
+#include <shared_mutex>
+#include <algorithm>
 #include <condition_variable>
 #include <vector>
 #include "engine.h"
@@ -48,7 +50,9 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     int rc = -1;
     if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the CUs
         std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-        const unsigned lo = cus * part / kPoolPartitions, hi = cus * (part + 1) / kPoolPartitions;
+        // this tenant's share of the chip (the whole of it by default), cut into the pool's partitions
+        const unsigned t_lo = cus * kTenantIndex / kTenants, t_cus = cus * (kTenantIndex + 1) / kTenants - t_lo;
+        const unsigned lo = t_lo + t_cus * part / kPoolPartitions, hi = t_lo + t_cus * (part + 1) / kPoolPartitions;
         for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
         rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
         if (rc) (void)hipGetLastError();          // CU masking unavailable: a plain stream serves as well
@@ -64,6 +68,52 @@ void hs::pool_put(hs_ed25519_ctx *c) {
     if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
     g_devs[c->slot].free_ctx[c->narrow ? 1 : 0].push_back(c);
     g_cv.notify_all();
+}
+
+// ---- caller-owned pinned buffers ---------------------------------------------------------------
+// hs_ed25519_host_alloc hands out pinned, device-mapped host memory and remembers the range.  A host-pointer call whose
+// digests, keys and signatures ALL lie inside such ranges (and are aligned as the device entry points ask) is not staged:
+// the kernels read the caller's memory over PCIe directly, as they read the engine's own pinned staging - the 128 bytes per
+// signature are then written once (by whoever packs them: the shim copying out of Vec<(PublicKey, Signature)>) instead of
+// twice.  One thread submitting bursts of sixteen 1,024-signature batches spends its time in that second copy (2 MB per
+// launch): bench.py `end_to_end`, rows with "caller_pinned".  Such buffers belong to the call until its verdict has been
+// collected (ticket_wait / the synchronous return); ordinary buffers may still be reused as soon as submit returns.
+namespace {
+std::shared_mutex r_mu;
+std::vector<std::pair<uintptr_t, size_t>> r_ranges;      // sorted by start
+bool pinned_range(const void *p, size_t len) {
+    const uintptr_t a = (uintptr_t)p;
+    std::shared_lock<std::shared_mutex> lk(r_mu);
+    auto it = std::upper_bound(r_ranges.begin(), r_ranges.end(), std::make_pair(a, (size_t)-1));
+    if (it == r_ranges.begin()) return false;
+    --it;
+    return a >= it->first && a + len <= it->first + it->second;
+}
+// all three inputs of a call in caller-owned pinned memory, aligned for the kernels
+bool caller_pinned(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const void *keys, const uint8_t *sigs, size_t n) {
+    if (misaligned(digests, 16) || misaligned(keys, ks ? 4 : 16) || misaligned(sigs, 16)) return false;
+    { std::shared_lock<std::shared_mutex> lk(r_mu); if (r_ranges.empty()) return false; }
+    return pinned_range(digests, digest_stride ? 32 * n : 32) && pinned_range(keys, (ks ? 4 : 32) * n) && pinned_range(sigs, 64 * n);
+}
+}  // namespace
+extern "C" void *hs_ed25519_host_alloc(size_t bytes) {
+    if (!bytes || !g_init.load()) { (void)fail(HS_ED25519_E_ARG, "host_alloc: zero bytes, or hs_ed25519_init has not succeeded"); return nullptr; }
+    void *p = nullptr;
+    // Portable: visible to every device slot of the process (a sharded call reads it from several GPUs)
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) { (void)fail(HS_ED25519_E_NOMEM, "host_alloc: hipHostMalloc", e); return nullptr; }
+    std::unique_lock<std::shared_mutex> lk(r_mu);
+    const auto v = std::make_pair((uintptr_t)p, bytes);
+    r_ranges.insert(std::upper_bound(r_ranges.begin(), r_ranges.end(), v), v);
+    return p;
+}
+extern "C" void hs_ed25519_host_free(void *p) {
+    if (!p) return;
+    {
+        std::unique_lock<std::shared_mutex> lk(r_mu);
+        for (size_t i = 0; i < r_ranges.size(); i++) if (r_ranges[i].first == (uintptr_t)p) { r_ranges.erase(r_ranges.begin() + (long)i); break; }
+    }
+    (void)hipHostFree(p);
 }
 
 // One host-pointer verification on one device slot, split into submit (stage + enqueue, asynchronous)
@@ -85,18 +135,28 @@ int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const 
     // staging layout: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n], each section 16-byte aligned
     const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
     const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
-    memcpy(c->h_in, digests, dg_bytes);
-    memcpy(c->h_in + off_k, keys, key_bytes);
-    memcpy(c->h_in + off_sig, sigs, 64 * n);
+    const bool own = caller_pinned(ks, digests, digest_stride, keys, sigs, n);     // caller-owned pinned buffers: no staging copy
+    if (!own) {
+        memcpy(c->h_in, digests, dg_bytes);
+        memcpy(c->h_in + off_k, keys, key_bytes);
+        memcpy(c->h_in + off_sig, sigs, 64 * n);
+    }
     job.zc = n <= kZeroCopyMax;
     uint8_t *in = job.zc ? c->h_in : c->d_in, *outp = job.zc ? c->h_out : c->d_out;
-    if (job.zc) memset(c->h_out, 0, bitmap_bytes(n));
-    else {
+    const uint8_t *p_dg = in, *p_k = in + off_k, *p_sg = in + off_sig;
+    if (job.zc) {
+        memset(c->h_out, 0, bitmap_bytes(n));
+        if (own) { p_dg = digests; p_k = (const uint8_t *)keys; p_sg = sigs; }
+    } else {
         HS_HIP(hipMemsetAsync(c->d_out, 0, bitmap_bytes(n), c->stream), "clear bitmap");
-        HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+        if (own) {
+            HS_HIP(hipMemcpyAsync(c->d_in, digests, dg_bytes, hipMemcpyHostToDevice, c->stream), "H2D digests");
+            HS_HIP(hipMemcpyAsync(c->d_in + off_k, keys, key_bytes, hipMemcpyHostToDevice, c->stream), "H2D keys");
+            HS_HIP(hipMemcpyAsync(c->d_in + off_sig, sigs, 64 * n, hipMemcpyHostToDevice, c->stream), "H2D signatures");
+        } else HS_HIP(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
     }
-    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, in, digest_stride, (const uint32_t *)(in + off_k), in + off_sig, n, mode, outp, nullptr, c->stream);
-    else rc = hs_ed25519_verify_device(c, in, digest_stride, in + off_k, in + off_sig, n, mode, outp, nullptr, c->stream);
+    if (ks) rc = hs_ed25519_verify_device_cached(c, ks, p_dg, digest_stride, (const uint32_t *)p_k, p_sg, n, mode, outp, nullptr, c->stream);
+    else rc = hs_ed25519_verify_device(c, p_dg, digest_stride, p_k, p_sg, n, mode, outp, nullptr, c->stream);
     if (rc) return rc;
     if (!job.zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     return 0;
@@ -225,14 +285,19 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
     uint8_t *in = c->h_in + idx * kGroupInStride, *outp = c->h_out + idx * group_out_stride();
     const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
     const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16);
-    memcpy(in, digests, dg_bytes);
-    memcpy(in + off_k, keys, key_bytes);
-    memcpy(in + off_sig, sigs, 64 * n);
+    const bool own = caller_pinned(ks, digests, digest_stride, keys, sigs, n);     // caller-owned pinned buffers: no staging copy
+    if (!own) {
+        memcpy(in, digests, dg_bytes);
+        memcpy(in + off_k, keys, key_bytes);
+        memcpy(in + off_sig, sigs, 64 * n);
+    }
     memset(outp, 0, bitmap_bytes(n));
     {
         std::lock_guard<std::mutex> lk(g->mu);
         hs_ed25519_batch &d = g->desc[idx];
-        d.d_digests = in; d.digest_stride = digest_stride; d.d_pks = in + off_k; d.d_sigs = in + off_sig; d.n = n;
+        d.digest_stride = digest_stride; d.n = n;
+        if (own) { d.d_digests = digests; d.d_pks = (const uint8_t *)keys; d.d_sigs = sigs; }
+        else { d.d_digests = in; d.d_pks = in + off_k; d.d_sigs = in + off_sig; }
         d.mode = mode == HS_ED25519_STRICT ? HS_ED25519_STRICT : HS_ED25519_BATCH;   // BATCH_RLC this small is the per-signature BATCH law
         d.d_bitmap = outp; d.d_nreject = nullptr;
         g->staged++;
@@ -273,6 +338,7 @@ static int verify_host(const hs_ed25519_keyset *ks, const uint8_t *digests, size
         if (rc) return rc;
         return group_finish(g, idx, n, bitmap);
     }
+    t_open.drop(true);          // a burst left open launches before a call of another kind (the documented rule)
     host_job job;
     int rc = host_submit(job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, keys, sigs, n, mode);
     if (rc) { host_abandon(job); return rc; }
@@ -298,7 +364,11 @@ extern "C" int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyse
     t->n = n;
     int rc = 0;
     if (group_sized(n, mode)) rc = group_submit(&t->g, &t->idx, ks, digests, digest_stride, pks_or_idx, sigs, n, mode, flags & HS_ED25519_SUBMIT_MORE, true);
-    else if (n) { rc = host_submit(t->job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true); if (rc) host_abandon(t->job); }
+    else if (n) {
+        t_open.drop(true);      // a burst left open launches before a call of another kind (the documented rule)
+        rc = host_submit(t->job, ks ? ks->slot : next_cold_slot(), ks, digests, digest_stride, pks_or_idx, sigs, n, mode, true);
+        if (rc) host_abandon(t->job);
+    }
     if (rc) { delete t; return rc; }
     *out = t;
     return 0;

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include "rlc.h"
 #include "engine.h"
@@ -364,7 +365,8 @@ struct rlc_ws {
 };
 std::mutex k_mu;
 rlc_key g_key;
-bool g_key_set = false;
+bool g_key_set = false, g_key_pinned = false;
+std::atomic<unsigned long long> g_call_seq{1};
 
 // Below this many signatures the pipeline (five stages, the last a 248-doubling chain on one quad) costs
 // more than the per-signature kernels: the call then runs plain BATCH.  profiles/r2_sweeps.md: the RLC path wins
@@ -429,8 +431,15 @@ extern "C" int hs_ed25519_set_rlc_key(const uint8_t key[32]) {
     std::lock_guard<std::mutex> lk(k_mu);
     memcpy(g_key.w, key, 32);
     g_key_set = true;
+    g_key_pinned = true;           // pinned: the same coefficients on every call
     return 0;
 }
+// The key of ONE call.  dalek draws fresh thread_rng() coefficients for every verify_batch call; a process-wide key
+// alone would give the same signature at the same index the same z_i on every call, which on crafted torsion inputs
+// (SURVEY.md 8a class iii) turns dalek's independent 1/8 chance per verification into a permanent, learnable verdict
+// (ADVICE r2).  So unless the key was pinned with hs_ed25519_set_rlc_key (tests, reproducible runs), every call mixes its
+// own 64-bit sequence number into the process secret: z_i = SHA-512(secret ^ call || h_i || s_i || i) - a keyed PRF on a
+// never-repeating input, i.e. coefficients independent from call to call.
 static int current_key(rlc_key &out) {
     std::lock_guard<std::mutex> lk(k_mu);
     if (!g_key_set) {              // dalek: thread_rng(); here 32 bytes from the OS, once per process
@@ -441,6 +450,10 @@ static int current_key(rlc_key &out) {
         g_key_set = true;
     }
     out = g_key;
+    if (!g_key_pinned) {
+        const unsigned long long seq = g_call_seq.fetch_add(1, std::memory_order_relaxed);
+        out.w[6] ^= (u32)seq; out.w[7] ^= (u32)(seq >> 32);
+    }
     return 0;
 }
 // tests / tuning: run the RLC stage from `min_batch` signatures up on this context (0 = library default)
@@ -453,12 +466,13 @@ extern "C" int hs_ed25519_ctx_set_rlc_min(hs_ed25519_ctx *ctx, size_t min_batch)
 }
 extern "C" size_t hs_ed25519_rlc_min_batch(void) { return kRlcMinBatch; }
 // after the context's stream has drained: how many calls ran the RLC stage, and whether the last one
-// accepted the batch outright (1), fell through to the per-signature kernels (0), or did not run (-1)
+// accepted the batch outright (1), fell through to the per-signature kernels (0), or did not run
+// (HS_ED25519_RLC_NOT_RUN = 2: a state, deliberately outside the negative HS_ED25519_E_* range)
 extern "C" int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls) {
     if (!ctx) return fail(HS_ED25519_E_ARG, "ctx_rlc_last: null context");
     rlc_ws *w = (rlc_ws *)ctx->rlc;
     if (calls) *calls = w ? w->calls : 0;
-    if (!w || !w->small || !w->calls) return -1;
+    if (!w || !w->small || !w->calls) return HS_ED25519_RLC_NOT_RUN;
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(ctx->stream), "stream sync");
     u32 flags[2] = {0, 0};

@@ -55,12 +55,22 @@ struct rccl_api {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
-std::mutex s_mu;
+std::mutex s_mu;                        // the communicators, the free list below, and the ENQUEUE of a grouped all-gather
 rccl_api s_rccl;
 std::vector<ncclComm_t> s_comms;       // one per slot
-std::vector<uint8_t *> s_gather;       // per slot: device buffer for the gathered bitmaps
-size_t s_gather_bytes = 0;
+// Gather buffers are per CALL: a set = one device buffer per slot, taken from a free list for the duration of one
+// sharded call and given back when that call's streams have drained.  (Round 2 had ONE set and held s_mu until
+// the read-back finished, so concurrent sharded callers ran one after the other; now the lock only covers the
+// enqueue - RCCL wants the grouped calls of one communicator issued by one thread at a time - and the calls'
+// kernels, collectives and copies overlap on their own streams.)
+struct gather_set { std::vector<uint8_t *> buf; size_t bytes = 0; };
+std::vector<gather_set *> s_free_sets;
 std::atomic<int> s_exchange{HS_ED25519_EXCHANGE_HOST};
+
+void gather_set_free(gather_set *g) {
+    for (size_t s = 0; s < g->buf.size(); s++) if (g->buf[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(g->buf[s]); }
+    delete g;
+}
 
 int rccl_load() {      // under s_mu
     if (s_rccl.h) return 0;
@@ -87,7 +97,7 @@ int rccl_fail(const char *what, ncclResult_t r) {
     snprintf(buf, sizeof buf, "%s: %s", what, s_rccl.GetErrorString ? s_rccl.GetErrorString(r) : "RCCL error");
     return fail(HS_ED25519_E_DEVICE, buf);
 }
-int rccl_ensure(size_t slice_bytes) {      // under s_mu: communicators + gather buffers for the current device list
+int rccl_ensure() {      // under s_mu: communicators for the current device list
     int rc = rccl_load();
     if (rc) return rc;
     const int k = dev_slots();
@@ -101,26 +111,49 @@ int rccl_ensure(size_t slice_bytes) {      // under s_mu: communicators + gather
         if (r != ncclSuccess) return rccl_fail("ncclCommInitAll", r);
         s_comms.swap(comms);
     }
-    const size_t want = round_up((size_t)k * slice_bytes, 256);
-    if (want > s_gather_bytes || (int)s_gather.size() != k) {
-        for (size_t s = 0; s < s_gather.size(); s++) if (s_gather[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(s_gather[s]); }
-        s_gather.assign(k, nullptr); s_gather_bytes = 0;
-        for (int s = 0; s < k; s++) {
-            HS_HIP(hipSetDevice(dev_ordinal(s)), "hipSetDevice");
-            HS_HIP(hipMalloc((void **)&s_gather[s], want), "hipMalloc gather buffer");
-        }
-        s_gather_bytes = want;
-    }
     return 0;
+}
+// under s_mu: a gather set of at least k * slice_bytes per slot
+int gather_set_get(gather_set **out, size_t slice_bytes) {
+    const int k = dev_slots();
+    const size_t want = round_up((size_t)k * slice_bytes, 256);
+    for (size_t i = 0; i < s_free_sets.size(); i++)
+        if (s_free_sets[i]->bytes >= want && (int)s_free_sets[i]->buf.size() == k) {
+            *out = s_free_sets[i]; s_free_sets.erase(s_free_sets.begin() + (long)i); return 0;
+        }
+    if (!s_free_sets.empty()) { gather_set_free(s_free_sets.back()); s_free_sets.pop_back(); }     // too small: replace it
+    gather_set *g = new (std::nothrow) gather_set();
+    if (!g) return fail(HS_ED25519_E_NOMEM, "RCCL exchange: out of memory");
+    g->buf.assign(k, nullptr);
+    for (int s = 0; s < k; s++) {
+        hipError_t e = hipSetDevice(dev_ordinal(s));
+        if (e == hipSuccess) e = hipMalloc((void **)&g->buf[s], want);
+        if (e != hipSuccess) { gather_set_free(g); return fail(HS_ED25519_E_DEVICE, "hipMalloc gather buffer", e); }
+    }
+    g->bytes = want;
+    *out = g;
+    return 0;
+}
+void gather_set_put(gather_set *g) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(s_mu);
+    if ((int)g->buf.size() == dev_slots() && s_free_sets.size() < 8) s_free_sets.push_back(g);
+    else gather_set_free(g);
 }
 }  // namespace
 
 extern "C" void hs_ed25519_shard_reset(void) {      // called by tests / before shutdown: drop communicators and buffers
     std::lock_guard<std::mutex> lk(s_mu);
-    for (size_t s = 0; s < s_gather.size(); s++) if (s_gather[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(s_gather[s]); }
-    s_gather.clear(); s_gather_bytes = 0;
+    for (gather_set *g : s_free_sets) gather_set_free(g);
+    s_free_sets.clear();
     if (s_rccl.CommDestroy) for (ncclComm_t c : s_comms) if (c) (void)s_rccl.CommDestroy(c);
     s_comms.clear();
+}
+// how many ranks the in-process RCCL exchange runs over (communicators of ncclCommInitAll): 0 until the first
+// HS_ED25519_EXCHANGE_RCCL call has initialised them
+extern "C" int hs_ed25519_shard_rccl_ranks(void) {
+    std::lock_guard<std::mutex> lk(s_mu);
+    return (int)s_comms.size();
 }
 extern "C" int hs_ed25519_set_shard_exchange(int how) {
     if (how != HS_ED25519_EXCHANGE_HOST && how != HS_ED25519_EXCHANGE_RCCL) return fail(HS_ED25519_E_ARG, "set_shard_exchange: unknown exchange");
@@ -147,14 +180,15 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
         rc = host_submit(jobs[s], s, items[s].ks, items[s].digests, digest_stride, items[s].keys, items[s].sigs, items[s].n, mode);
     }
     if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
-    // the communicators and the gather buffers are shared: a call that uses them keeps the lock until its streams
-    // have drained (the read-back of the gathered bitmap is asynchronous), so concurrent sharded callers serialise here
-    std::unique_lock<std::mutex> lk(s_mu, std::defer_lock);
+    gather_set *gs = nullptr;
     if (want_rccl) {
-        // all-gather of equal slice_bytes slices: slot s contributes its bitmap padded with zeros
-        lk.lock();
-        rc = rccl_ensure(slice_bytes);
-        if (!rc) {
+        // all-gather of equal slice_bytes slices: slot s contributes its bitmap padded with zeros.  s_mu covers the
+        // enqueue only (grouped calls of one communicator must come from one thread at a time); the gather buffers are
+        // this call's own until its streams have drained
+        {
+            std::lock_guard<std::mutex> lk(s_mu);
+            rc = rccl_ensure();
+            if (!rc) rc = gather_set_get(&gs, slice_bytes);
             std::vector<uint8_t *> send(k, nullptr);
             for (int s = 0; s < k && !rc; s++) {
                 hs_ed25519_ctx *c = jobs[s].c;
@@ -164,7 +198,7 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
                 }
                 if (hipSetDevice(c->device) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
                 // slice = the first slice_bytes of the gather buffer's own slot region, filled on the stream
-                send[s] = s_gather[s] + (size_t)s * slice_bytes;
+                send[s] = gs->buf[s] + (size_t)s * slice_bytes;
                 hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, jobs[s].c->stream);
                 if (e == hipSuccess && jobs[s].n) {
                     const uint8_t *src = jobs[s].zc ? c->h_out : c->d_out;
@@ -176,20 +210,21 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
             if (!rc) {
                 ncclResult_t r = s_rccl.GroupStart();
                 for (int s = 0; s < k && r == ncclSuccess; s++)
-                    r = s_rccl.AllGather(send[s], s_gather[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].c->stream);   // in place
+                    r = s_rccl.AllGather(send[s], gs->buf[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].c->stream);   // in place
                 const ncclResult_t r2 = s_rccl.GroupEnd();
                 if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather", r != ncclSuccess ? r : r2);
             }
-            if (!rc) {
-                gathered->assign((size_t)k * slice_bytes, 0);
-                hs_ed25519_ctx *c0 = jobs[0].c;
-                if (hipSetDevice(c0->device) != hipSuccess ||
-                    hipMemcpyAsync(gathered->data(), s_gather[0], gathered->size(), hipMemcpyDeviceToHost, jobs[0].c->stream) != hipSuccess)
-                    rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: reading the gathered bitmap");
-            }
         }
-        if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
+        if (!rc) {
+            gathered->assign((size_t)k * slice_bytes, 0);
+            hs_ed25519_ctx *c0 = jobs[0].c;
+            if (hipSetDevice(c0->device) != hipSuccess ||
+                hipMemcpyAsync(gathered->data(), gs->buf[0], gathered->size(), hipMemcpyDeviceToHost, jobs[0].c->stream) != hipSuccess)
+                rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: reading the gathered bitmap");
+        }
+        if (rc) { for (host_job &j : jobs) host_abandon(j); gather_set_put(gs); return rc; }     // abandon drains the streams first
     }
+    struct put_later { gather_set *g; ~put_later() { gather_set_put(g); } } gs_guard{gs};      // after every stream below has drained
     int verdict = 1;
     for (int s = 0; s < k; s++) {
         if (!jobs[s].c) continue;

@@ -63,15 +63,43 @@ class VoteIngest:
     must neither block X's genuine vote while pending nor after it has been dropped), an exact
     duplicate of a waiting candidate is ignored, and at most one candidate per author is
     accepted.  AuthorityReuse is raised exactly where the reference raises it: for a vote
-    whose author already has an accepted vote."""
+    whose author already has an accepted vote.
 
-    def __init__(self, committee, verify_fn=None, max_pending=None):
+    What a hostile peer can cost (the reference verifies each vote on arrival and holds no queue, so it has neither
+    problem):
+
+    * MEMORY: at most `per_author_cap` candidates wait per author; the candidate that would exceed it triggers a
+      verification of everything pending first (which settles that author's candidates) - so the queue never exceeds
+      per_author_cap x committee size, `max_pending` (default: committee size + 64) flushes before that, and a flood
+      naming ONE authority costs one call per `per_author_cap` votes.  The stake that could still verify is kept
+      incrementally (`_pend_weight`), not recomputed per vote.
+    * CALLS: once verified + pending stake reaches the quorum a verification could complete the certificate, so it
+      runs at once - the honest case, and the case of one or two bad votes in the round.  But a peer streaming
+      forgeries for distinct authorities would then buy one GPU call (0.1 - 0.4 ms, against 0.04 ms on a CPU core for
+      the single verification the reference does) per vote.  From the second verification in a row that COULD have
+      completed the quorum and did not, the next one waits until 2, 4, 8 ... `max_coalesce` votes are pending
+      - or until the oldest has waited `max_wait` seconds (`tick`, driven by the caller's event loop: the
+      reference's Core has a timer anyway, core.rs:422-433) - so forgeries are verified in growing groups and an
+      honest last vote is delayed by `max_wait` at most, and only while the round is under that attack.
+    """
+
+    def __init__(self, committee, verify_fn=None, max_pending=None, per_author_cap=2, max_coalesce=64, max_wait=0.002,
+                 clock=None):
+        import time
         self.committee = committee
         self.verify_fn = verify_fn or _gpu_verify(committee)
-        self.max_pending = max_pending
+        self.max_pending = max_pending if max_pending else committee.size() + 64
+        self.per_author_cap = max(1, per_author_cap)
+        self.max_coalesce = max(1, max_coalesce)
+        self.max_wait = max_wait
+        self.clock = clock or time.monotonic
         self.used = set()          # authors with a VERIFIED vote (aggregator.rs `used`)
         self.pending = []          # votes whose signature has not been checked yet
         self._pending_keys = set() # (author bytes, signature bytes) of the waiting candidates
+        self._pend_count = {}      # author -> candidates waiting
+        self._pend_weight = 0      # stake that COULD verify: one candidate per author at most
+        self._oldest = None        # arrival time of the oldest waiting candidate
+        self._misses = 0           # verifications in a row that could have completed the quorum and did not
         self.valid = []            # (author, signature) with a verified signature
         self.valid_weight = 0
         self.done = False
@@ -79,6 +107,13 @@ class VoteIngest:
         self.round = None
         self.gpu_calls = 0
         self.dropped = []
+
+    def _could_complete(self):
+        return self.valid_weight + self._pend_weight >= self.committee.quorum_threshold()
+
+    def _group_size(self):
+        """votes that must be waiting before the next quorum-completing attempt (1 until two attempts in a row failed)"""
+        return 1 if self._misses < 2 else min(self.max_coalesce, 1 << (self._misses - 1))
 
     def add_vote(self, vote):
         """Structural checks now (messages.rs:138-142, aggregator.rs:79-82), signature later.
@@ -96,18 +131,39 @@ class VoteIngest:
         key = (vote.author.b, vote.signature.flatten())
         if key in self._pending_keys:
             return None            # byte-identical to a candidate already waiting
+        qc = None
+        if self._pend_count.get(vote.author, 0) >= self.per_author_cap:
+            qc = self.flush()      # settle this author's waiting candidates before queueing another
+            if vote.author in self.used:
+                raise AuthorityReuse(vote.author)   # one of them verified: this vote is late, as in the reference
+            if qc is not None or self.done:
+                return qc
         self._pending_keys.add(key)
         self.pending.append(vote)
-        # stake that COULD verify: one candidate per author at most
-        pend_weight = sum(self.committee.stake(a) for a in {v.author for v in self.pending})
-        if (self.valid_weight + pend_weight >= self.committee.quorum_threshold()
-                or (self.max_pending and len(self.pending) >= self.max_pending)):
+        c = self._pend_count.get(vote.author, 0)
+        self._pend_count[vote.author] = c + 1
+        if c == 0:
+            self._pend_weight += self.committee.stake(vote.author)
+        if self._oldest is None:
+            self._oldest = self.clock()
+        if len(self.pending) >= self.max_pending:
+            return self.flush()
+        if self._could_complete() and (len(self.pending) >= self._group_size()
+                                       or self.clock() - self._oldest >= self.max_wait):
+            return self.flush()
+        return None
+
+    def tick(self):
+        """Called by the owner's event loop: verifies what is waiting once the oldest candidate has waited `max_wait`
+        (only matters while add_vote is coalescing, i.e. under a forgery stream).  Returns a QC or None."""
+        if self.pending and not self.done and self._could_complete() and self.clock() - self._oldest >= self.max_wait:
             return self.flush()
         return None
 
     def flush(self):
         """Verify everything pending in one call; keep the valid votes (first valid candidate per
         author), drop the rest individually - the set the reference drops one by one."""
+        could = self._could_complete()
         if self.pending:
             votes = [(v.author, v.signature) for v in self.pending]
             oks = self.verify_fn(self.pending[0].digest(), votes)
@@ -121,9 +177,14 @@ class VoteIngest:
                     self.dropped.append(v.author)     # the reference warns and drops (core.rs:434-439)
             self.pending = []
             self._pending_keys = set()
+            self._pend_count = {}
+            self._pend_weight = 0
+            self._oldest = None
         if not self.done and self.valid_weight >= self.committee.quorum_threshold():
             self.done = True                          # QCMaker: "ensures QC is only made once"
             return QC(self.hash, self.round, list(self.valid))
+        if could and not self.done:
+            self._misses += 1                         # this attempt could have completed the certificate and did not
         return None
 
 

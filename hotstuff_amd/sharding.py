@@ -32,6 +32,10 @@ def gather_bitmaps(local_bitmap, group=None):
     (world * len(local_bitmap) bytes) on every rank.  The returned tensor is reused by the next
     call with the same shape on the same device: copy it to keep it."""
     world = dist.get_world_size(group)
+    if local_bitmap.is_cuda and dist.get_backend(group) == "gloo":
+        # ranks sharing one GPU (a rehearsal of the multi-GPU path on fewer devices; RCCL refuses two ranks per
+        # device): the <= 1 KB slices travel through host memory and gloo
+        return gather_bitmaps(local_bitmap.cpu(), group).to(local_bitmap.device)
     key = (local_bitmap.device, world * local_bitmap.numel())
     out = _gather_out.get(key)
     if out is None:

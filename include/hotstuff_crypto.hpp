@@ -30,6 +30,7 @@
 // fallback: an engine error (no GPU, HIP failure) is an Err like any other, never an Ok.
 #pragma once
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -423,9 +424,23 @@ struct VoteIngest {
     using Verifier = std::vector<bool> (*)(const std::vector<Digest> &, const std::vector<std::pair<PublicKey, Signature>> &);
     const Committee &committee;
     Verifier verifier = &Signature::verify_many;           // injectable (tests: the oracle)
-    size_t max_pending = 0;
+    // What a hostile peer can cost (the reference verifies every vote on arrival and holds no queue):
+    //   memory - at most per_author_cap candidates wait per author; the one that would exceed it triggers a verification
+    //            of everything pending first.  The queue never exceeds per_author_cap x committee size, and max_pending
+    //            (default: committee size + 64) verifies before that.
+    //   calls  - a verification that could complete the quorum runs at once (the honest case, and one or two bad votes);
+    //            from the second such attempt in a row that failed, the next waits for 2, 4, 8 ... max_coalesce pending
+    //            votes or for max_wait (tick(), driven by the owner's timer): a forgery stream is verified in growing
+    //            groups instead of one GPU call per vote.
+    size_t max_pending = 0, per_author_cap = 2, max_coalesce = 64;
+    double max_wait_s = 0.002;
+    double (*clock)() = &VoteIngest::steady_seconds;
     std::set<PublicKey> used;
     std::vector<Vote> pending;
+    std::map<PublicKey, size_t> pend_count;                // author -> candidates waiting
+    Stake pend_weight = 0;                                 // stake that could verify: one candidate per author at most
+    double oldest = -1;                                    // arrival of the oldest waiting candidate
+    unsigned misses = 0;                                   // attempts in a row that could have completed the quorum and did not
     std::vector<std::pair<PublicKey, Signature>> valid;
     std::vector<PublicKey> dropped;
     Stake valid_weight = 0;
@@ -434,10 +449,20 @@ struct VoteIngest {
     Digest hash;
     Round round = 0;
 
-    explicit VoteIngest(const Committee &c, size_t max_pending_ = 0) : committee(c), max_pending(max_pending_) {}
+    static double steady_seconds() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    explicit VoteIngest(const Committee &c, size_t max_pending_ = 0)
+        : committee(c), max_pending(max_pending_ ? max_pending_ : c.authorities.size() + 64) {}
 
     struct Outcome { ConsensusResult status; std::unique_ptr<QC> qc; };   // qc set the first time a quorum verified
 
+    bool could_complete() const { return valid_weight + pend_weight >= committee.quorum_threshold(); }
+    size_t group_size() const {
+        if (misses < 2) return 1;
+        const size_t g = misses - 1 >= 20 ? max_coalesce : (size_t)1 << (misses - 1);
+        return g < max_coalesce ? g : max_coalesce;
+    }
     Outcome add_vote(const Vote &v) {
         if (!started) { hash = v.hash; round = v.round; started = true; }
         if (committee.stake(v.author) == 0) return {ConsensusResult::Err(ConsensusError::UnknownAuthority, v.author), nullptr};
@@ -445,22 +470,35 @@ struct VoteIngest {
         if (done) return {ConsensusResult::Ok(), nullptr};
         for (const Vote &p : pending)                      // byte-identical to a candidate already waiting
             if (p.author == v.author && p.signature.flatten() == v.signature.flatten()) return {ConsensusResult::Ok(), nullptr};
+        auto it = pend_count.find(v.author);
+        if (it != pend_count.end() && it->second >= per_author_cap) {
+            Outcome o = flush();                           // settle this author's waiting candidates before queueing another
+            if (!o.status.is_ok()) return o;
+            if (used.count(v.author)) return {ConsensusResult::Err(ConsensusError::AuthorityReuse, v.author), std::move(o.qc)};
+            if (o.qc || done) return o;
+        }
         pending.push_back(v);
-        std::set<PublicKey> authors;
-        Stake pend = 0;
-        for (const Vote &p : pending) if (authors.insert(p.author).second) pend += committee.stake(p.author);
-        if (valid_weight + pend >= committee.quorum_threshold() || (max_pending && pending.size() >= max_pending)) return flush();
+        if (pend_count[v.author]++ == 0) pend_weight += committee.stake(v.author);
+        if (oldest < 0) oldest = clock();
+        if (pending.size() >= max_pending) return flush();
+        if (could_complete() && (pending.size() >= group_size() || clock() - oldest >= max_wait_s)) return flush();
+        return {ConsensusResult::Ok(), nullptr};
+    }
+    // the owner's timer: verifies what is waiting once the oldest candidate has waited max_wait_s
+    Outcome tick() {
+        if (!pending.empty() && !done && could_complete() && clock() - oldest >= max_wait_s) return flush();
         return {ConsensusResult::Ok(), nullptr};
     }
     Outcome flush() {
+        const bool could = could_complete();
         if (!pending.empty()) {
             std::vector<Digest> dg;
             std::vector<std::pair<PublicKey, Signature>> votes;
             for (const Vote &p : pending) { dg.push_back(p.digest()); votes.push_back({p.author, p.signature}); }
             const std::vector<bool> ok = verifier(dg, votes);
             verify_calls++;
-            if (ok.size() != pending.size()) { pending.clear(); return {ConsensusResult::Err(ConsensusError::InvalidSignature), nullptr}; }   // engine error: never Ok
-            for (size_t i = 0; i < pending.size(); i++) {
+            const bool engine_error = ok.size() != pending.size();
+            for (size_t i = 0; !engine_error && i < pending.size(); i++) {
                 if (ok[i] && !used.count(pending[i].author)) {
                     used.insert(pending[i].author);
                     valid.push_back(votes[i]);
@@ -469,7 +507,8 @@ struct VoteIngest {
                     dropped.push_back(pending[i].author);  // the reference warns and drops (core.rs:434-439)
                 }
             }
-            pending.clear();
+            pending.clear(); pend_count.clear(); pend_weight = 0; oldest = -1;
+            if (engine_error) return {ConsensusResult::Err(ConsensusError::InvalidSignature), nullptr};   // engine error: never Ok
         }
         if (!done && valid_weight >= committee.quorum_threshold()) {
             done = true;                                   // QCMaker: "ensures QC is only made once"
@@ -477,6 +516,7 @@ struct VoteIngest {
             qc->hash = hash; qc->round = round; qc->votes = valid;
             return {ConsensusResult::Ok(), std::move(qc)};
         }
+        if (could && !done) misses++;                      // this attempt could have completed the certificate and did not
         return {ConsensusResult::Ok(), nullptr};
     }
 };

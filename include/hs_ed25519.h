@@ -32,16 +32,19 @@
  *                          [8]R == O or [8]A == O.
  *   HS_ED25519_BATCH_RLC (2)  ed25519-dalek 1.0.1 `verify_batch` as it computes it: ONE
  *                          random linear combination  -[sum z_i s_i]B + sum [z_i]R_i +
- *                          sum [z_i h_i mod L]A_i == O  over the whole call (128-bit z_i,
- *                          Pippenger multi-scalar multiplication on the GPU).  If it holds the
+ *                          sum [z_i h_i mod L]A_i == O  over the whole call (127-bit z_i - dalek
+ *                          draws 128 bits; one bit less keeps the signed radix-256 recoding inside
+ *                          16 windows - Pippenger multi-scalar multiplication on the GPU).  If it holds the
  *                          call accepts (bitmap all ones); if it does not, the per-signature
  *                          BATCH kernels run in the same call and localise the rejects, so the
  *                          verdict and bitmap are then exactly BATCH's.  Identical to BATCH on
  *                          every input where dalek is deterministic (SURVEY.md 8a classes i / ii);
  *                          on crafted torsion inputs (class iii) it can accept where BATCH
- *                          rejects, with dalek's own probability.  z_i = SHA-512(process-secret
- *                          key || h_i || s_i || i): unpredictable to whoever built the batch, as
- *                          dalek's thread_rng is (hs_ed25519_set_rlc_key pins it for tests).
+ *                          rejects, with dalek's own probability.  z_i = low 127 bits of
+ *                          SHA-512((process secret ^ call number) || h_i || s_i || i):
+ *                          unpredictable to whoever built the batch and independent from call to
+ *                          call, as dalek's thread_rng draws are (hs_ed25519_set_rlc_key pins the
+ *                          key AND drops the call number: reproducible coefficients for tests).
  *
  * Return value of every verify call:
  *    1  every signature accepted (n == 0 -> 1, as lib.rs:206-219 returns Ok)
@@ -87,13 +90,31 @@ int hs_ed25519_init(int device, size_t max_batch);
 int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch);
 int hs_ed25519_device_count(void);        /* device slots, 0 before init */
 void hs_ed25519_shutdown(void);
+/* Several node processes on ONE GPU (the reference's `fab local` runs four node processes on one host,
+ * benchmark/benchmark/local.py:94-104).  Tell the engine, before hs_ed25519_init, that this
+ * process is tenant `index` of `tenants` (1..8) on its GPU: it then takes 1/tenants of the stream budget (the
+ * device multiplexes every process's streams; past ~16 in flight throughput collapses) and confines its small
+ * calls to its own 1/tenants of the compute units, so co-tenants do not stack their batches on the same CUs.
+ * Environment HS_ED25519_TENANTS / HS_ED25519_TENANT_INDEX do the same for an unmodified host.  Verdicts are
+ * identical with or without it.  hs_ed25519_init exports GPU_MAX_HW_QUEUES (one hardware queue per stream
+ * context) unless the host already set it or HS_ED25519_KEEP_ENV=1 forbids touching the environment. */
+int hs_ed25519_set_tenancy(unsigned tenants, unsigned index);
+/* Caller-owned pinned buffers.  Memory from hs_ed25519_host_alloc is page-locked and mapped on every device
+ * slot; a host-pointer call (synchronous, submit, sharded) whose digests, keys and signatures all lie in such
+ * memory (16-byte aligned; key indices 4-byte) is NOT staged - the kernels read it in place over PCIe - so the
+ * shim's own packing of Vec<(PublicKey, Signature)> is the only host copy.  Such buffers
+ * belong to the call until its verdict has been collected; any other buffer may be reused as soon as the call
+ * or hs_ed25519_submit returns.  NULL on failure (hs_ed25519_last_error). */
+void *hs_ed25519_host_alloc(size_t bytes);
+void hs_ed25519_host_free(void *p);
 /* The batch size below which a call should stay on the CPU path of the shim (dalek): the GPU round
  * trip costs one wavefront's serial chain (~0.36-0.4 ms cold, ~0.09-0.12 ms with registered keys) whatever n
  * is.  keys_registered != 0: the caller would use a *_cached entry point.  bench.py measures the
  * crossover (`small_batch_crossover`); env HS_ED25519_MIN_GPU_BATCH overrides. */
 size_t hs_ed25519_min_gpu_batch(int keys_registered);
-/* HS_ED25519_BATCH_RLC draws its 128-bit coefficients from SHA-512 keyed with a 32-byte secret taken
- * from the OS at first use; this pins it (tests, reproducible runs). */
+/* HS_ED25519_BATCH_RLC draws its 127-bit coefficients from SHA-512 keyed with a 32-byte secret taken
+ * from the OS at first use, mixed with a per-call sequence number; this pins the key and switches the
+ * sequence number off (tests, reproducible runs). */
 int hs_ed25519_set_rlc_key(const uint8_t key[32]);
 /* HS_ED25519_BATCH_RLC calls below this size run as plain HS_ED25519_BATCH (the five-stage MSM pipeline
  * only pays from a few thousand signatures up; profiles/r2_rlc_ab.md).  A context can override the
@@ -132,8 +153,10 @@ int hs_ed25519_ctx_create_on(hs_ed25519_ctx **out, size_t max_batch, int slot);
 int hs_ed25519_ctx_device(const hs_ed25519_ctx *ctx);                                /* HIP ordinal */
 int hs_ed25519_ctx_set_rlc_min(hs_ed25519_ctx *ctx, size_t min_batch);
 /* After the context's stream has drained: 1 = the last HS_ED25519_BATCH_RLC call on it accepted the
- * batch by the combination alone, 0 = it fell through to the per-signature kernels, -1 = the RLC
- * stage has not run; *calls (optional) = how many calls ran it. */
+ * batch by the combination alone, 0 = it fell through to the per-signature kernels,
+ * HS_ED25519_RLC_NOT_RUN = the RLC stage has not run (a state, not an error: errors are < 0);
+ * *calls (optional) = how many calls ran it. */
+#define HS_ED25519_RLC_NOT_RUN 2
 int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls);
 void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);
 /* Like hs_ed25519_ctx_create, but the context's own stream is restricted to partition `part`
@@ -300,6 +323,7 @@ const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t coun
 int hs_ed25519_shard_plan(size_t n, unsigned nshards, unsigned shard, size_t *lo, size_t *hi);
 int hs_ed25519_set_shard_exchange(int how);
 void hs_ed25519_shard_reset(void);        /* drop RCCL communicators / gather buffers (before shutdown) */
+int hs_ed25519_shard_rccl_ranks(void);    /* ranks of the in-process RCCL exchange (0 until it first ran) */
 int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
                                      uint32_t mode, uint8_t *bitmap);
 int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,
@@ -381,18 +405,6 @@ int hs_ed25519_submit(hs_ed25519_ticket **out, const hs_ed25519_keyset *ks, cons
 int hs_ed25519_ticket_ready(hs_ed25519_ticket *t);
 int hs_ed25519_ticket_device_slot(const hs_ed25519_ticket *t);  /* which device slot verifies it (diagnostics) */
 int hs_ed25519_ticket_wait(hs_ed25519_ticket *t, uint8_t *bitmap);
-
-/* Measurement aid: `threads` native host threads call hs_ed25519_verify_multi (digest_stride 32) or
- * hs_ed25519_verify_shared (0) in a loop for `seconds`, thread t on batch t mod nbatches of the caller's
- * packed host buffers (nbatches x n tuples, all valid; with a key set `ks` the *_cached forms, `pks` then
- * holding nbatches x n uint32 key indices).  Reports completed calls, the median call latency
- * and the elapsed time.  This is SURVEY.md 8d's end-to-end metric - host buffers in, host verdict out -
- * without an interpreter in the loop.  inflight <= 1: the synchronous calls; inflight = k > 1: every thread
- * keeps k tickets outstanding through hs_ed25519_submit / hs_ed25519_ticket_wait (latency = submit to verdict),
- * submitted in bursts of batches_per_launch (HS_ED25519_SUBMIT_MORE on all but the last of a burst). */
-int hs_ed25519_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
-                       size_t nbatches, uint32_t mode, unsigned threads, unsigned inflight, unsigned batches_per_launch,
-                       double seconds, uint64_t *calls_out, double *p50_ms_out, double *elapsed_s_out);
 
 #ifdef __cplusplus
 }

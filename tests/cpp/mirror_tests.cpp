@@ -224,6 +224,45 @@ int main(int argc, char **argv) {
         const auto late = ing.add_vote(vote(3));
         CHECK("VoteIngest: late votes after the QC need no verification", late.status.is_ok() && !late.qc && ing.verify_calls == 2);
     }
+    // ---- VoteIngest under a hostile peer: bounded queue, coalesced verifications
+    {
+        VoteIngest ing(committee);
+        size_t peak = 0;
+        bool quiet = true;
+        for (int t = 0; t < 20; t++) {                     // twenty different garbage votes naming authority 0
+            Vote g = vote(0);
+            g.signature.part1[0] ^= 1; g.signature.part1[1] ^= (uint8_t)(t + 1);
+            auto o = ing.add_vote(g);
+            quiet = quiet && o.status.is_ok() && !o.qc;
+            if (ing.pending.size() > peak) peak = ing.pending.size();
+        }
+        CHECK("VoteIngest: a flood naming one authority stays bounded (queue <= per_author_cap, one call per cap votes)",
+              quiet && peak <= 2 && ing.verify_calls <= 10 && ing.used.empty() && ing.max_pending == committee.authorities.size() + 64);
+        auto a0 = ing.add_vote(vote(0)), a1 = ing.add_vote(vote(1)), a2 = ing.add_vote(vote(2));
+        CHECK("VoteIngest: the flooded authority's genuine vote still counts", a0.status.is_ok() && a1.status.is_ok() && a2.qc
+              && a2.qc->votes.size() == 3 && a2.qc->verify(committee).is_ok());
+    }
+    {
+        static double now = 0;
+        VoteIngest ing(committee);
+        ing.clock = +[]() { return now; };
+        ing.add_vote(vote(0)); ing.add_vote(vote(1));      // quorum 3 of 4: two verified-to-be, one missing
+        size_t calls0 = ing.verify_calls;
+        Vote f2 = vote(2); f2.signature.part1[0] ^= 1;
+        Vote f3 = vote(3); f3.signature.part1[0] ^= 1;
+        ing.add_vote(f2);                                  // could complete -> verified at once: miss 1
+        ing.add_vote(f3);                                  // again: miss 2 -> from now on groups of two
+        const size_t calls1 = ing.verify_calls;
+        Vote f2b = vote(2); f2b.signature.part1[0] ^= 2;
+        auto w = ing.add_vote(f2b);                        // waits: one pending, group size two
+        const bool waited = ing.verify_calls == calls1 && ing.pending.size() == 1 && !w.qc;
+        auto t0 = ing.tick();                              // not due yet
+        const bool no_call_yet = ing.verify_calls == calls1;
+        now += 0.01;
+        auto last = ing.add_vote(vote(3));                 // the honest last vote: past the deadline it is verified with the group
+        CHECK("VoteIngest: a forgery stream is verified in groups, the honest last vote completes the QC",
+              calls1 - calls0 == 2 && waited && !t0.qc && no_call_yet && ing.verify_calls == calls1 + 1 && last.qc && last.qc->votes.size() == 3);
+    }
     // ---- Timeout::verify and the verified-QC cache (messages.rs:250-265, core.rs:227-238)
     {
         VerifiedQCCache cache;

@@ -139,3 +139,30 @@ def test_the_dpp_guard_is_live(tmp_path):
     if bad is None:
         pytest.skip("LLVM tools not installed")
     assert len(bad) == 3 and all("v_subrev_u32_dpp" in l for l in bad)
+
+
+def test_library_exports_nothing_the_header_does_not_declare():
+    """the shipped library exported a load generator and an undeclared debug symbol.  Every
+    exported hs_ed25519_* symbol must be declared in include/hs_ed25519.h, and the measurement aid lives in
+    tools/libhs_loadgen.so, a client of the public ABI."""
+    import subprocess
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hs_ed25519.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(hs_ed25519_\w+)\s*\(", hdr))
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("hs_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert not any("loadgen" in n or "debug" in n for n in exported)
+    tool = os.path.join(ROOT, "tools", "libhs_loadgen.so")
+    if os.path.exists(tool):
+        deps = subprocess.run(["nm", "-D", "--undefined-only", tool], capture_output=True, text=True, check=True).stdout
+        used = {l.split()[-1] for l in deps.splitlines() if "hs_ed25519_" in l}
+        assert used and used <= declared          # the tool is an ordinary client of the public ABI
+
+
+def test_tenancy_and_pinned_alloc_need_the_right_moment():
+    lib = _lib.lib()
+    assert lib.hs_ed25519_set_tenancy(0, 0) == -3 and lib.hs_ed25519_set_tenancy(4, 4) == -3 and lib.hs_ed25519_set_tenancy(9, 0) == -3
+    if not torch.cuda.is_available():
+        assert lib.hs_ed25519_set_tenancy(4, 1) == 0 and lib.hs_ed25519_set_tenancy(1, 0) == 0     # before init: accepted
+        assert not lib.hs_ed25519_host_alloc(4096)              # no engine, no pinned memory
+        assert lib.hs_ed25519_shard_rccl_ranks() == 0

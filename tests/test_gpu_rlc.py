@@ -109,5 +109,5 @@ def test_small_calls_skip_the_pipeline():
     r = DeviceRunner(n)
     dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
     assert all(r.bits(dg, pk, sg, n, _lib.BATCH_RLC, True))
-    assert r.ctx.rlc_last() == (-1, 0)
+    assert r.ctx.rlc_last() == (_lib.RLC_NOT_RUN, 0)
     r.close()

@@ -131,3 +131,62 @@ def test_timeout_genesis_check_compares_hash_and_round_only():
     qc2 = QC(Digest(bytes([1]) * 32), 0, [])
     with pytest.raises(Exception):
         Timeout(qc2, 3, k, _Sig()).verify(committee)   # not genesis: verified (and rejected: no quorum)
+
+
+def _garbage(v, tag):
+    return Vote(v.hash, v.round, v.author, Signature(bytes([tag % 251 + 1]) * 32, bytes([tag // 251]) + bytes(31)))
+
+
+def test_forgery_stream_cannot_force_one_call_per_vote(oracle):
+    """once verified + pending stake reaches the quorum, every forged vote for a fresh authority
+    used to trigger its own verification call.  Now the second miss in a row starts coalescing: forgeries are verified in
+    groups of 2, 4, 8 ... and the honest last vote completes the certificate with the group it arrives in, or at the
+    deadline (tick)."""
+    votes = make_votes(40)
+    committee = Committee({v.author: 1 for v in votes})          # N = 40 -> quorum 27
+    now = [0.0]
+    ing = VoteIngest(committee, verify_fn=oracle_fn(oracle), clock=lambda: now[0], max_wait=0.002)
+    for v in votes[:26]:
+        assert ing.add_vote(v) is None
+    assert ing.gpu_calls == 0
+    # 12 forgeries for fresh authorities, one by one, at shortfall 1: each "could" complete the quorum
+    calls_before = ing.gpu_calls
+    for t, v in enumerate(votes[26:38]):
+        assert ing.add_vote(_garbage(v, t)) is None
+    forged_calls = ing.gpu_calls - calls_before
+    assert forged_calls <= 5, forged_calls                        # 1 + 1 + groups of 2, 4, (4 waiting): not 12
+    assert ing.valid_weight == 26
+    # the honest last vote: it joins the group that is waiting; the deadline verifies it if nobody else arrives
+    qc = ing.add_vote(votes[38])
+    if qc is None:
+        assert ing.tick() is None                                 # not yet due
+        now[0] += 0.003
+        qc = ing.tick()
+    assert qc is not None and len(qc.votes) == 27 and ing.done
+    assert sorted(a.b for a in ing.dropped) == sorted(v.author.b for v in votes[26:38])[:len(ing.dropped)]
+
+
+def test_same_author_flood_is_bounded_in_memory_and_calls(oracle):
+    """unlimited garbage votes naming ONE authority piled up unverified (distinct (author, signature)
+    keys, no stake added, nothing flushed).  Now at most `per_author_cap` wait per author: the queue stays bounded and the
+    flood costs one call per per_author_cap votes - and the authority's genuine vote still counts afterwards."""
+    votes = make_votes(7)
+    committee = Committee({v.author: 1 for v in votes})          # quorum 5
+    ing = VoteIngest(committee, verify_fn=oracle_fn(oracle), per_author_cap=2)
+    peak = 0
+    for t in range(100):
+        assert ing.add_vote(_garbage(votes[0], t)) is None
+        peak = max(peak, len(ing.pending))
+    assert peak <= 2 and ing.gpu_calls <= 50 and not ing.used
+    assert len(ing.pending) <= 2 and len(ing._pending_keys) == len(ing.pending)
+    for v in votes[:4]:
+        assert ing.add_vote(v) is None
+    qc = ing.add_vote(votes[4])
+    assert qc is not None and len(qc.votes) == 5 and votes[0].author in [a for a, _ in qc.votes]
+
+
+def test_default_max_pending_is_finite(oracle):
+    votes = make_votes(4)
+    committee = Committee({v.author: 1 for v in votes})
+    ing = VoteIngest(committee, verify_fn=oracle_fn(oracle))
+    assert ing.max_pending == committee.size() + 64

@@ -2,7 +2,10 @@
 (hs_ed25519_init_devices) and calls hs_ed25519_verify_shared_sharded - one contiguous shard per GPU launched from
 one thread, bitmap slices exchanged through the host or an in-process RCCL all-gather.  Prints one JSON object.
 
-    python tools/sharded_c_abi.py <gpus> [validators] [iters]
+    python tools/sharded_c_abi.py <gpus> [validators] [iters] [devices]
+
+`devices` < `gpus` (a rehearsal on fewer GPUs than slots): slot s runs on device s mod devices - the RCCL exchange
+then refuses (two slots on one device) and says so, everything else runs.
 
 Run by bench.py (rank 0) in a subprocess with a timeout, so that a fault on hardware this path has never seen
 cannot cost the bench line."""
@@ -23,8 +26,9 @@ def main():
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     import synth
     from hotstuff_amd import _lib
+    ndev = int(sys.argv[4]) if len(sys.argv) > 4 else ngpus
     n = 2 * validators // 3 + 1
-    _lib.init_devices(list(range(ngpus)), 8192)
+    _lib.init_devices([s % ndev for s in range(ngpus)], 8192)
     lib = _lib.lib()
     # the synthetic QC is signed on the GPU (hs_ed25519_public_keys / hs_ed25519_sign_batch): milliseconds instead of seconds
     seeds = b"".join(synth.key_seed(9_000_000 + i) for i in range(n))
@@ -34,7 +38,8 @@ def main():
     sg = _lib.sign_batch(secrets, dg, n, shared=True)
     b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
     a = [ctypes.addressof(x) for x in b]
-    out = {"n_validators": validators, "signatures": n, "gpus": ngpus, "process": "one process drives every GPU through the C ABI",
+    out = {"n_validators": validators, "signatures": n, "gpus": ngpus, "devices": ndev,
+           "process": "one process drives every GPU through the C ABI",
            "signatures_per_shard": _lib.shard_plan(n, ngpus, 0)[1]}
     for name, how in (("host_exchange", _lib.EXCHANGE_HOST), ("rccl_all_gather", _lib.EXCHANGE_RCCL)):
         try:
@@ -52,8 +57,48 @@ def main():
                 times.sort()
                 out.setdefault(name, {})[mode_name] = {"p50_ms": round(times[len(times) // 2] * 1e3, 4),
                                                        "verifies_per_s": round(n / times[len(times) // 2], 1)}
+            if how == _lib.EXCHANGE_RCCL:
+                out[name]["rccl_ranks"] = lib.hs_ed25519_shard_rccl_ranks()      # communicators ncclCommInitAll gave this process
         except Exception as e:
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the committee registered as a key set on every GPU: whole table per GPU, or each GPU the keys it owns
+    try:
+        lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
+        import random
+        import struct
+        # ranks sharing devices share their memory too: a smaller committee keeps the replicated tables within one GPU
+        nv = validators if ndev >= ngpus else min(validators, 12000)
+        nq = 2 * nv // 3 + 1
+        rng = random.Random(7)
+        voters = sorted(rng.sample(range(nv), nq))          # a QC = some 2f+1 subset of the committee, in committee order
+        committee = [synth.key_seed(400_000_000 + i) for i in range(nv)]      # non-voting members: any 32 bytes that are keys
+        for j, v in enumerate(voters):
+            committee[v] = pk[32 * j:32 * j + 32]
+        vsg = sg[:64 * nq]
+        vix = struct.pack("<%dI" % nq, *voters)
+        for pname, placement in (("replicate", _lib.KEYS_REPLICATE), ("by_owner", _lib.KEYS_BY_OWNER)):
+            try:
+                t0 = time.perf_counter()
+                kss = _lib.ShardedKeySet(committee, placement)
+                build_ms = (time.perf_counter() - t0) * 1e3
+                times = []
+                for i in range(iters + 3):
+                    t0 = time.perf_counter()
+                    ok, _ = kss.verify_packed(dg, vix, vsg, nq, _lib.BATCH, True)
+                    dt = time.perf_counter() - t0
+                    if not ok:
+                        raise RuntimeError("sharded key-cache QC rejected")
+                    if i >= 3:
+                        times.append(dt)
+                times.sort()
+                out.setdefault("key_cache", {"n_validators": nv, "signatures": nq})[pname] = {
+                    "p50_ms": round(times[len(times) // 2] * 1e3, 4), "verifies_per_s": round(nq / times[len(times) // 2], 1),
+                    "table_bytes_per_gpu": kss.bytes_per_device(0), "build_ms": round(build_ms, 1)}
+                kss.close()
+            except Exception as e:
+                out.setdefault("key_cache", {})[pname] = {"error": "%s: %s" % (type(e).__name__, e)}
+    except Exception as e:
+        out["key_cache"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # one corrupted signature must be localised across the shards
     try:
         lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
@@ -79,11 +124,9 @@ def main():
         aa = [ctypes.addressof(x) for x in bb]
         rows = []
         for th, k in ((16, 2), (16, 2 * ngpus), (16, 4 * ngpus)):
-            calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
-            _lib.check(lib.hs_ed25519_loadgen(None, aa[0], 32, aa[1], aa[2], bn, nb, _lib.STRICT, th, k, 2, 1.0, ctypes.byref(calls),
-                                              ctypes.byref(p50), ctypes.byref(el)), "hs_ed25519_loadgen")
-            rows.append({"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": 2, "call_p50_ms": round(p50.value, 4),
-                         "verifies_per_s": round(calls.value * bn / el.value, 1)})
+            cv, pv, ev = _lib.loadgen(None, aa[0], 32, aa[1], aa[2], bn, nb, _lib.STRICT, th, k, 2, 1.0)
+            rows.append({"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": 2, "call_p50_ms": round(pv, 4),
+                         "verifies_per_s": round(cv * bn / ev, 1)})
             if ngpus == 1:
                 break
         out["small_batches_all_gpus"] = {"signatures_per_call": bn, "api": "hs_ed25519_submit bursts of two + hs_ed25519_ticket_wait", "rows": rows}
