@@ -57,18 +57,20 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # verification, counted statically from the kernels' field-operation counts
 #   (field mul = 100 mads, square = 55; quad kernels count all four lanes of the quad),
 # against the chip-wide issue rate measured by tools/ubench_valu.hip (profiles/r1_ubench_valu.txt).
+# Round 3: the cold kernels verify the half-size form (halfscalar.h): [v s]B + [u](-A) + [v](-R) == O with |u|, v ~ 2^128 -
+# NWIN windows of four doublings (33 for 77 % of wavefronts, 34 for most of the rest; 34 is priced), two table additions per
+# window, two per-signature tables, sixteen additions of [w]B.  Round 2 priced 252 doublings + 64 + 16 additions: 232,690 (lane).
+NWIN = 34
 MAD_PER_VERIFY = {
-    # fused quad: per wavefront of 16 signatures 252 dbl x (55 + 100) + (64 + 16) add x 200 + table 7 x 300
-    # + decompress (255 sq + 21 mul), all x 64 lanes / 16 signatures.  (r2: the strict small-order test became a
-    # comparison of the canonical y - no doublings; [s]B went from 32 additions on 8-bit windows to 16 on 16-bit
-    # windows; the four doublings of the identity at the start are skipped.  r1 counted 315,860.)
-    "k_verify_fused": (252 * 155 + 80 * 200 + 7 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
+    # fused quad, per wavefront of 16 signatures: (NWIN - 1) x 4 doublings x (55 + 100) + (2 NWIN + 16) additions x 200
+    # + two tables 2 x 7 x 300 + decompress (255 sq + 21 mul), all x 64 lanes / 16 signatures
+    "k_verify_fused": ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
     # pairs form: a wavefront carries 32 signatures; one decompression pass of all 64 lanes serves both window loops
-    "k_verify_fused_pairs": (2 * (252 * 155 + 80 * 200 + 7 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
-    "k_verify_quad": (252 * 155 + 80 * 200 + 7 * 300) * 64 // 16,
-    # lane: 1008 sq + ~1450 mul in k_verify; k_prepare adds 2 x (255 sq + 21 mul)
-    "k_verify": 1008 * 55 + 1450 * 100,
-    "k_verify_batches": 1008 * 55 + 1450 * 100 + 2 * (255 * 55 + 21 * 100),
+    "k_verify_fused_pairs": (2 * ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
+    # lane: doublings 4 sq + 3 mul (+ 1 with T, every fourth); per window 15 mul in two additions; tables 2 x 65 mul;
+    # [w]B 16 x 7 mul; k_prepare adds 2 x (255 sq + 21 mul)
+    "k_verify": (NWIN - 1) * (4 * 520 + 100) + NWIN * 1500 + 13000 + 11200,
+    "k_verify_batches": (NWIN - 1) * (4 * 520 + 100) + NWIN * 1500 + 13000 + 11200 + 2 * (255 * 55 + 21 * 100),
 }
 MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 
@@ -315,7 +317,11 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
     n = 2 * validators // 3 + 1
     lo, hi, S = sharding.shard_bounds(n, world, rank)
     m = hi - lo
-    dg, pk, sg = synth.make_batch(m, shared=True, first=lo, cache_dir="/tmp/hs_synth")
+    # this rank's shard of the synthetic QC, signed on the GPU (hs_ed25519_sign_batch): milliseconds for any shard
+    seeds = b"".join(synth.key_seed(500_000_000 + lo + i) for i in range(m))
+    pk = _lib.public_keys(seeds, m)
+    dg = synth.shared_digest(11)
+    sg = _lib.sign_batch(b"".join(seeds[32 * i:32 * i + 32] + pk[32 * i:32 * i + 32] for i in range(m)), dg, m, shared=True)
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
     out = {"n_validators": validators, "signatures": n, "ranks": world, "signatures_per_shard": S,
@@ -327,7 +333,7 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
             ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(m)])      # this rank's slice of the committee
             d_ki = torch.arange(m, dtype=torch.int32, device=dev)
         v = sharding.GpuShardVerifier(d_dg, 0, None if cached else d_pk, d_sg, _lib.BATCH, max_batch=S,
-                                      keyset=ks, key_idx=d_ki)
+                                      keyset=ks, key_idx=d_ki, first=lo)
         for _ in range(5):
             ok, _bm = sharding.verify_sharded(v, n)
             assert ok, "sharded QC rejected"
@@ -353,8 +359,9 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
-               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16)),
-               pinned_shapes=((1, 64, 16), (1, 32, 8), (1, 64, 4), (4, 32, 16))):
+               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16), (1, 128, 8),
+                         (1, 256, 16)),
+               pinned_shapes=((1, 64, 16), (1, 128, 8), (1, 256, 16), (1, 64, 4), (4, 32, 16))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
     `threads` NATIVE host threads (tools/libhs_loadgen.so, a client of the public ABI - interpreter threads would measure
     the interpreter lock) each verify their own 1,024-tuple batch in a loop; every call stages into pinned memory,
@@ -703,8 +710,20 @@ def main():
     stride = 0 if shared else 32
     B = max(1, args.batches_per_step)
     ns = max(1, min(args.streams, B))
-    # one distinct synthetic batch per stream context (ns x 1,024 distinct tuples per GPU)
-    batches = [synth.make_batch(n, shared=shared, first=(rank * ns + j) * n, cache_dir="/tmp/hs_synth") for j in range(ns)]
+    # one distinct synthetic batch per stream context (ns x 1,024 distinct tuples per GPU).  Rank 0's are OpenSSL-signed
+    # fixtures (cached on disk, independent of the engine under test); the other ranks sign theirs on their GPU
+    # (hs_ed25519_sign_batch, bit-identical to OpenSSL by tests/test_gpu_wire_and_sign.py) - milliseconds instead of the
+    # ~10 s of host signing per rank, which would otherwise stagger the ranks' arrival at the first barrier
+    def gpu_signed_batch(first):
+        seeds = b"".join(synth.key_seed(first + i) for i in range(n))
+        pks = _lib.public_keys(seeds, n)
+        dgs = synth.shared_digest(1) if shared else b"".join(synth.msg_digest(first + i) for i in range(n))
+        sgs = _lib.sign_batch(b"".join(seeds[32 * i:32 * i + 32] + pks[32 * i:32 * i + 32] for i in range(n)), dgs, n, shared=shared)
+        return dgs, pks, sgs
+    if rank == 0:
+        batches = [synth.make_batch(n, shared=shared, first=j * n, cache_dir="/tmp/hs_synth") for j in range(ns)]
+    else:
+        batches = [gpu_signed_batch((rank * ns + j) * n) for j in range(ns)]
     dg, pk, sg = batches[0]
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_in = [tuple(t(x) for x in bt) for bt in batches]
@@ -1019,6 +1038,8 @@ def main():
                 res = fn()
         except Exception as e:
             res = {"error": "%s: %s" % (type(e).__name__, e)}
+            # a rank that fails alone leaves its peers inside the collective until rank 0's deadline: say why, at once
+            print("bench: rank %d: extra %s failed: %s" % (rank, key, res["error"]), file=sys.stderr, flush=True)
         if rank == 0:
             dog.disarm()
             out[key] = res

@@ -45,6 +45,7 @@ struct hs_ed25519_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
+    unsigned part = 0;            // which slice (narrow pool contexts)
     size_t cap = 0;               // signatures
     hs::u32 *d_ws = nullptr;      // workspace of the two-kernel cold path
     uint8_t *d_in = nullptr;      // digests | keys | sigs   (host API only)
@@ -82,6 +83,7 @@ struct dev_state {
     // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one XCD-aligned slice of the CUs)
     std::vector<hs_ed25519_ctx *> free_ctx[2];
     int live[2] = {0, 0};
+    unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
 };
 extern std::mutex g_mu;

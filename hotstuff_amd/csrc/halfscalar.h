@@ -1,0 +1,279 @@
+// halfscalar.h - half-size scalars for the cold verification path (host+device).
+//
+// dalek's strict / per-signature check is the exact point equation  D := [s]B + [k](-A) - R == O
+// (/root/reference/crypto/src/lib.rs:203 -> ed25519-dalek 1.0.1 verify_strict; k = SHA-512(R||A||M) mod L).  Evaluated as
+// written it costs 252 point doublings, 56 % of a cold verification, all on one serial chain.  Antipa et al. (SAC 2005)
+// and Pornin (2020, "Optimized lattice basis reduction in dimension 2, and fast Schnorr and EdDSA signature
+// verification") halve the scalars: take a SHORT vector (u, v) of the lattice
+//
+//          { (u, v) :  u = v k  (mod 8L) },        |u|, |v| ~ sqrt(8L) ~ 2^128,
+//
+// and check   [v s mod L]B + [u](-A) + [v](-R) == O   instead: u = v k modulo the ORDER OF THE WHOLE GROUP (8L, not L), so
+// [u]A = [v][k]A for every curve point A, torsion component included, and the left side is exactly [v]D.  D has order
+// dividing 8L; with v ODD and 0 < v < L,  [v]D = O  <=>  D = O  - the same verdict as dalek's on EVERY input, including
+// the mixed-order keys and R's of SURVEY.md 8a class (iii) (tests: all edge and torsion-fuzz vectors, CPU and GPU).
+// Cost: ~130 doublings instead of 252 for two more table additions per window; the B part needs no doublings at all
+// (the base point's sixteen 16-bit-window tables are absolute).
+//
+// The short vector comes from a truncated extended Euclid on (8L, k), Lehmer style: the quotient steps run on the leading
+// 63 bits in 64-bit arithmetic and are applied to the full numbers as one 2x2 matrix with 32-bit entries (multi-word
+// multiply-adds, which this chip does well).  NOTHING here needs to be exact for the verdict to be right: every step is a
+// unimodular row operation applied to remainders and cofactors alike, so (a, ta), (b, tb) always stay a basis of the
+// lattice (hence ta, tb are never both even); precision only decides how short the result is.  And the result is CHECKED
+// before use (half_scalar_ok: v odd, u = v k mod L and mod 8) - a pair that fails falls back to (k, 1), i.e. to the plain
+// equation.  The window loop's length follows the scalars it is given, so long pairs (special k such as L - 1, for which
+// no short odd-v vector exists) cost time, never correctness.
+#pragma once
+#include "sha512_sc.h"
+
+namespace hs {
+
+HS_HD int hs_clz32(u32 x) {      // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)x);
+#else
+    return __builtin_clz(x);
+#endif
+}
+HS_HD int hs_clz64(u64 x) {      // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+// bit length of an N-word little-endian number (0 for 0); lane-uniform select chain
+template <int N>
+HS_HD int mp_bitlen(const u32 *a) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) n = a[i] ? 32 * i + 32 - hs_clz32(a[i]) : n;
+    return n;
+}
+// bits [e, e + 64) of a 256-bit number, e in [0, 255]
+HS_HD u64 mp_window64(const u32 a[8], int e) {
+    const int wi = e >> 5, bit = e & 31;
+    u32 x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        x0 = wi == i ? a[i] : x0;
+        x1 = wi + 1 == i ? a[i] : x1;
+        x2 = wi + 2 == i ? a[i] : x2;
+    }
+    const u32 lo = (u32)((((u64)x1 << 32) | x0) >> bit), hi = (u32)((((u64)x2 << 32) | x1) >> bit);
+    return ((u64)hi << 32) | lo;
+}
+// r = p x - q y  modulo 2^(32 W)  (two's complement; exact whenever the true value fits W words)
+template <int W>
+HS_HD void mp_lin2(u32 *r, u32 p, const u32 *x, u32 q, const u32 *y) {
+    u64 cp = 0, cq = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        cp += (u64)p * x[i];
+        cq += (u64)q * y[i];
+        const u64 d = (u64)(u32)cp - (u32)cq - borrow;
+        r[i] = (u32)d;
+        borrow = (d >> 63) & 1;
+        cp >>= 32; cq >>= 32;
+    }
+}
+template <int W>
+HS_HD void mp_neg_if(u32 *r, bool neg) {       // two's complement negation under a predicate
+    const u32 m = neg ? 0xffffffffu : 0u;
+    u64 c = neg ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) { c += (u64)(r[i] ^ m); r[i] = (u32)c; c >>= 32; }
+}
+template <int W>
+HS_HD void mp_addsub(u32 *r, const u32 *x, const u32 *y, bool sub) {      // r = x + y or x - y, modulo 2^(32 W)
+    const u32 m = sub ? 0xffffffffu : 0u;
+    u64 c = sub ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) { c += (u64)x[i] + (y[i] ^ m); r[i] = (u32)c; c >>= 32; }
+}
+template <int W>
+HS_HD bool mp_less(const u32 *x, const u32 *y) {      // unsigned x < y
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) { const u64 d = (u64)x[i] - y[i] - borrow; borrow = (d >> 63) & 1; }
+    return borrow != 0;
+}
+template <int W>
+HS_HD void mp_swap_if(u32 *x, u32 *y, bool sw) {
+#pragma unroll
+    for (int i = 0; i < W; i++) { const u32 a = x[i], b = y[i]; x[i] = sw ? b : a; y[i] = sw ? a : b; }
+}
+
+#define HS_HALF_TARGET_BITS 131      // stop the reduction once the larger remainder has at most this many bits
+#define HS_HALF_COF_WORDS 6          // cofactors: two's complement, 192 bits (they stay below ~2^140)
+#define HS_8L_WORDS { 0xe7ae9f68u, 0xc09318d2u, 0x17bce6b2u, 0xa6f7cef5u, 0u, 0u, 0u, 0x80000000u }      // 8 L
+
+struct half_pair {
+    u32 u[8];        // |u|
+    u32 v[8];        // v > 0, odd
+    u32 u_neg;       // 1: u < 0
+};
+
+// (a, ta), (b, tb): a basis of { (x, t) : x = t k (mod 8L) } with a >= b >= 0 reduced until bitlen(a) <= target
+// (or until no further step is possible at this precision - then b is already far shorter than a).
+HS_HD void half_reduce(u32 a[9], u32 ta[HS_HALF_COF_WORDS], u32 b[9], u32 tb[HS_HALF_COF_WORDS], const u32 k[8]) {
+    const u32 n8[8] = HS_8L_WORDS;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = n8[i]; b[i] = k[i]; }
+    a[8] = b[8] = 0;
+#pragma unroll
+    for (int i = 0; i < HS_HALF_COF_WORDS; i++) { ta[i] = 0; tb[i] = 0; }
+    tb[0] = 1;
+    bool go = true;
+#pragma nounroll
+    for (int outer = 0; outer < 8; outer++) {
+        const int n = mp_bitlen<8>(a);
+        bool bzero = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) bzero = bzero && b[i] == 0;
+        go = go && !bzero && n > HS_HALF_TARGET_BITS;
+        // the leading 63 bits of a, and the bits of b at the same position
+        const int e = n > 63 ? n - 63 : 0;
+        u64 ah = mp_window64(a, e), bh = mp_window64(b, e);
+        // quotient steps on (ah, bh): row a = (p, -q), row b = (-r, s) up to a common sign `flip`
+        u64 p = 1, q = 0, r = 0, s = 1;
+        bool flip = false, run = go;
+        int steps = 0;
+#pragma nounroll
+        for (int it = 0; it < 44; it++) {
+            run = run && bh != 0 && (64 - hs_clz64(ah | 1)) + e > HS_HALF_TARGET_BITS;
+            int sft = hs_clz64(bh | 1) - hs_clz64(ah | 1);
+            sft = sft < 0 ? 0 : sft;
+            u64 t = bh << sft;
+            const bool over = t > ah;
+            t = over ? t >> 1 : t;
+            sft = over ? sft - 1 : sft;
+            run = run && sft >= 0 && sft < 32;
+            const u64 np = p + (r << (sft & 31)), nq = q + (s << (sft & 31));
+            run = run && (np >> 32) == 0 && (nq >> 32) == 0;
+            ah = run ? ah - t : ah;
+            p = run ? np : p; q = run ? nq : q;
+            steps += run ? 1 : 0;
+            const bool sw = run && ah < bh;
+            { const u64 x = ah; ah = sw ? bh : ah; bh = sw ? x : bh; }
+            { const u64 x = p; p = sw ? r : p; r = sw ? x : r; }
+            { const u64 x = q; q = sw ? s : q; s = sw ? x : s; }
+            flip = flip != sw;
+        }
+        go = go && steps > 0;
+        if (!go) { p = 1; q = 0; r = 0; s = 1; flip = false; }      // identity for the lanes that are done
+        // apply the matrix to the remainders and to the cofactors:  a' = +-(p a - q b),  b' = +-(s b - r a)
+        u32 na[9], nb[9], nta[HS_HALF_COF_WORDS], ntb[HS_HALF_COF_WORDS];
+        mp_lin2<9>(na, (u32)p, a, (u32)q, b);
+        mp_lin2<9>(nb, (u32)s, b, (u32)r, a);
+        mp_lin2<HS_HALF_COF_WORDS>(nta, (u32)p, ta, (u32)q, tb);
+        mp_lin2<HS_HALF_COF_WORDS>(ntb, (u32)s, tb, (u32)r, ta);
+        // remainders are kept non-negative (beyond the precision of the leading parts a difference may come out negative);
+        // the cofactor follows its remainder's sign.  `flip` (rows swapped an odd number of times) exchanges the roles.
+        const bool nega = (na[8] >> 31) != 0, negb = (nb[8] >> 31) != 0;
+        mp_neg_if<9>(na, nega); mp_neg_if<HS_HALF_COF_WORDS>(nta, nega);
+        mp_neg_if<9>(nb, negb); mp_neg_if<HS_HALF_COF_WORDS>(ntb, negb);
+        const bool sw = mp_less<9>(na, nb);
+        mp_swap_if<9>(na, nb, sw); mp_swap_if<HS_HALF_COF_WORDS>(nta, ntb, sw);
+        (void)flip;      // the ordering is re-established by value, not by parity
+#pragma unroll
+        for (int i = 0; i < 9; i++) { a[i] = na[i]; b[i] = nb[i]; }
+#pragma unroll
+        for (int i = 0; i < HS_HALF_COF_WORDS; i++) { ta[i] = nta[i]; tb[i] = ntb[i]; }
+    }
+}
+
+// |x| of a two's complement W-word number -> 8 words, and its sign
+template <int W>
+HS_HD bool mp_abs8(u32 out[8], const u32 *x) {
+    u32 t[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) t[i] = x[i];
+    const bool neg = (t[W - 1] >> 31) != 0;
+    mp_neg_if<W>(t, neg);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = i < W ? t[i] : 0;
+    return neg;
+}
+
+// The pair must be usable before it is trusted: v odd and non-zero, |u|, v < 2^253 (what the recodings take), and
+// u = v k modulo L and modulo 8 (together: modulo 8L).
+HS_HD bool half_scalar_ok(const half_pair &h, const u32 k[8]) {
+    bool ok = (h.v[0] & 1) != 0 && (h.v[7] >> 29) == 0 && (h.u[7] >> 29) == 0;
+    u32 vk[8];
+    sc_mul(vk, h.v, k);                                  // v k mod L
+    // u mod L: |u| < 2^253 < 2 L ... reduce by one conditional subtraction, then negate modulo L when u < 0
+    const u32 Lw[8] = HS_L_WORDS;
+    u32 um[8], t[8];
+    mp_addsub<8>(t, h.u, Lw, true);
+    const bool lt = mp_less<8>(h.u, Lw);
+#pragma unroll
+    for (int i = 0; i < 8; i++) um[i] = lt ? h.u[i] : t[i];
+    bool zero = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) zero = zero && um[i] == 0;
+    mp_addsub<8>(t, Lw, um, true);                       // L - um
+#pragma unroll
+    for (int i = 0; i < 8; i++) um[i] = (h.u_neg && !zero) ? t[i] : um[i];
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= um[i] ^ vk[i];
+    ok = ok && d == 0;
+    const u32 u8 = h.u_neg ? (0u - h.u[0]) & 7u : h.u[0] & 7u;
+    ok = ok && (((h.v[0] & 7u) * (k[0] & 7u)) & 7u) == u8;
+    return ok;
+}
+
+// (u, v) for the scalar k < L:  u = v k (mod 8L), v odd and positive, both as short as the lattice allows (~2^128 for all
+// but a negligible fraction of k; up to 2^253 for the few k that have no short odd-v vector).  Never fails: the plain
+// pair (k, 1) is the fallback.
+HS_HD void half_scalar(half_pair &out, const u32 k[8]) {
+    u32 a[9], b[9], ta[HS_HALF_COF_WORDS], tb[HS_HALF_COF_WORDS];
+    half_reduce(a, ta, b, tb, k);
+    // candidates: b, a, a - b, a + b (with their cofactors); the shortest one whose cofactor is odd
+    u32 cu[4][9], ct[4][HS_HALF_COF_WORDS];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { cu[0][i] = b[i]; cu[1][i] = a[i]; }
+#pragma unroll
+    for (int i = 0; i < HS_HALF_COF_WORDS; i++) { ct[0][i] = tb[i]; ct[1][i] = ta[i]; }
+    mp_addsub<9>(cu[2], a, b, true);  mp_addsub<HS_HALF_COF_WORDS>(ct[2], ta, tb, true);
+    mp_addsub<9>(cu[3], a, b, false); mp_addsub<HS_HALF_COF_WORDS>(ct[3], ta, tb, false);
+    int best = 1 << 20;
+    half_pair h;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { h.u[i] = k[i]; h.v[i] = 0; }
+    h.v[0] = 1; h.u_neg = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        u32 uu[8], vv[8];
+        const bool toolong = cu[c][8] != 0;                                  // only a + b can reach the ninth word
+        const bool vneg = mp_abs8<HS_HALF_COF_WORDS>(vv, ct[c]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) uu[i] = cu[c][i];
+        const int lu = mp_bitlen<8>(uu), lv = mp_bitlen<8>(vv);
+        const int len = lu > lv ? lu : lv;
+        const bool take = !toolong && (vv[0] & 1) && len < best;
+        best = take ? len : best;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { h.u[i] = take ? uu[i] : h.u[i]; h.v[i] = take ? vv[i] : h.v[i]; }
+        h.u_neg = take ? (vneg ? 1u : 0u) : h.u_neg;                         // remainders are >= 0: u takes -sign(v) after v is made positive
+    }
+    // the fallback pair, for whatever reason the candidate does not check out
+    const bool ok = half_scalar_ok(h, k);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { out.u[i] = ok ? h.u[i] : k[i]; out.v[i] = ok ? h.v[i] : (i == 0 ? 1u : 0u); }
+    out.u_neg = ok ? h.u_neg : 0u;
+}
+
+// number of signed radix-16 digits the recoded scalar r = x + 0x88...8 (sc_recode16) really has: the digits above are 0
+HS_HD int sc_recode16_len(const u32 r[8]) {
+    int n = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 d = r[i] ^ 0x88888888u;
+        n = d ? 8 * i + 8 - (hs_clz32(d) >> 2) : n;
+    }
+    return n;
+}
+
+}  // namespace hs

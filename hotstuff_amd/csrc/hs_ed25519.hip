@@ -11,7 +11,7 @@
 //                                         wavefront decompressing the R's beside the chains
 //               k_verify_cached_lane      above: one lane per signature
 //   k_tc_digests                          timeout-certificate digests ahead of any of the above
-//   (-DHS_AB_VARIANTS additionally builds k_verify_quad, k_verify_cached, _5w, _lane2: measured
+//   (-DHS_AB_VARIANTS additionally builds k_verify_cached, _5w, _lane2: measured
 //    and beaten forms kept for A/B runs, not part of the shipped library)
 // Every verify kernel takes an optional `skip` word: when the batch random-linear-combination
 // check (hs_rlc.hip) has already accepted the whole batch it writes an all-ones bitmap and leaves.
@@ -141,35 +141,6 @@ k_tc_digests(unsigned long long round, const unsigned long long *__restrict__ hq
 // Four lanes per signature (verify_quad.h): a wavefront covers 16 signatures, so a
 // 1,024-signature batch is 64 wavefronts on 64 CUs instead of 16.
 
-#ifdef HS_AB_VARIANTS
-__global__ void __launch_bounds__(64)
-k_verify_quad(workspace ws, u32 n, u32 mode, unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
-    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
-    qtab atab; atab.lds = s_atab;
-    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
-    const bool active = i < n;
-    bool flags_ok;
-    const qflags f = verify_quad(ws, active ? i : n - 1, mode, g_b16, flags_ok, atab);
-    unsigned long long m = __ballot(f.f && flags_ok && active);
-    // signature q accepted iff all four lanes of its quad agree; gather bit 4q -> bit q
-    m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
-    m = (m | (m >> 3)) & 0x0303030303030303ull;
-    m = (m | (m >> 6)) & 0x000f000f000f000full;
-    m = (m | (m >> 12)) & 0x000000ff000000ffull;
-    m = (m | (m >> 24)) & 0xffffull;
-    if (threadIdx.x == 0) {
-        bitmap16[blockIdx.x] = (unsigned short)m;
-        if (nreject) {
-            const u32 first = blockIdx.x * 16;
-            const u32 sigs = first < n ? min(16u, n - first) : 0u;
-            const u32 bad = sigs - (u32)__popcll(m);
-            if (bad) atomicAdd(nreject, bad);
-        }
-    }
-}
-
-#endif  // HS_AB_VARIANTS
-
 // Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
 // `block` = this wavefront's index within its batch (16 signatures per wavefront).
 __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
@@ -181,13 +152,13 @@ __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs
         if (threadIdx.x == 0) bitmap16[block] = (unsigned short)((1u << here) - 1);
         return;
     }
-    qtab atab; atab.lds = s_atab;
+    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS;
     const u32 i = block * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
     u32 msg[8];
     load_msg(msg, msgs, j);
-    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab);
+    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab, rtab);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
     m = (m | (m >> 3)) & 0x0303030303030303ull;
@@ -219,7 +190,7 @@ __device__ __forceinline__ u32 quad_ballot16(bool ok) {
 __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
                                                   const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
                                                   u32 *__restrict__ nreject) {
-    qtab atab; atab.lds = s_atab;
+    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS;
     const u32 q = threadIdx.x >> 2;
     const u32 i0 = block * 32 + q, i1 = i0 + 16;
     const u32 j0 = i0 < n ? i0 : n - 1, j1 = i1 < n ? i1 : n - 1;
@@ -228,7 +199,7 @@ __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_sr
 #pragma nounroll
     for (u32 h = 0; h < 2; h++) {
         const u32 i = h ? i1 : i0;
-        const bool ok = quad_pair_pass(pp, h, mode, g_b16, atab);
+        const bool ok = quad_pair_pass(pp, h, mode, g_b16, atab, rtab);
         const u32 m = quad_ballot16(ok && i < n);
         if (threadIdx.x == 0) bitmap16[2 * block + h] = (unsigned short)m;
         const u32 first = block * 32 + 16 * h;
@@ -239,7 +210,7 @@ __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_sr
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
                unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    __shared__ u32 s_atab[HS_QTAB_WORDS];       // this wavefront's j*(-A) tables (verify_quad.h)
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)       // this wavefront's j*(-A) tables (verify_quad.h)
     fused_block(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
 }
 // Several independent small batches in ONE grid (hs_ed25519_verify_device_batches): a 1,024-signature
@@ -251,7 +222,7 @@ struct fused_batch { msg_src msgs; const u32 *pks, *sigs; unsigned short *bitmap
 struct fused_batch_list { fused_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused_batches(fused_batch_list L) {
-    __shared__ u32 s_atab[HS_QTAB_WORDS];
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)
     u32 k = 0;
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
@@ -261,7 +232,7 @@ k_verify_fused_batches(fused_batch_list L) {
 // The same list served by the pairs form: first_block counts 32-signature wavefronts.
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused_pairs_batches(fused_batch_list L) {
-    __shared__ u32 s_atab[HS_QTAB_WORDS];
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)
     u32 k = 0;
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
@@ -648,7 +619,11 @@ static const size_t kCachedLane1Min = 98304;
 // HS_ED25519_PAIRS_MIN_BATCHES / HS_ED25519_LANE_MIN_BATCHES override the counts for A/B runs (0 = never).
 static std::atomic<size_t> g_pairs_min_batches{4}, g_lane_min_batches{8};
 static const size_t kLaneMinTotal = 8192;
-static const size_t kQuadMaxBatch = 32768;   // fused quad kernel up to here (latency), lane kernels above (throughput)
+// fused quad kernel up to here (latency), lane kernels above (throughput).  32,768 is also the API's bound on a list entry.
+// With the half-size form the quad kernels hold TWO per-signature tables in LDS (40,960 B per wavefront: one wavefront per
+// SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
+static std::atomic<size_t> g_quad_max_batch{16384};
+static const size_t kQuadMaxBatch = 32768;
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
 // of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py `end_to_end`); one caller
@@ -850,6 +825,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
     int have = 0;
@@ -907,10 +883,10 @@ extern "C" size_t hs_ed25519_min_gpu_batch(int keys_registered) {
 
 static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     const int f = ctx ? ctx->kernel : HS_K_AUTO;
-    if (f == HS_K_AUTO) return n <= kQuadMaxBatch ? HS_K_FUSED : HS_K_LANE;
+    if (f == HS_K_AUTO) return n <= g_quad_max_batch.load() ? HS_K_FUSED : HS_K_LANE;
     return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
 }
-extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= kQuadMaxBatch ? "k_verify_fused" : "k_verify"; }
+extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= g_quad_max_batch.load() ? "k_verify_fused" : "k_verify"; }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 // (for `count` batches of 1,024 signatures each: the lane form also wants 8,192 signatures in the call)
 extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
@@ -973,12 +949,6 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
     } else {
         HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
                "launch k_prepare");
-#ifdef HS_AB_VARIANTS
-        if (kern == 2 || kern == 12) {
-            void *aq[] = { &ws, &nn_, &mode_, &p_bm, &p_nr };
-            HS_HIP(launch1((const void *)k_verify_quad, dim3(np / 16), dim3(64), aq, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify_quad");
-        } else
-#endif
         HS_HIP(launch1((const void *)k_verify, dim3(np / 64), dim3(64), a2, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify");
     }
     return 0;

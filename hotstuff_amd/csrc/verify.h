@@ -20,6 +20,7 @@
 #pragma once
 #include "ge25519.h"
 #include "sha512_sc.h"
+#include "halfscalar.h"
 
 namespace hs {
 
@@ -29,21 +30,26 @@ enum : u32 { HS_F_ONCURVE = 1, HS_F_SMALL = 2, HS_F_SCANON = 4 };
 // Workspace between the stages, structure-of-arrays with row stride `np` (n padded to
 // 64) so that a wavefront's 64 lanes touch 64 consecutive dwords of every row:
 //   pt   [2][20][np] u32   x,y limbs of A (slot 0) and R (slot 1)
-//   sc   [16][np]    u32   k recoded signed radix-16 (rows 0-7), s recoded signed radix-256 (rows 8-15)
+//   sc   [24][np]    u32   the three scalars of the half-size form (halfscalar.h), recoded: |u| signed radix 16 (rows 0-7),
+//                          v signed radix 16 (rows 8-15), w = v s mod L signed radix 65536 (rows 16-23)
 //   flag [2][np]     u32   HS_F_* bits per point
-//   tab  [np][9][40] u32   stage 2's per-signature table j * (-A), j = 0..8, cached form (Y+X, Y-X, Z, 2dT), one
-//                          160-byte entry after the other: a lane reads the entry its digit picks with ten 16-byte
-//                          loads (the compiler's private-memory layout of the same array interleaves the lanes' dwords,
-//                          so that every one of the 40 dwords of a lookup touched up to 64 cache lines)
+//   meta [np]        u32   bits 0-7: windows the signature's u and v need (1 ... 64); bit 8: u is negative
+//   tab  [np][2][9][40] u32 stage 2's per-signature tables j * P, j = 0..8, for P = (+-)A and P = -R, cached form
+//                          (Y+X, Y-X, Z, 2dT), one 160-byte entry after the other: a lane reads the entry its digit picks
+//                          with ten 16-byte loads (the compiler's private-memory layout of the same array interleaves the
+//                          lanes' dwords, so that every one of the 40 dwords of a lookup touched up to 64 cache lines)
 struct workspace {
-    u32 *pt, *sc, *flag, *tab;
+    u32 *pt, *sc, *flag, *meta, *tab;
     u32 np;
 };
-#define HS_WS_TAB_WORDS (9 * 40)
-HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + 16 + 2 + HS_WS_TAB_WORDS); }
+#define HS_WS_SC_ROWS 24
+#define HS_WS_TAB1_WORDS (9 * 40)
+#define HS_WS_TAB_WORDS (2 * HS_WS_TAB1_WORDS)
+HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + HS_WS_SC_ROWS + 2 + 1 + HS_WS_TAB_WORDS); }
 HS_HD workspace workspace_at(u32 *base, size_t np) {
     workspace ws;
-    ws.np = (u32)np; ws.pt = base; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)16 * np; ws.tab = ws.flag + (size_t)2 * np;
+    ws.np = (u32)np; ws.pt = base; ws.sc = ws.pt + (size_t)40 * np; ws.flag = ws.sc + (size_t)HS_WS_SC_ROWS * np;
+    ws.meta = ws.flag + (size_t)2 * np; ws.tab = ws.meta + np;
     return ws;
 }
 HS_HD void ws_store_cached(u32 *p, const ge_cached &c) {
@@ -87,16 +93,28 @@ HS_HD void prepare_point(const workspace &ws, u32 i, bool is_r, const u32 *pk, c
 #pragma unroll
     for (int j = 0; j < 10; j++) { row[(size_t)j * ws.np] = p.X.v[j]; row[(size_t)(10 + j) * ws.np] = p.Y.v[j]; }
     if (is_r) {
-        u32 in[24], h[16], k[8], s[8], rk[8], rs[8];
+        u32 in[24], h[16], k[8], s[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
         sha512_96(h, in);
         sc_reduce512(k, h);
         fl |= sc_is_canonical(s) ? HS_F_SCANON : 0;
-        sc_recode16(rk, k);
-        sc_recode256(rs, s);     // meaningless when s >= L; the lane is rejected by HS_F_SCANON
+        // the half-size form of  [s]B + [k](-A) == R :   [v s]B + [u](-A) + [v](-R) == O,  u = v k (mod 8L), v odd
+        half_pair hp;
+        half_scalar(hp, k);
+        u32 w[8], ru[8], rv[8], rw[8];
+        sc_mul(w, hp.v, s);      // meaningless when s >= L; the lane is rejected by HS_F_SCANON
+        sc_recode16(ru, hp.u);
+        sc_recode16(rv, hp.v);
+        sc_recode65536(rw, w);
+        int nw = sc_recode16_len(ru);
+        const int nv = sc_recode16_len(rv);
+        nw = nw > nv ? nw : nv;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { ws.sc[(size_t)j * ws.np + i] = rk[j]; ws.sc[(size_t)(8 + j) * ws.np + i] = rs[j]; }
+        for (int j = 0; j < 8; j++) {
+            ws.sc[(size_t)j * ws.np + i] = ru[j]; ws.sc[(size_t)(8 + j) * ws.np + i] = rv[j]; ws.sc[(size_t)(16 + j) * ws.np + i] = rw[j];
+        }
+        ws.meta[i] = (u32)nw | (hp.u_neg << 8);
     }
     ws.flag[(size_t)slot * ws.np + i] = fl;
 }
@@ -153,80 +171,105 @@ HS_HD void ge_load_niels(ge_niels &n, const u32 *entry) {
 #pragma unroll
     for (int i = 0; i < 10; i++) { n.ymx.v[i] = w[i]; n.ypx.v[i] = w[10 + i]; n.xy2d.v[i] = w[20 + i]; }
 }
-// b16: window 0 of the base point's 16-bit table (verify_cached.h): entry j = j B, j <= 32,768, 128 bytes each,
-// L2 / MALL-resident - one addition per 16 doublings for [s]B.
+// the largest value of x over the lanes of the wavefront (x itself on the host, where a "wavefront" is one lane)
+HS_HD u32 wave_max_u32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const u32 y = (u32)__shfl_xor((int)x, m, 64); x = y > x ? y : x; }
+    return (u32)__builtin_amdgcn_readfirstlane((int)x);
+#else
+    return x;
+#endif
+}
+// j * P, j = 0..8, cached form, into nine consecutive 160-byte entries
+HS_HD void ws_build_table(u32 *tab, ge_p3 p) {
+    ge_cached a1, c;
+    ge_cached_identity(c);
+    ws_store_cached(tab, c);
+    ge_to_cached(a1, p);
+    ws_store_cached(tab + 40, a1);
+#pragma nounroll
+    for (int j = 2; j <= 8; j++) {
+        ge_p1p1 t;
+        ge_add(t, p, a1, false);
+        ge_p1p1_to_p3(p, t, true);
+        ge_to_cached(c, p);
+        ws_store_cached(tab + 40 * j, c);
+    }
+}
+// Stage 2 in the half-size form (halfscalar.h):  [w]B + [u](-A) + [v](-R) == O  with |u|, v ~ 2^128 - about 33 windows of
+// four doublings instead of 64, two table additions per window (the signature's tables of (+-)A and -R), and the
+// sixteen additions of [w]B from the base point's sixteen 16-bit-window tables (b16: T[i][j] = j 2^(16 i) B, 32,769
+// entries of 128 bytes per window; absolute multiples, added after the last doubling).
+// Control flow is uniform over the wavefront: every lane runs the window count of the lane that needs most.
 HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
     const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
     bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+    const u32 meta = ws.meta[i];
+    const bool u_neg = (meta >> 8) & 1;
 
-    ge_p3 p;                       // -A
-    fe rx, ry;
+    // per-lane tables j * P, j = 0..8, in this signature's slice of the workspace (indexed per lane below):
+    // P = -A (or +A when u < 0: the digits are those of |u|) and P = -R
+    u32 *atab = ws.tab + (size_t)i * HS_WS_TAB_WORDS, *rtab = atab + HS_WS_TAB1_WORDS;
     {
         const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
-        fe ax;
+        ge_p3 p;
+        fe x, nx;
 #pragma unroll
-        for (int j = 0; j < 10; j++) {
-            ax.v[j] = ra[(size_t)j * ws.np]; p.Y.v[j] = ra[(size_t)(10 + j) * ws.np];
-            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
-        }
-        fe_neg(p.X, ax);
+        for (int j = 0; j < 10; j++) { x.v[j] = ra[(size_t)j * ws.np]; p.Y.v[j] = ra[(size_t)(10 + j) * ws.np]; }
+        fe_neg(nx, x);
+        fe_select(p.X, nx, x, u_neg);
         fe_1(p.Z);
         fe_mul(p.T, p.X, p.Y);
-    }
-    u32 kw[8], sw[8];
+        ws_build_table(atab, p);
 #pragma unroll
-    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
-    {   // stage 1 stored s + 0x80..80 (radix 256); 16-bit windows want s + 0x8000..8000: subtract 0x0080..0080
-        u64 borrow = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const u64 t = (u64)sw[j] - 0x00800080u - borrow; sw[j] = (u32)t; borrow = (t >> 32) & 1; }
+        for (int j = 0; j < 10; j++) { x.v[j] = rr[(size_t)j * ws.np]; p.Y.v[j] = rr[(size_t)(10 + j) * ws.np]; }
+        fe_neg(p.X, x);
+        fe_1(p.Z);
+        fe_mul(p.T, p.X, p.Y);
+        ws_build_table(rtab, p);
     }
 
-    // per-lane table j * (-A), j = 0..8, in this signature's slice of the workspace (indexed per lane below)
-    u32 *atab = ws.tab + (size_t)i * HS_WS_TAB_WORDS;
-    {
-        ge_cached a1, c;
-        ge_cached_identity(c);
-        ws_store_cached(atab, c);
-        ge_to_cached(a1, p);
-        ws_store_cached(atab + 40, a1);
-#pragma nounroll
-        for (int j = 2; j <= 8; j++) {
-            ge_p1p1 t;
-            ge_add(t, p, a1, false);
-            ge_p1p1_to_p3(p, t, true);
-            ge_to_cached(c, p);
-            ws_store_cached(atab + 40 * j, c);
-        }
-    }
-
+    const int nwin = (int)wave_max_u32(meta & 0xffu);
+    const u32 *scu = ws.sc + i, *scv = ws.sc + (size_t)8 * ws.np + i, *scw = ws.sc + (size_t)16 * ws.np + i;
     ge_p3 acc;
     ge_identity(acc);
 #pragma nounroll
-    for (int w = 0; w < 64; w++) {
+    for (int w = nwin - 1; w >= 0; w--) {
         ge_p1p1 t;
-        const int nd = w ? 4 : 0;       // the accumulator is still the identity in the first window
+        const int nd = w == nwin - 1 ? 0 : 4;       // the accumulator is still the identity in the first window
 #pragma nounroll
         for (int d = 0; d < nd; d++) {
             ge_dbl(t, acc);
             ge_p1p1_to_p3(acc, t, d == 3);
         }
-        const int dk = sc_pop_digit(kw);
-        const int ik = dk < 0 ? -dk : dk;
-        ge_cached ea;
-        ws_load_cached(ea, atab + 40 * ik);
-        ge_add(t, acc, ea, dk < 0);
-        if ((w & 3) == 3) {     // [s]B: one 16-bit window per four 4-bit windows of k
-            ge_p1p1_to_p3(acc, t, true);
-            const int ds = sc_pop_digit16(sw);
-            ge_niels eb;
-            ge_load_niels(eb, b16 + (size_t)(ds < 0 ? -ds : ds) * 32);
-            ge_madd(t, acc, eb, ds < 0);
-        }
-        ge_p1p1_to_p3(acc, t, false);
+        // the digits of this window: one dword of each recoded scalar (wavefront-uniform row, coalesced)
+        const u32 sh = 4u * ((u32)w & 7u);
+        const int du = (int)((scu[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
+        const int dv = (int)((scv[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
+        ge_cached e;
+        ws_load_cached(e, atab + 40 * (du < 0 ? -du : du));
+        ge_add(t, acc, e, du < 0);
+        ge_p1p1_to_p3(acc, t, true);
+        ws_load_cached(e, rtab + 40 * (dv < 0 ? -dv : dv));
+        ge_add(t, acc, e, dv < 0);
+        ge_p1p1_to_p3(acc, t, w == 0);
     }
-    return ok && ge_match_point(acc, rx, ry);
+    // [w]B: sixteen entries of the base point's tables, T[j][d_j] = d_j 2^(16 j) B - absolute multiples, so they are added
+    // once the doublings are over
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        const int dw = (int)((scw[(size_t)(j >> 1) * ws.np] >> (16u * ((u32)j & 1u))) & 0xffffu) - 32768;
+        ge_niels eb;
+        ge_load_niels(eb, b16 + ((size_t)j * 32769 + (size_t)(dw < 0 ? -dw : dw)) * 32);
+        ge_p1p1 t;
+        ge_madd(t, acc, eb, dw < 0);
+        ge_p1p1_to_p3(acc, t, j < 15);
+    }
+    // [v]([s]B + [k](-A) - R) == O  <=>  the equation itself (v odd, halfscalar.h).  Z != 0: fail closed on a zeroed accumulator
+    fe_carry(acc.X); fe_carry(acc.Y); fe_carry(acc.Z);
+    return ok && fe_iszero(acc.X) && fe_eq(acc.Y, acc.Z) && !fe_iszero(acc.Z);
 }
 
 // ---- base-point table (computed once on the host at init) ----------------------------------

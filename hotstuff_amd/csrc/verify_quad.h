@@ -275,77 +275,71 @@ HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
     return q_eq_nz(rhs, lhs);
 }
 
-// The quad stage-2 core.  ax, ay, rx, ry (affine A and R) and the recoded scalars are uniform
-// across the four lanes of a quad.  atab entries are per lane: on the GPU each lane keeps its
-// own component in private memory.
-// b16: window 0 of the base point's 16-bit table (verify_cached.h): entry j = the affine Niels form of j B, j <= 32,768,
-// 128 bytes each (4.2 MB, L2 / MALL-resident) - [s]B costs 16 additions, one per 16 doublings, where 8-bit windows and
-// a 129-entry table cost 32.  kw: k in signed radix 16, sw: s in signed radix 65536.
-// Returns, per lane, whether this lane's coordinate check passed (lanes 2, 3: always true);
-// the caller ANDs the four lanes of the quad with the signature-level flags.
-HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, u32 kw[8], u32 sw[8],
-                             const u32 *b16, qtab &atab) {
-    // -A = (-x, y, 1, -xy): one vector multiplication (-x, y, 1, -x) * (1, 1, 1, y)
-    fe nax; fe_neg(nax, ax);
-    qv p = q_mul(q_lanes(nax, ay, fe_small(1), nax), q_lanes(fe_small(1), fe_small(1), fe_small(1), ay));
+// The recoded scalars of the half-size form (halfscalar.h) for one signature: |u| and v in signed radix 16, w = v s mod L
+// in signed radix 65536, how many windows u and v need, and the sign of u.
+struct half_scalars { u32 ru[8], rv[8], rw[8]; u32 meta; };      // meta: bits 0-7 windows (1 ... 64), bit 8: u < 0
 
-    // j * (-A), cached, j = 1..8 at index j - 1
-    {
-        const qv a1 = q_to_cached(p);
-        qtab_store(atab, 0, a1);
+// j * P, cached, j = 1..8 at index j - 1, for the affine point (x, y)
+HS_Q void qtab_build(qtab &tab, const fe &x, const fe &y) {
+    qv p = q_mul(q_lanes(x, y, fe_small(1), x), q_lanes(fe_small(1), fe_small(1), fe_small(1), y));       // (x, y, 1, xy)
+    const qv a1 = q_to_cached(p);
+    qtab_store(tab, 0, a1);
 #pragma nounroll
-        for (int j = 2; j <= 8; j++) {
-            p = q_add_cached(p, a1);
-            qtab_store(atab, j - 1, q_to_cached(p));
-        }
+    for (int j = 2; j <= 8; j++) {
+        p = q_add_cached(p, a1);
+        qtab_store(tab, j - 1, q_to_cached(p));
     }
-
-    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
-#pragma nounroll
-    for (int g = 0; g < 16; g++) {
-        // [s]B: one 16-bit window per four 4-bit windows of k; its entry is fetched now and added 16 doublings later
-        const int ds = sc_pop_digit16(sw);
-        const qv eb = q_load_entry(b16 + (size_t)(ds < 0 ? -ds : ds) * HS_ENTRY_WORDS);
-#pragma nounroll
-        for (int w = 0; w < 4; w++) {
-            // the accumulator is still the identity in the very first window: its four doublings are skipped
-            const int nd = (g | w) ? 4 : 0;
-#pragma nounroll
-            for (int d = 0; d < nd; d++) acc = q_dbl(acc);
-            const int dk = sc_pop_digit(kw);
-            const int ik = dk < 0 ? -dk : dk;
-            const qv ea = qtab_pick(atab, ik);
-            acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
-        }
-        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
-    }
-    return q_match_point(acc, rx, ry);
+}
+// acc == O as a point: X == 0 (lane 0), Y == Z (lane 1), Z != 0 (lanes 2, 3; fail closed on a zeroed accumulator, see
+// ge_match_point in verify.h).  The caller ANDs the four flags.
+HS_Q qflags q_is_identity(const qv &acc) {
+    const qv z = q_perm<2, 2, 2, 2>(acc);
+    const qv zero = q_lanes(fe_small(0), fe_small(0), fe_small(0), fe_small(0));
+    const qv rhs = q_sel<0b0001>(z, zero);                // (0, Z, Z, Z)
+    const qv lhs = q_carry(q_sel<0b1100>(acc, z));        // (X, Y, Z, Z), reduced
+    return q_eq_nz(rhs, lhs);
 }
 
-// stage 2 reading the workspace written by k_prepare
-HS_Q qflags verify_quad(const workspace &ws, u32 i, u32 mode, const u32 *b16, bool &flags_ok, qtab &atab) {
-    const u32 fa = ws.flag[i], fr = ws.flag[ws.np + i];
-    bool ok = (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE) && (fr & HS_F_SCANON);
-    if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
-    flags_ok = ok;
-    fe ax, ay, rx, ry;
+// The quad stage-2 core in the half-size form (halfscalar.h):  [w]B + [u](-A) + [v](-R) == O.  ax, ay, rx, ry (affine A
+// and R) and the recoded scalars are uniform across the four lanes of a quad; `nwin` (windows of four doublings) is uniform
+// over the wavefront.  atab / rtab: the per-signature tables j * (+-A) and j * (-R), j = 1..8, in LDS.
+// b16: the base point's sixteen 16-bit-window tables (verify_cached.h): T[i][j] = j 2^(16 i) B, 32,769 affine Niels entries
+// of 128 bytes per window - [w]B costs 16 additions and no doublings; they come after the window loop (absolute multiples).
+// Returns, per lane, whether this lane's part of the identity test passed; the caller ANDs the four lanes of the quad
+// with the signature-level flags.
+HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, half_scalars &hs, int nwin,
+                             const u32 *b16, qtab &atab, qtab &rtab) {
     {
-        const u32 *ra = ws.pt + i, *rr = ws.pt + (size_t)20 * ws.np + i;
-#pragma unroll
-        for (int j = 0; j < 10; j++) {
-            ax.v[j] = ra[(size_t)j * ws.np]; ay.v[j] = ra[(size_t)(10 + j) * ws.np];
-            rx.v[j] = rr[(size_t)j * ws.np]; ry.v[j] = rr[(size_t)(10 + j) * ws.np];
-        }
+        // (+-)A: -A when u > 0 (the digits are those of |u|), and -R
+        fe nax, sx, nrx;
+        fe_neg(nax, ax);
+        fe_select(sx, nax, ax, ((hs.meta >> 8) & 1) != 0);
+        qtab_build(atab, sx, ay);
+        fe_neg(nrx, rx);
+        qtab_build(rtab, nrx, ry);
     }
-    u32 kw[8], sw[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { kw[j] = ws.sc[(size_t)j * ws.np + i]; sw[j] = ws.sc[(size_t)(8 + j) * ws.np + i]; }
-    {   // stage 1 stored s + 0x80..80 (radix 256); the core wants s + 0x8000..8000 (radix 65536): subtract 0x0080..0080
-        u64 borrow = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const u64 t = (u64)sw[j] - 0x00800080u - borrow; sw[j] = (u32)t; borrow = (t >> 32) & 1; }
+    // the recoded scalars are popped from the top: drop the windows above the wavefront's count (all zero digits)
+#pragma nounroll
+    for (int t = nwin; t < 64; t++) { (void)sc_pop_digit(hs.ru); (void)sc_pop_digit(hs.rv); }
+    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
+#pragma nounroll
+    for (int w = nwin - 1; w >= 0; w--) {
+        // the accumulator is still the identity in the very first window: its four doublings are skipped
+        const int nd = w == nwin - 1 ? 0 : 4;
+#pragma nounroll
+        for (int d = 0; d < nd; d++) acc = q_dbl(acc);
+        const int du = sc_pop_digit(hs.ru);
+        acc = q_add_cached(acc, q_cached_signed(qtab_pick(atab, du < 0 ? -du : du), du < 0));
+        const int dv = sc_pop_digit(hs.rv);
+        acc = q_add_cached(acc, q_cached_signed(qtab_pick(rtab, dv < 0 ? -dv : dv), dv < 0));
     }
-    return verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
+#pragma nounroll
+    for (int j = 15; j >= 0; j--) {
+        const int ds = sc_pop_digit16(hs.rw);
+        const qv eb = q_load_entry(b16 + ((size_t)j * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
+        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
+    }
+    return q_is_identity(acc);
 }
 
 // The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
@@ -365,11 +359,30 @@ HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, 
     return sc_is_canonical(s);
 }
 
+// The same for the cold path's half-size form (halfscalar.h): hash, range check, the short pair (u, v) for k, w = v s mod L,
+// the three recodings, the window count.  Returns s < L.
+HS_HD bool prepare_scalars_half(half_scalars &out, const u32 *pk, const u32 *sig, const u32 *msg) {
+    u32 in[24], h[16], k[8], s[8], w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
+    sha512_96(h, in);
+    sc_reduce512(k, h);
+    half_pair hp;
+    half_scalar(hp, k);
+    sc_mul(w, hp.v, s);
+    sc_recode16(out.ru, hp.u);
+    sc_recode16(out.rv, hp.v);
+    sc_recode65536(out.rw, w);
+    const int nu = sc_recode16_len(out.ru), nv = sc_recode16_len(out.rv);
+    out.meta = (u32)(nu > nv ? nu : nv) | (hp.u_neg << 8);
+    return sc_is_canonical(s);
+}
+
 #if defined(__HIPCC__)
 // Fused stage 1 + stage 2 for one quad: lane 1 decompresses R, the other lanes decompress A
 // (one shared instruction stream), everybody hashes, DPP broadcasts hand A to the whole
 // quad, then the core.  One launch per batch and no workspace traffic.
-HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const u32 *b16, qtab &atab) {
+HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const u32 *b16, qtab &atab, qtab &rtab) {
     const u32 lane = q_lane();
     u32 enc[8];
 #pragma unroll
@@ -379,13 +392,14 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
     if (mode & HS_MODE_STRICT) fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
     const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
     const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
-    u32 kw[8], sw[8];
-    bool ok = prepare_scalars(kw, sw, pk, sig, msg, false, true);
+    half_scalars hs;
+    bool ok = prepare_scalars_half(hs, pk, sig, msg);
     ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
+    const int nwin = (int)wave_max_u32(hs.meta & 0xffu);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }
 
@@ -395,7 +409,7 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
 // all lanes useful), then the quad runs the window loop twice: 11 % fewer multiply-adds per verification, 1.85x the
 // latency of a wavefront (which now carries 32 signatures).  Used where the caller hands over enough batches per
 // launch to fill the chip anyway (hs_ed25519_verify_device_batches).
-struct quad_pair_points { fe X, Y; u32 fl; u32 kw[8], sw[8]; };
+struct quad_pair_points { fe X, Y; u32 fl; half_scalars hs; };
 // lane 0: A of signature j0, lane 1: R of j0, lane 2: A of j1, lane 3: R of j1; lanes 0, 1 also hash signature j0 and
 // lanes 2, 3 signature j1 (one SHA-512 pass for both; HS_F_SCANON in fl = s < L)
 HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, msg_src msgs, u32 j0, u32 j1, u32 mode) {
@@ -412,28 +426,32 @@ HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, msg_
     r.X = pt.X; r.Y = pt.Y;
     u32 msg[8];
     load_msg(msg, msgs, j);
-    if (prepare_scalars(r.kw, r.sw, pk, sig, msg, false, true)) r.fl |= HS_F_SCANON;
+    if (prepare_scalars_half(r.hs, pk, sig, msg)) r.fl |= HS_F_SCANON;
     return r;
 }
 // pass h (0 / 1, uniform over the wavefront): the quad's first / second signature
-HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 *b16, qtab &atab) {
+HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 *b16, qtab &atab, qtab &rtab) {
     fe sx = pp.X, sy = pp.Y;
     u32 sf = pp.fl;
-    u32 kw[8], sw[8];
+    half_scalars hs;
     if (h) {        // bring lanes 2, 3 down to lanes 0, 1
         sx = q_perm<2, 3, 2, 3>(pp.X); sy = q_perm<2, 3, 2, 3>(pp.Y);
         sf = (u32)__builtin_amdgcn_mov_dpp((int)pp.fl, HS_QP(2, 3, 2, 3), 0xf, 0xf, true);
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            kw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.kw[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
-            sw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.sw[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
+            hs.ru[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.ru[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
+            hs.rv[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.rv[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
+            hs.rw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.rw[t], HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
         }
+        hs.meta = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.meta, HS_QP(2, 2, 2, 2), 0xf, 0xf, true);
     } else {
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            kw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.kw[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
-            sw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.sw[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
+            hs.ru[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.ru[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
+            hs.rv[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.rv[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
+            hs.rw[t] = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.rw[t], HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
         }
+        hs.meta = (u32)__builtin_amdgcn_mov_dpp((int)pp.hs.meta, HS_QP(0, 0, 0, 0), 0xf, 0xf, true);
     }
     const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x00, 0xf, 0xf, true);
     const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)sf, 0x55, 0xf, 0xf, true);
@@ -442,7 +460,8 @@ HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(sx), ay = q_perm<0, 0, 0, 0>(sy);
     const fe rx = q_perm<1, 1, 1, 1>(sx), ry = q_perm<1, 1, 1, 1>(sy);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, kw, sw, b16, atab);
+    const int nwin = (int)wave_max_u32(hs.meta & 0xffu);
+    const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }
 #endif

@@ -77,13 +77,17 @@ class GpuShardVerifier:
     """verify_shard callable for device-resident inputs: slices the packed tensors and
     runs this rank's range through the C-ABI device entry point on the current stream."""
 
-    def __init__(self, digests, digest_stride, pks, sigs, mode, max_batch=None, keyset=None, key_idx=None):
+    def __init__(self, digests, digest_stride, pks, sigs, mode, max_batch=None, keyset=None, key_idx=None, first=0):
         """keyset / key_idx (int32 device tensor, one index per signature): verify through the
-        committee key cache instead of by key bytes (`pks` may then be None)."""
+        committee key cache instead of by key bytes (`pks` may then be None).
+        `first`: the global index of the first signature the tensors hold - a rank normally holds only its own shard
+        (signatures [lo, hi) of the call), so first = lo.  (Until round 3 the call indexed the tensors with GLOBAL
+        indices, which is only right for rank 0 or for tensors holding the whole batch: the first rehearsal of a second
+        rank found it.)"""
         from . import _lib
         self._lib = _lib
         self.digests, self.digest_stride, self.pks, self.sigs, self.mode = digests, digest_stride, pks, sigs, mode
-        self.keyset, self.key_idx = keyset, key_idx
+        self.keyset, self.key_idx, self.first = keyset, key_idx, int(first)
         self.ctx = _lib.DeviceContext(max_batch or 1024)
         # the kernels run on the context's own stream; consumers on torch's current stream (the
         # all-gather) are ordered behind it explicitly - a raw handle of 0 would mean "the
@@ -99,6 +103,11 @@ class GpuShardVerifier:
         bitmap = self._buf
         n = hi - lo
         if n > 0:
+            lo -= self.first                         # position inside the tensors this rank holds
+            held = self.sigs.numel() // 64
+            if lo < 0 or lo + n > held:
+                raise ValueError("shard [%d, %d) is outside the signatures this verifier holds [%d, %d)"
+                                 % (lo + self.first, lo + self.first + n, self.first, self.first + held))
             dg = self.digests if self.digest_stride == 0 else self.digests[32 * lo:]
             cur = torch.cuda.current_stream(dev)
             self._stream.wait_stream(cur)            # inputs / the zeroed bitmap were produced on `cur`

@@ -52,6 +52,15 @@ void emu_sha512_96(const uint8_t *in, uint8_t *out) { u32 wi[24], wo[16]; load_w
 void emu_tc_vote_digest(uint64_t round, uint64_t hq, uint8_t *out) { u32 w[8]; tc_vote_digest(w, round, hq); memcpy(out, w, 32); }
 void emu_sc_reduce512(const uint8_t *in, uint8_t *out) { u32 wi[16], wo[8]; load_words(wi, in, 16); sc_reduce512(wo, wi); memcpy(out, wo, 32); }
 void emu_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { u32 wa[8], wb[8], wo[8]; load_words(wa, a, 8); load_words(wb, b, 8); sc_mul(wo, wa, wb); memcpy(out, wo, 32); }
+// halfscalar.h: (|u|, u < 0, v) for k; returns 1 when the pair passed its own check (0: the (k, 1) fallback was taken)
+int emu_half_scalar(const uint8_t *k32, uint8_t *u32_out, int *u_neg, uint8_t *v32_out) {
+    u32 k[8]; load_words(k, k32, 8);
+    half_pair h; half_scalar(h, k);
+    memcpy(u32_out, h.u, 32); memcpy(v32_out, h.v, 32); *u_neg = (int)h.u_neg;
+    bool same = h.u_neg == 0; for (int i = 0; i < 8; i++) same = same && h.u[i] == k[i] && h.v[i] == (i == 0 ? 1u : 0u);
+    return same ? 0 : 1;
+}
+int emu_recode16_len(const uint8_t *x32) { u32 x[8], r[8]; load_words(x, x32, 8); sc_recode16(r, x); return sc_recode16_len(r); }
 int emu_sc_is_canonical(const uint8_t *s) { u32 w[8]; load_words(w, s, 8); return sc_is_canonical(w); }
 void emu_sc_digits8(const uint8_t *s, int16_t *digits) {
     u32 w[8], r[8]; load_words(w, s, 8); sc_recode256(r, w);
@@ -87,23 +96,23 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
     for (size_t i = 0; i < n; i++) out[i] = verify_lane(ws, (u32)i, mode, btab) ? 1 : 0;
 }
 const uint32_t *emu_base16(void);
-// the quad (4 lanes per signature) stage 2, same stage 1
+// the quad (4 lanes per signature) core (verify_quad_core) behind the scalar half of stage 1 (prepare_scalars) and a
+// plain decompression of A and R - what verify_quad_fused does on the device with DPP broadcasts
 void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
                      uint32_t mode, uint8_t *out) {
-    if (!n) return;
-    const u32 np = (u32)((n + 63) / 64 * 64);
-    std::vector<u32> buf(workspace_words(np));
-    workspace ws = workspace_at(buf.data(), np);
-    const u32 *btab = emu_base16();        // window 0 of the base point's 16-bit table: j B, j <= 32,768
-    for (size_t t = 0; t < 2 * n; t++) {
-        const bool is_r = t >= n; const size_t i = is_r ? t - n : t;
+    const u32 *btab = emu_base16();        // the base point's 16-bit tables
+    for (size_t i = 0; i < n; i++) {
         u32 pk[8], sig[16], msg[8];
         load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
-        prepare_point(ws, (u32)i, is_r, pk, sig, msg, mode);
-    }
-    for (size_t i = 0; i < n; i++) {
-        bool fl; qtab atab; qflags f = verify_quad(ws, (u32)i, mode, btab, fl, atab);
-        out[i] = (fl && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
+        ge_p3 A, R;
+        u32 fa = ge_decompress(A, pk) ? HS_F_ONCURVE : 0, fr = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
+        if (mode & HS_MODE_STRICT) { fa |= ge_is_small_order_affine(A.Y) ? HS_F_SMALL : 0; fr |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0; }
+        half_scalars hs;
+        bool ok = prepare_scalars_half(hs, pk, sig, msg);
+        ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
+        if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+        qtab atab, rtab; qflags f = verify_quad_core(A.X, A.Y, R.X, R.Y, hs, (int)(hs.meta & 0xffu), btab, atab, rtab);
+        out[i] = (ok && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
     }
 }
 // Every finishing form must reject an all-zero accumulator (what an arithmetic fault leaves behind:
