@@ -95,6 +95,8 @@ for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else (8192, 16384, 32768,
     b = measure(n, _lib.STRICT, _lib.KERNEL_LANE, shared=False)
     print("| %d | %.3f | %.3f | %.3f | %.1f | %.1f | %.1f |" % (n, a[0], c[0], b[0], a[1], c[1], b[1]), flush=True)
 
+if os.environ.get("HS_SWEEP_SKIP3"):
+    sys.exit(0)
 print("\n## 3. Key-cache path (batch semantics, shared digest, one key per signature): two-lane + R-wavefront kernel vs one-lane kernel\n")
 print("| signatures | lane2r p50 ms | lane p50 ms | lane2r M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
 print("|---|---|---|---|---|")
