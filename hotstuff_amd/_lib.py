@@ -9,7 +9,13 @@ import threading
 
 # one hardware queue per stream context (HIP's default of 4 multiplexes the pool / ring slots);
 # read by the HIP runtime when it initialises, i.e. at the first device call in the process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (a process that shares its GPU with co-tenants - HS_ED25519_TENANTS, include/hs_ed25519.h - takes its share of them)
+try:
+    _tenants = max(1, min(8, int(os.environ.get("HS_ED25519_TENANTS", "1"))))
+except ValueError:
+    _tenants = 1
+if os.environ.get("HS_ED25519_KEEP_ENV") != "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if _tenants == 1 else str(max(4, 16 // _tenants + 2)))
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HS_ED25519_LIB") or os.path.join(_HERE, "libhs_ed25519.so")   # override: A/B measurements

@@ -44,6 +44,8 @@ struct hs_ed25519_ctx {
     int slot = 0, device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
+    hipStream_t side = nullptr;   // large one-lane calls: the sliver past a whole round of wavefronts runs beside them (enqueue_cold)
+    hipEvent_t fork = nullptr, join = nullptr;
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     unsigned part = 0;            // which slice (narrow pool contexts)
     size_t cap = 0;               // signatures

@@ -43,6 +43,14 @@ HS_HD int hs_clz64(u64 x) {      // x != 0
 #endif
 }
 // bit length of an N-word little-endian number (0 for 0); lane-uniform select chain
+// does any lane of the wavefront want another round?  (on the host a "wavefront" is the one value)
+HS_HD bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(x) != 0ull;
+#else
+    return x;
+#endif
+}
 template <int N>
 HS_HD int mp_bitlen(const u32 *a) {
     int n = 0;
@@ -125,6 +133,8 @@ HS_HD void half_reduce(u32 a[9], u32 ta[HS_HALF_COF_WORDS], u32 b[9], u32 tb[HS_
     for (int i = 0; i < HS_HALF_COF_WORDS; i++) { ta[i] = 0; tb[i] = 0; }
     tb[0] = 1;
     bool go = true;
+    // both loops run as long as ANY lane of the wavefront still steps (uniform control flow; a finished lane idles through
+    // identity steps): typically 5 outer rounds of ~25-35 quotient steps, against the 8 x 44 of the bounds
 #pragma nounroll
     for (int outer = 0; outer < 8; outer++) {
         const int n = mp_bitlen<8>(a);
@@ -132,6 +142,7 @@ HS_HD void half_reduce(u32 a[9], u32 ta[HS_HALF_COF_WORDS], u32 b[9], u32 tb[HS_
 #pragma unroll
         for (int i = 0; i < 8; i++) bzero = bzero && b[i] == 0;
         go = go && !bzero && n > HS_HALF_TARGET_BITS;
+        if (!wave_any(go)) break;
         // the leading 63 bits of a, and the bits of b at the same position
         const int e = n > 63 ? n - 63 : 0;
         u64 ah = mp_window64(a, e), bh = mp_window64(b, e);
@@ -142,6 +153,7 @@ HS_HD void half_reduce(u32 a[9], u32 ta[HS_HALF_COF_WORDS], u32 b[9], u32 tb[HS_
 #pragma nounroll
         for (int it = 0; it < 44; it++) {
             run = run && bh != 0 && (64 - hs_clz64(ah | 1)) + e > HS_HALF_TARGET_BITS;
+            if (!wave_any(run)) break;
             int sft = hs_clz64(bh | 1) - hs_clz64(ah | 1);
             sft = sft < 0 ? 0 : sft;
             u64 t = bh << sft;

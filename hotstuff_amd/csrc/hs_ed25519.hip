@@ -43,6 +43,9 @@ using namespace hs;
 __device__ const u32 *g_b16;                      // window 0 of the base point's 16-bit table: j*B, j <= 32,768, 128-byte entries
                                                   // (verify_cached.h; built and set by hs_ed25519_init_devices)
 
+#ifndef HS_LANE_WAVES
+#define HS_LANE_WAVES 2                 // wavefronts per SIMD the one-lane stage 2 is compiled for (3 = 168 VGPRs with 36 B of spills: measured equal)
+#endif
 // (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
 __global__ void __launch_bounds__(64, 3)
 k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
@@ -57,7 +60,7 @@ k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__
     prepare_point(ws, i, is_r, pks + (size_t)8 * i, sigs + (size_t)16 * i, msg, mode);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, HS_LANE_WAVES)
 k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject,
          const u32 *__restrict__ skip) {
     if (skip && *skip) {
@@ -104,7 +107,7 @@ k_prepare_batches(lane_batch_list L) {
     if (is_r) load_msg(msg, B.msgs, i);
     prepare_point(B.ws, i, is_r, B.pks + (size_t)8 * i, B.sigs + (size_t)16 * i, msg, B.mode);
 }
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, HS_LANE_WAVES)
 k_verify_batches(lane_batch_list L) {
     u32 k = 0;
 #pragma unroll
@@ -624,6 +627,7 @@ static const size_t kLaneMinTotal = 8192;
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{16384};
 static const size_t kQuadMaxBatch = 32768;
+static const size_t kTailMax = 2048;         // the largest sliver past whole rounds of one-lane wavefronts that goes through the quad kernel (enqueue_cold)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
 // of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py `end_to_end`); one caller
@@ -730,6 +734,9 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->done) (void)hipEventDestroy(c->done);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
     hs::rlc_release(c);
@@ -947,6 +954,44 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused");
     } else {
+        // One lane per signature: a launch is ceil(n / 64) wavefronts for the chip's 1,024 SIMDs, and its time is that of
+        // the SIMD with most wavefronts - 66,667 signatures (the QC of N = 100,000) are 1,042 wavefronts, eighteen SIMDs
+        // carry two, and the call took 1.49 ms where 65,536 signatures take 0.85.  When such a sliver
+        // is left over (up to one round of the quad kernel: 16 signatures per wavefront, a third of the one-lane
+        // wavefront's time), it goes through k_verify_fused instead - on a side stream, beside the one-lane pair.
+        const size_t round_sigs = (size_t)g_devs[ctx->slot].cus * 4 * 64;
+        const size_t tail = round_sigs ? n % round_sigs : 0;
+        if (ctx->kernel == HS_K_AUTO && n > round_sigs && tail && tail <= kTailMax) {
+            const size_t main_n = n - tail;                      // a multiple of 64: the tail's bitmap starts on a word
+            msg_src tmsgs = msgs;
+            tmsgs.digests = msgs.digests + (size_t)msgs.stride_words * main_n;
+            const u32 *t_pk = p_pk + (size_t)8 * main_n, *t_sg = p_sg + (size_t)16 * main_n;
+            unsigned long long *t_bm = p_bm + main_n / 64;
+            u32 tn = (u32)tail;
+            void *at[] = { &tmsgs, &t_pk, &t_sg, &tn, &mode_, &t_bm, &p_nr, &p_skip };
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cap);
+            hipStream_t side = st;
+            if (cap == hipStreamCaptureStatusNone) {             // (under graph capture the two parts simply follow each other)
+                if (!ctx->side) {
+                    HS_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking), "hipStreamCreate (side stream)");
+                    HS_HIP(hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming), "hipEventCreate");
+                    HS_HIP(hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming), "hipEventCreate");
+                }
+                side = ctx->side;
+                HS_HIP(hipEventRecord(ctx->fork, st), "hipEventRecord");         // the inputs' producers were ordered on st
+                HS_HIP(hipStreamWaitEvent(side, ctx->fork, 0), "hipStreamWaitEvent");
+            }
+            HS_HIP(launch1((const void *)k_verify_fused, dim3((unsigned)(round_up(tail, 64) / 16)), dim3(64), at, side, nullptr, nullptr),
+                   "launch k_verify_fused (tail)");
+            if (side != st) HS_HIP(hipEventRecord(ctx->join, side), "hipEventRecord");
+            nn_ = (u32)main_n;
+            HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn_ + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
+                   "launch k_prepare");
+            HS_HIP(launch1((const void *)k_verify, dim3(nn_ / 64), dim3(64), a2, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify");
+            if (side != st) HS_HIP(hipStreamWaitEvent(st, ctx->join, 0), "hipStreamWaitEvent");
+            return 0;
+        }
         HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
                "launch k_prepare");
         HS_HIP(launch1((const void *)k_verify, dim3(np / 64), dim3(64), a2, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify");

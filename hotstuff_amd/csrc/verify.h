@@ -34,16 +34,18 @@ enum : u32 { HS_F_ONCURVE = 1, HS_F_SMALL = 2, HS_F_SCANON = 4 };
 //                          v signed radix 16 (rows 8-15), w = v s mod L signed radix 65536 (rows 16-23)
 //   flag [2][np]     u32   HS_F_* bits per point
 //   meta [np]        u32   bits 0-7: windows the signature's u and v need (1 ... 64); bit 8: u is negative
-//   tab  [np][2][9][40] u32 stage 2's per-signature tables j * P, j = 0..8, for P = (+-)A and P = -R, cached form
-//                          (Y+X, Y-X, Z, 2dT), one 160-byte entry after the other: a lane reads the entry its digit picks
-//                          with ten 16-byte loads (the compiler's private-memory layout of the same array interleaves the
-//                          lanes' dwords, so that every one of the 40 dwords of a lookup touched up to 64 cache lines)
+//   tab  [np][2][9][32] u32 stage 2's per-signature tables j * P, j = 0..8, for P = (+-)A and P = -R, cached form
+//                          (Y+X, Y-X, Z, 2dT) with every coordinate packed to 255 bits: one 128-byte entry = one cache
+//                          line after the other; a lane reads the entry its digit picks with eight 16-byte loads (the
+//                          compiler's private-memory layout of the same array interleaves the lanes' dwords, so that every
+//                          dword of a lookup touched up to 64 cache lines; round 2's 160-byte entries straddled two lines)
 struct workspace {
     u32 *pt, *sc, *flag, *meta, *tab;
     u32 np;
 };
 #define HS_WS_SC_ROWS 24
-#define HS_WS_TAB1_WORDS (9 * 40)
+#define HS_WS_ENTRY_WORDS 32
+#define HS_WS_TAB1_WORDS (9 * HS_WS_ENTRY_WORDS)
 #define HS_WS_TAB_WORDS (2 * HS_WS_TAB1_WORDS)
 HS_HD size_t workspace_words(size_t np) { return (size_t)np * (2 * 20 + HS_WS_SC_ROWS + 2 + 1 + HS_WS_TAB_WORDS); }
 HS_HD workspace workspace_at(u32 *base, size_t np) {
@@ -52,29 +54,57 @@ HS_HD workspace workspace_at(u32 *base, size_t np) {
     ws.meta = ws.flag + (size_t)2 * np; ws.tab = ws.meta + np;
     return ws;
 }
+// A table entry in the workspace: the four coordinates of the cached form packed to 255 bits each, 4 x 32 bytes = ONE
+// 128-byte line (ten 32-bit limbs per coordinate are 160 bytes, which straddle two lines: with two tables per signature
+// the lookups' lines, not the arithmetic, bounded the one-lane kernel - profiles/r3_pmc_traffic.json).
+// fe_pack255: any lazily reduced element (limbs < 2^28, value < 2^256) -> the same residue as an integer below 2^255.
+// The limbs are SUMMED at their bit offsets (0, 26, 51, 77, 102, 128, 153, 179, 204, 230) rather than OR-ed, so limb
+// slack is absorbed arithmetically, and bit 255 is folded back as 19.
+HS_HD void fe_pack255(u32 w[8], const fe &a) {
+    u64 acc = (u64)a.v[0] + ((u64)a.v[1] << 26);
+    w[0] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[2] << 19;
+    w[1] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[3] << 13;
+    w[2] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[4] << 6;
+    w[3] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[5] + ((u64)a.v[6] << 25);
+    w[4] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[7] << 19;
+    w[5] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[8] << 12;
+    w[6] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[9] << 6;
+    HS_CHECK((acc >> 32) == 0, "fe_pack255: value does not fit 256 bits");
+    const u32 top = (u32)acc;
+    w[7] = top & 0x7fffffffu;
+    u64 c = 19u * (top >> 31);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += w[i]; w[i] = (u32)c; c >>= 32; }
+    HS_CHECK((w[7] >> 31) == 0, "fe_pack255: fold did not land below 2^255");
+}
 HS_HD void ws_store_cached(u32 *p, const ge_cached &c) {
+    u32 w[32];
+    fe_pack255(w, c.YpX); fe_pack255(w + 8, c.YmX); fe_pack255(w + 16, c.Z); fe_pack255(w + 24, c.T2d);
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     uint4 *q = reinterpret_cast<uint4 *>(p);
-    u32 w[40];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z.v[i]; w[30 + i] = c.T2d.v[i]; }
-#pragma unroll
-    for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    for (int i = 0; i < 8; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 #else
-    for (int i = 0; i < 10; i++) { p[i] = c.YpX.v[i]; p[10 + i] = c.YmX.v[i]; p[20 + i] = c.Z.v[i]; p[30 + i] = c.T2d.v[i]; }
+    for (int i = 0; i < 32; i++) p[i] = w[i];
 #endif
 }
 HS_HD void ws_load_cached(ge_cached &c, const u32 *p) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    u32 w[40];
+    u32 w[32];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    for (int i = 0; i < 8; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
 #else
     const u32 *w = p;
 #endif
-#pragma unroll
-    for (int i = 0; i < 10; i++) { c.YpX.v[i] = w[i]; c.YmX.v[i] = w[10 + i]; c.Z.v[i] = w[20 + i]; c.T2d.v[i] = w[30 + i]; }
+    fe_from_words(c.YpX, w); fe_from_words(c.YmX, w + 8); fe_from_words(c.Z, w + 16); fe_from_words(c.T2d, w + 24);
 }
 
 // ---- stage 1 ------------------------------------------------------------------------------
@@ -187,14 +217,14 @@ HS_HD void ws_build_table(u32 *tab, ge_p3 p) {
     ge_cached_identity(c);
     ws_store_cached(tab, c);
     ge_to_cached(a1, p);
-    ws_store_cached(tab + 40, a1);
+    ws_store_cached(tab + HS_WS_ENTRY_WORDS, a1);
 #pragma nounroll
     for (int j = 2; j <= 8; j++) {
         ge_p1p1 t;
         ge_add(t, p, a1, false);
         ge_p1p1_to_p3(p, t, true);
         ge_to_cached(c, p);
-        ws_store_cached(tab + 40 * j, c);
+        ws_store_cached(tab + HS_WS_ENTRY_WORDS * j, c);
     }
 }
 // Stage 2 in the half-size form (halfscalar.h):  [w]B + [u](-A) + [v](-R) == O  with |u|, v ~ 2^128 - about 33 windows of
@@ -231,7 +261,11 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
         ws_build_table(rtab, p);
     }
 
+#ifdef HS_FORCE_NWIN
+    const int nwin = HS_FORCE_NWIN;          // timing experiments only (wrong verdicts for scalars that need more windows)
+#else
     const int nwin = (int)wave_max_u32(meta & 0xffu);
+#endif
     const u32 *scu = ws.sc + i, *scv = ws.sc + (size_t)8 * ws.np + i, *scw = ws.sc + (size_t)16 * ws.np + i;
     ge_p3 acc;
     ge_identity(acc);
@@ -249,10 +283,10 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
         const int du = (int)((scu[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
         const int dv = (int)((scv[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
         ge_cached e;
-        ws_load_cached(e, atab + 40 * (du < 0 ? -du : du));
+        ws_load_cached(e, atab + HS_WS_ENTRY_WORDS * (du < 0 ? -du : du));
         ge_add(t, acc, e, du < 0);
         ge_p1p1_to_p3(acc, t, true);
-        ws_load_cached(e, rtab + 40 * (dv < 0 ? -dv : dv));
+        ws_load_cached(e, rtab + HS_WS_ENTRY_WORDS * (dv < 0 ? -dv : dv));
         ge_add(t, acc, e, dv < 0);
         ge_p1p1_to_p3(acc, t, w == 0);
     }

@@ -277,6 +277,11 @@ HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
 
 // The recoded scalars of the half-size form (halfscalar.h) for one signature: |u| and v in signed radix 16, w = v s mod L
 // in signed radix 65536, how many windows u and v need, and the sign of u.
+#ifdef HS_FORCE_NWIN
+#define HS_NWIN_OF(meta) (HS_FORCE_NWIN)     // timing experiments only
+#else
+#define HS_NWIN_OF(meta) ((int)wave_max_u32((meta) & 0xffu))
+#endif
 struct half_scalars { u32 ru[8], rv[8], rw[8]; u32 meta; };      // meta: bits 0-7 windows (1 ... 64), bit 8: u < 0
 
 // j * P, cached, j = 1..8 at index j - 1, for the affine point (x, y)
@@ -398,7 +403,7 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
-    const int nwin = (int)wave_max_u32(hs.meta & 0xffu);
+    const int nwin = HS_NWIN_OF(hs.meta);
     const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }
@@ -460,7 +465,7 @@ HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(sx), ay = q_perm<0, 0, 0, 0>(sy);
     const fe rx = q_perm<1, 1, 1, 1>(sx), ry = q_perm<1, 1, 1, 1>(sy);
-    const int nwin = (int)wave_max_u32(hs.meta & 0xffu);
+    const int nwin = HS_NWIN_OF(hs.meta);
     const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }

@@ -23,7 +23,14 @@ def test_bench_gpus_2_runs_by_itself_and_its_exchange_extras_work():
                         "--batches-per-step", "64", "--large-committee", "3000"],
                        capture_output=True, text=True, timeout=600, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-3000:])
+    try:        # keep the ranks' stderr where a gpurun visit can pick it up
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "test_bench_gpus2.err"), "w") as f:
+            f.write(r.stderr)
+    except OSError:
+        pass
+    tb = "\n".join(l for l in r.stderr.splitlines() if l.startswith(("[rank", "bench:")) or "Error" in l)
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, tb[-4000:])
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["ranks"]["world"] == 2
     sc = j["sharded_committee"]
