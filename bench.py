@@ -61,12 +61,16 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # NWIN windows of four doublings (33 for 77 % of wavefronts, 34 for most of the rest; 34 is priced), two table additions per
 # window, two per-signature tables, sixteen additions of [w]B.  Round 2 priced 252 doublings + 64 + 16 additions: 232,690 (lane).
 NWIN = 34
+NWIN3 = 45
 MAD_PER_VERIFY = {
     # fused quad, per wavefront of 16 signatures: (NWIN - 1) x 4 doublings x (55 + 100) + (2 NWIN + 16) additions x 200
     # + two tables 2 x 7 x 300 + decompress (255 sq + 21 mul), all x 64 lanes / 16 signatures
     "k_verify_fused": ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
+    # the same with 3-bit windows (NWIN3 windows of three doublings, four-entry tables): the kernels that put several
+    # batches into one launch, two wavefronts per SIMD
+    "k_verify_fused3": ((NWIN3 - 1) * 3 * 155 + (2 * NWIN3 + 16) * 200 + 6 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
     # pairs form: a wavefront carries 32 signatures; one decompression pass of all 64 lanes serves both window loops
-    "k_verify_fused_pairs": (2 * ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
+    "k_verify_fused_pairs": (2 * ((NWIN3 - 1) * 3 * 155 + (2 * NWIN3 + 16) * 200 + 6 * 300) + 255 * 55 + 21 * 100) * 64 // 32,
     # lane: doublings 4 sq + 3 mul (+ 1 with T, every fourth); per window 15 mul in two additions; tables 2 x 65 mul;
     # [w]B 16 x 7 mul; k_prepare adds 2 x (255 sq + 21 mul)
     "k_verify": (NWIN - 1) * (4 * 520 + 100) + NWIN * 1500 + 13000 + 11200,
@@ -991,7 +995,7 @@ def main():
                            "k_verify": round(avg_verify_ms, 4)},
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
-        kname = {"k_verify_fused_batches": "k_verify_fused", "k_verify_fused_pairs_batches": "k_verify_fused_pairs"}.get(kernel_name, kernel_name)
+        kname = {"k_verify_fused_batches": "k_verify_fused3", "k_verify_fused_pairs_batches": "k_verify_fused_pairs"}.get(kernel_name, kernel_name)
         if kname in MAD_PER_VERIFY:
             mad_s = value / world * MAD_PER_VERIFY[kname]
             out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,

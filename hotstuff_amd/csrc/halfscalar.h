@@ -16,8 +16,8 @@
 // (the base point's sixteen 16-bit-window tables are absolute).
 //
 // The short vector comes from a truncated extended Euclid on (8L, k), Lehmer style: the quotient steps run on the leading
-// 63 bits in 64-bit arithmetic and are applied to the full numbers as one 2x2 matrix with 32-bit entries (multi-word
-// multiply-adds, which this chip does well).  NOTHING here needs to be exact for the verdict to be right: every step is a
+// 63 bits (64-bit arithmetic, the quotient from one double-precision division) and are applied to the full numbers as one
+// 2x2 matrix with 32-bit entries (multi-word multiply-adds, which this chip does well).  NOTHING here needs to be exact for the verdict to be right: every step is a
 // unimodular row operation applied to remainders and cofactors alike, so (a, ta), (b, tb) always stay a basis of the
 // lattice (hence ta, tb are never both even); precision only decides how short the result is.  And the result is CHECKED
 // before use (half_scalar_ok: v odd, u = v k mod L and mod 8) - a pair that fails falls back to (k, 1), i.e. to the plain
@@ -42,7 +42,6 @@ HS_HD int hs_clz64(u64 x) {      // x != 0
     return __builtin_clzll(x);
 #endif
 }
-// bit length of an N-word little-endian number (0 for 0); lane-uniform select chain
 // does any lane of the wavefront want another round?  (on the host a "wavefront" is the one value)
 HS_HD bool wave_any(bool x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -51,6 +50,7 @@ HS_HD bool wave_any(bool x) {
     return x;
 #endif
 }
+// bit length of an N-word little-endian number (0 for 0); lane-uniform select chain
 template <int N>
 HS_HD int mp_bitlen(const u32 *a) {
     int n = 0;
@@ -112,7 +112,7 @@ HS_HD void mp_swap_if(u32 *x, u32 *y, bool sw) {
     for (int i = 0; i < W; i++) { const u32 a = x[i], b = y[i]; x[i] = sw ? b : a; y[i] = sw ? a : b; }
 }
 
-#define HS_HALF_TARGET_BITS 131      // stop the reduction once the larger remainder has at most this many bits
+#define HS_HALF_TARGET_BITS 130      // stop the reduction once the larger remainder has at most this many bits
 #define HS_HALF_COF_WORDS 6          // cofactors: two's complement, 192 bits (they stay below ~2^140)
 #define HS_8L_WORDS { 0xe7ae9f68u, 0xc09318d2u, 0x17bce6b2u, 0xa6f7cef5u, 0u, 0u, 0u, 0x80000000u }      // 8 L
 
@@ -146,48 +146,52 @@ HS_HD void half_reduce(u32 a[9], u32 ta[HS_HALF_COF_WORDS], u32 b[9], u32 tb[HS_
         // the leading 63 bits of a, and the bits of b at the same position
         const int e = n > 63 ? n - 63 : 0;
         u64 ah = mp_window64(a, e), bh = mp_window64(b, e);
-        // quotient steps on (ah, bh): row a = (p, -q), row b = (-r, s) up to a common sign `flip`
-        u64 p = 1, q = 0, r = 0, s = 1;
-        bool flip = false, run = go;
+        // Euclid steps on (ah, bh): row a = (p, -q), row b = (-r, s) up to a common sign; a step replaces
+        // (row a, row b) by (row b, row a - quot row b).  The quotient comes from one double-precision division (both
+        // operands below 2^63, the quotient below 2^32: the estimate is off by one at most, and a remainder that comes
+        // out negative or >= bh says which way).  Masks instead of selects throughout: a lone wavefront pays 20+ cycles
+        // for a v_cndmask on a freshly written condition (profiles/r1_ubench_valu.txt), a handful for and / xor.
+        u32 p = 1, q = 0, r = 0, s = 1;
+        bool run = go;
         int steps = 0;
 #pragma nounroll
-        for (int it = 0; it < 44; it++) {
+        for (int it = 0; it < 40; it++) {
             run = run && bh != 0 && (64 - hs_clz64(ah | 1)) + e > HS_HALF_TARGET_BITS;
             if (!wave_any(run)) break;
-            int sft = hs_clz64(bh | 1) - hs_clz64(ah | 1);
-            sft = sft < 0 ? 0 : sft;
-            u64 t = bh << sft;
-            const bool over = t > ah;
-            t = over ? t >> 1 : t;
-            sft = over ? sft - 1 : sft;
-            run = run && sft >= 0 && sft < 32;
-            const u64 np = p + (r << (sft & 31)), nq = q + (s << (sft & 31));
-            run = run && (np >> 32) == 0 && (nq >> 32) == 0;
-            ah = run ? ah - t : ah;
-            p = run ? np : p; q = run ? nq : q;
-            steps += run ? 1 : 0;
-            const bool sw = run && ah < bh;
-            { const u64 x = ah; ah = sw ? bh : ah; bh = sw ? x : bh; }
-            { const u64 x = p; p = sw ? r : p; r = sw ? x : r; }
-            { const u64 x = q; q = sw ? s : q; s = sw ? x : s; }
-            flip = flip != sw;
+            const u64 bsafe = bh | (u64)(bh == 0);
+            u64 quot = (u64)((double)ah / (double)bsafe);
+            const u64 prod = quot * bsafe;                          // <= ah + bsafe < 2^64
+            u64 rem = ah - prod;
+            const u64 neg = (u64)((int64_t)rem >> 63);              // estimate one too large
+            rem += bsafe & neg; quot += neg;
+            const u64 ge = ~(u64)((int64_t)(rem - bsafe) >> 63);    // estimate one too small
+            rem -= bsafe & ge; quot -= ge;
+            const u64 np = (u64)p + (quot & 0xffffffffu) * r, nq = (u64)q + (quot & 0xffffffffu) * s;
+            run = run && ((quot | np | nq) >> 32) == 0;
+            const u64 m = run ? ~(u64)0 : (u64)0;
+            const u32 m32 = (u32)m;
+            const u64 xa = (ah ^ bh) & m, xb = (bh ^ rem) & m;
+            ah ^= xa; bh ^= xb;
+            const u32 xp = (p ^ r) & m32, xq = (q ^ s) & m32, xr = (r ^ (u32)np) & m32, xs = (s ^ (u32)nq) & m32;
+            p ^= xp; q ^= xq; r ^= xr; s ^= xs;
+            steps += (int)(m32 & 1u);
         }
         go = go && steps > 0;
-        if (!go) { p = 1; q = 0; r = 0; s = 1; flip = false; }      // identity for the lanes that are done
+        if (!go) { p = 1; q = 0; r = 0; s = 1; }      // identity for the lanes that are done
         // apply the matrix to the remainders and to the cofactors:  a' = +-(p a - q b),  b' = +-(s b - r a)
         u32 na[9], nb[9], nta[HS_HALF_COF_WORDS], ntb[HS_HALF_COF_WORDS];
-        mp_lin2<9>(na, (u32)p, a, (u32)q, b);
-        mp_lin2<9>(nb, (u32)s, b, (u32)r, a);
-        mp_lin2<HS_HALF_COF_WORDS>(nta, (u32)p, ta, (u32)q, tb);
-        mp_lin2<HS_HALF_COF_WORDS>(ntb, (u32)s, tb, (u32)r, ta);
-        // remainders are kept non-negative (beyond the precision of the leading parts a difference may come out negative);
-        // the cofactor follows its remainder's sign.  `flip` (rows swapped an odd number of times) exchanges the roles.
+        mp_lin2<9>(na, p, a, q, b);
+        mp_lin2<9>(nb, s, b, r, a);
+        mp_lin2<HS_HALF_COF_WORDS>(nta, p, ta, q, tb);
+        mp_lin2<HS_HALF_COF_WORDS>(ntb, s, tb, r, ta);
+        // remainders are kept non-negative (the rows' common sign alternates with every step, and beyond the precision of the
+        // leading parts a difference may come out negative anyway); the cofactor follows its remainder's sign, and the
+        // ordering a >= b is re-established by value.
         const bool nega = (na[8] >> 31) != 0, negb = (nb[8] >> 31) != 0;
         mp_neg_if<9>(na, nega); mp_neg_if<HS_HALF_COF_WORDS>(nta, nega);
         mp_neg_if<9>(nb, negb); mp_neg_if<HS_HALF_COF_WORDS>(ntb, negb);
         const bool sw = mp_less<9>(na, nb);
         mp_swap_if<9>(na, nb, sw); mp_swap_if<HS_HALF_COF_WORDS>(nta, ntb, sw);
-        (void)flip;      // the ordering is re-established by value, not by parity
 #pragma unroll
         for (int i = 0; i < 9; i++) { a[i] = na[i]; b[i] = nb[i]; }
 #pragma unroll
@@ -286,6 +290,46 @@ HS_HD int sc_recode16_len(const u32 r[8]) {
         n = d ? 8 * i + 8 - (hs_clz32(d) >> 2) : n;
     }
     return n;
+}
+
+// Signed radix-8 recoding for x < 2^253 (the quad kernels' 3-bit-window form): r = x + 0o44...4 (85 digits, < 2^255);
+// digit_i = bits [3i, 3i + 3) of r - 4 in [-4, 3] and sum digit_i 8^i = x.
+#define HS_RADIX8_DIGITS 85
+#define HS_BIAS8_WORDS { 0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x49249249u }
+HS_HD void sc_recode8(u32 r[8], const u32 x[8]) {
+    const u32 bias[8] = HS_BIAS8_WORDS;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)x[i] + bias[i] + carry;
+        r[i] = (u32)t;
+        carry = t >> 32;
+    }
+}
+// digits the radix-8 recoding really has (the ones above are 0)
+HS_HD int sc_recode8_len(const u32 r[8]) {
+    const u32 bias[8] = HS_BIAS8_WORDS;
+    int top = 0;      // position of the highest bit in which r differs from the bias
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 d = r[i] ^ bias[i];
+        top = d ? 32 * i + 31 - hs_clz32(d) : top;
+    }
+    return top / 3 + 1;
+}
+// the recoded scalar is kept left-aligned for popping: digit 84 at bits [253, 256)
+HS_HD void sc_align8(u32 r[8]) {
+#pragma unroll
+    for (int j = 7; j > 0; j--) r[j] = (r[j] << 1) | (r[j - 1] >> 31);
+    r[0] <<= 1;
+}
+// take the top three bits as a signed digit and shift left by 3
+HS_HD int sc_pop_digit3(u32 w[8]) {
+    const int d = (int)(w[7] >> 29) - 4;
+#pragma unroll
+    for (int j = 7; j > 0; j--) w[j] = (w[j] << 3) | (w[j - 1] >> 29);
+    w[0] <<= 3;
+    return d;
 }
 
 }  // namespace hs

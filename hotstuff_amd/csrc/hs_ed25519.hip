@@ -146,6 +146,7 @@ k_tc_digests(unsigned long long round, const unsigned long long *__restrict__ hq
 
 // Whole verification in one launch (verify_quad_fused): reads the packed inputs, writes the bitmap.
 // `block` = this wavefront's index within its batch (16 signatures per wavefront).
+template <int W>
 __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
                                             const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
                                             u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
@@ -155,13 +156,13 @@ __device__ __forceinline__ void fused_block(u32 *s_atab, u32 block, msg_src msgs
         if (threadIdx.x == 0) bitmap16[block] = (unsigned short)((1u << here) - 1);
         return;
     }
-    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS;
+    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS_OF(W);
     const u32 i = block * 16 + (threadIdx.x >> 2);
     const bool active = i < n;
     const u32 j = active ? i : n - 1;
     u32 msg[8];
     load_msg(msg, msgs, j);
-    const bool ok = verify_quad_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab, rtab);
+    const bool ok = verify_quad_fused<W>(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, atab, rtab);
     unsigned long long m = __ballot(ok && active);
     m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
     m = (m | (m >> 3)) & 0x0303030303030303ull;
@@ -193,16 +194,16 @@ __device__ __forceinline__ u32 quad_ballot16(bool ok) {
 __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_src msgs, const u32 *__restrict__ pks,
                                                   const u32 *__restrict__ sigs, u32 n, u32 mode, unsigned short *__restrict__ bitmap16,
                                                   u32 *__restrict__ nreject) {
-    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS;
+    qtab atab, rtab; atab.lds = s_atab; rtab.lds = s_atab + HS_QTAB_WORDS_OF(3);
     const u32 q = threadIdx.x >> 2;
     const u32 i0 = block * 32 + q, i1 = i0 + 16;
     const u32 j0 = i0 < n ? i0 : n - 1, j1 = i1 < n ? i1 : n - 1;
-    const quad_pair_points pp = quad_pair_decompress(pks, sigs, msgs, j0, j1, mode);
+    const quad_pair_points pp = quad_pair_decompress<3>(pks, sigs, msgs, j0, j1, mode);
     u32 bad = 0;
 #pragma nounroll
     for (u32 h = 0; h < 2; h++) {
         const u32 i = h ? i1 : i0;
-        const bool ok = quad_pair_pass(pp, h, mode, g_b16, atab, rtab);
+        const bool ok = quad_pair_pass<3>(pp, h, mode, g_b16, atab, rtab);
         const u32 m = quad_ballot16(ok && i < n);
         if (threadIdx.x == 0) bitmap16[2 * block + h] = (unsigned short)m;
         const u32 first = block * 32 + 16 * h;
@@ -210,11 +211,21 @@ __device__ __forceinline__ void fused_pairs_block(u32 *s_atab, u32 block, msg_sr
     }
     if (threadIdx.x == 0 && nreject && bad) atomicAdd(nreject, bad);
 }
-__global__ void __launch_bounds__(64, 2)
+// The latency form: 4-bit windows, both tables of eight entries in LDS (40,960 B: one wavefront per SIMD - a single batch
+// of up to 16,384 signatures is at most that anyway)
+__global__ void __launch_bounds__(64, 1)
 k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
                unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)       // this wavefront's j*(-A) tables (verify_quad.h)
-    fused_block(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(4)];    // this wavefront's tables j*(+-A) and j*(-R), j = 1..8 (verify_quad.h)
+    fused_block<4>(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
+}
+// The same with 3-bit windows: four entries per table, 20,480 B of LDS, two wavefronts per SIMD - single batches between
+// 16,384 and 32,768 signatures
+__global__ void __launch_bounds__(64, 2)
+k_verify_fused3(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(3)];
+    fused_block<3>(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
 }
 // Several independent small batches in ONE grid (hs_ed25519_verify_device_batches): a 1,024-signature
 // batch is only 64 wavefronts - at most one per SIMD of the CU slice its stream is confined to - and a lone
@@ -225,17 +236,17 @@ struct fused_batch { msg_src msgs; const u32 *pks, *sigs; unsigned short *bitmap
 struct fused_batch_list { fused_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused_batches(fused_batch_list L) {
-    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(3)];    // this wavefront's tables j*(+-A) and j*(-R), j = 1..4: two wavefronts per SIMD
     u32 k = 0;
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
     const fused_batch &B = L.b[k];
-    fused_block(s_atab, blockIdx.x - B.first_block, B.msgs, B.pks, B.sigs, B.n, B.mode, B.bitmap16, B.nreject, nullptr);
+    fused_block<3>(s_atab, blockIdx.x - B.first_block, B.msgs, B.pks, B.sigs, B.n, B.mode, B.bitmap16, B.nreject, nullptr);
 }
 // The same list served by the pairs form: first_block counts 32-signature wavefronts.
 __global__ void __launch_bounds__(64, 2)
 k_verify_fused_pairs_batches(fused_batch_list L) {
-    __shared__ u32 s_atab[2 * HS_QTAB_WORDS];    // this wavefront's tables j*(+-A) and j*(-R) (verify_quad.h)
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(3)];
     u32 k = 0;
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
@@ -625,7 +636,7 @@ static const size_t kLaneMinTotal = 8192;
 // fused quad kernel up to here (latency), lane kernels above (throughput).  32,768 is also the API's bound on a list entry.
 // With the half-size form the quad kernels hold TWO per-signature tables in LDS (40,960 B per wavefront: one wavefront per
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
-static std::atomic<size_t> g_quad_max_batch{16384};
+static std::atomic<size_t> g_quad_max_batch{32768};
 static const size_t kQuadMaxBatch = 32768;
 static const size_t kTailMax = 2048;         // the largest sliver past whole rounds of one-lane wavefronts that goes through the quad kernel (enqueue_cold)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
@@ -893,7 +904,10 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     if (f == HS_K_AUTO) return n <= g_quad_max_batch.load() ? HS_K_FUSED : HS_K_LANE;
     return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
 }
-extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) { return n <= g_quad_max_batch.load() ? "k_verify_fused" : "k_verify"; }
+extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
+    const size_t one_round = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 * 16 : 16384;
+    return n <= g_quad_max_batch.load() ? (n <= one_round ? "k_verify_fused" : "k_verify_fused3") : "k_verify";
+}
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 // (for `count` batches of 1,024 signatures each: the lane form also wants 8,192 signatures in the call)
 extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
@@ -951,8 +965,10 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         HS_HIP(launch1((const void *)k_verify_fused_pairs_batches, dim3(np / 32), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused_pairs_batches");
     } else if (kern == HS_K_FUSED) {
-        HS_HIP(launch1((const void *)k_verify_fused, dim3(np / 16), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-               "launch k_verify_fused");
+        // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above
+        const bool w4 = n <= (size_t)g_devs[ctx->slot].cus * 4 * 16;
+        HS_HIP(launch1(w4 ? (const void *)k_verify_fused : (const void *)k_verify_fused3, dim3(np / 16), dim3(64), a3, st,
+                       ev ? ev[0] : nullptr, ev ? ev[2] : nullptr), "launch k_verify_fused");
     } else {
         // One lane per signature: a launch is ceil(n / 64) wavefronts for the chip's 1,024 SIMDs, and its time is that of
         // the SIMD with most wavefronts - 66,667 signatures (the QC of N = 100,000) are 1,042 wavefronts, eighteen SIMDs

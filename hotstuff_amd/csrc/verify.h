@@ -95,17 +95,21 @@ HS_HD void ws_store_cached(u32 *p, const ge_cached &c) {
     for (int i = 0; i < 32; i++) p[i] = w[i];
 #endif
 }
-HS_HD void ws_load_cached(ge_cached &c, const u32 *p) {
+// the 32 packed words of an entry (eight 16-byte loads), and their unpacking - separate so that a lookup can be REQUESTED a
+// window ahead of its use (verify_lane)
+HS_HD void ws_fetch_entry(u32 w[32], const u32 *p) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    u32 w[32];
 #pragma unroll
     for (int i = 0; i < 8; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
 #else
-    const u32 *w = p;
+    for (int i = 0; i < 32; i++) w[i] = p[i];
 #endif
+}
+HS_HD void ws_unpack_entry(ge_cached &c, const u32 w[32]) {
     fe_from_words(c.YpX, w); fe_from_words(c.YmX, w + 8); fe_from_words(c.Z, w + 16); fe_from_words(c.T2d, w + 24);
 }
+HS_HD void ws_load_cached(ge_cached &c, const u32 *p) { u32 w[32]; ws_fetch_entry(w, p); ws_unpack_entry(c, w); }
 
 // ---- stage 1 ------------------------------------------------------------------------------
 // task in [0, n): A of signature `task`; task in [n, 2n): R of signature task - n.
@@ -269,6 +273,46 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
     const u32 *scu = ws.sc + i, *scv = ws.sc + (size_t)8 * ws.np + i, *scw = ws.sc + (size_t)16 * ws.np + i;
     ge_p3 acc;
     ge_identity(acc);
+#ifdef HS_LANE_PREFETCH      // measured equal (103.3 against 103.3 M verifies/s, 239 against 180 VGPRs): the kernel is VALU-issue bound; kept for A/B
+    // The two entries a window adds are requested ONE WINDOW AHEAD (their digits are known from the start) and consumed
+    // behind the next four doublings: the lookups go to L2 / MALL, and with two wavefronts per SIMD there is little else to
+    // cover them with (SQ_WAIT_ANY was 16 % of the wavefronts' cycles, profiles/r3_pmc_sq.json).
+    u32 wa[32], wr[32];
+    int du, dv;
+    {
+        const int w = nwin - 1;
+        const u32 sh = 4u * ((u32)w & 7u);
+        du = (int)((scu[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
+        dv = (int)((scv[(size_t)(w >> 3) * ws.np] >> sh) & 15u) - 8;
+        ws_fetch_entry(wa, atab + HS_WS_ENTRY_WORDS * (du < 0 ? -du : du));
+        ws_fetch_entry(wr, rtab + HS_WS_ENTRY_WORDS * (dv < 0 ? -dv : dv));
+    }
+#pragma nounroll
+    for (int w = nwin - 1; w >= 0; w--) {
+        ge_p1p1 t;
+        const int nd = w == nwin - 1 ? 0 : 4;       // the accumulator is still the identity in the first window
+#pragma nounroll
+        for (int d = 0; d < nd; d++) {
+            ge_dbl(t, acc);
+            ge_p1p1_to_p3(acc, t, d == 3);
+        }
+        ge_cached ea, er;
+        ws_unpack_entry(ea, wa);
+        ws_unpack_entry(er, wr);
+        const bool na = du < 0, nr = dv < 0;
+        if (w > 0) {        // next window's digits (one dword of each recoded scalar: wavefront-uniform row, coalesced) and entries
+            const u32 sh = 4u * ((u32)(w - 1) & 7u);
+            du = (int)((scu[(size_t)((w - 1) >> 3) * ws.np] >> sh) & 15u) - 8;
+            dv = (int)((scv[(size_t)((w - 1) >> 3) * ws.np] >> sh) & 15u) - 8;
+            ws_fetch_entry(wa, atab + HS_WS_ENTRY_WORDS * (du < 0 ? -du : du));
+            ws_fetch_entry(wr, rtab + HS_WS_ENTRY_WORDS * (dv < 0 ? -dv : dv));
+        }
+        ge_add(t, acc, ea, na);
+        ge_p1p1_to_p3(acc, t, true);
+        ge_add(t, acc, er, nr);
+        ge_p1p1_to_p3(acc, t, w == 0);
+    }
+#else
 #pragma nounroll
     for (int w = nwin - 1; w >= 0; w--) {
         ge_p1p1 t;
@@ -290,6 +334,7 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
         ge_add(t, acc, e, dv < 0);
         ge_p1p1_to_p3(acc, t, w == 0);
     }
+#endif
     // [w]B: sixteen entries of the base point's tables, T[j][d_j] = d_j 2^(16 j) B - absolute multiples, so they are added
     // once the doublings are over
 #pragma nounroll

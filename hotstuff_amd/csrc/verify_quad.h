@@ -193,8 +193,15 @@ HS_Q qv q_load_entry(const u32 *entry) {
 // SIMD - which is also what the kernel's ~250 VGPRs allow; with the identity stored as a ninth
 // entry (23,040 B) only six wavefronts fit a CU.
 #define HS_QTAB_ENTRIES 8
+// W-bit signed windows need 2^(W-1) entries.  W = 4: 8 entries, and with the two tables of the half-size form 40,960 B of
+// LDS per wavefront - one wavefront per SIMD (the latency kernel: a single batch of up to 16,384 signatures is at most one
+// wavefront per SIMD anyway).  W = 3: 4 entries, 20,480 B for both tables - two wavefronts per SIMD, which is what the
+// kernels that put several batches into one launch live on; 45 windows of three doublings instead of 34 of four cost
+// 3 - 4 % more instructions per verification (14 more additions, 8 fewer table entries to build).
+#define HS_QTAB_ENTRIES_OF(W) (1 << ((W) - 1))
 #if defined(__HIPCC__)
-#define HS_QTAB_WORDS (HS_QTAB_ENTRIES * 10 * 64)
+#define HS_QTAB_WORDS_OF(W) (HS_QTAB_ENTRIES_OF(W) * 10 * 64)
+#define HS_QTAB_WORDS HS_QTAB_WORDS_OF(4)
 struct qtab { u32 *lds; };      // this wavefront's slab
 HS_Q void qtab_store(const qtab &t, int j, const qv &e) {
     u32 *p = t.lds + (size_t)j * 640 + (threadIdx.x & 63u);
@@ -282,15 +289,18 @@ HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
 #else
 #define HS_NWIN_OF(meta) ((int)wave_max_u32((meta) & 0xffu))
 #endif
-struct half_scalars { u32 ru[8], rv[8], rw[8]; u32 meta; };      // meta: bits 0-7 windows (1 ... 64), bit 8: u < 0
+// The recoded scalars of the half-size form (halfscalar.h) for one signature: |u| and v in signed radix 2^W (W = 4: 64 digits;
+// W = 3: 85 digits, kept left-aligned), w = v s mod L in signed radix 65536, how many windows u and v need, the sign of u.
+struct half_scalars { u32 ru[8], rv[8], rw[8]; u32 meta; };      // meta: bits 0-7 windows (1 ... 85), bit 8: u < 0
 
-// j * P, cached, j = 1..8 at index j - 1, for the affine point (x, y)
+// j * P, cached, j = 1 ... 2^(W-1) at index j - 1, for the affine point (x, y)
+template <int W>
 HS_Q void qtab_build(qtab &tab, const fe &x, const fe &y) {
     qv p = q_mul(q_lanes(x, y, fe_small(1), x), q_lanes(fe_small(1), fe_small(1), fe_small(1), y));       // (x, y, 1, xy)
     const qv a1 = q_to_cached(p);
     qtab_store(tab, 0, a1);
 #pragma nounroll
-    for (int j = 2; j <= 8; j++) {
+    for (int j = 2; j <= HS_QTAB_ENTRIES_OF(W); j++) {
         p = q_add_cached(p, a1);
         qtab_store(tab, j - 1, q_to_cached(p));
     }
@@ -304,14 +314,16 @@ HS_Q qflags q_is_identity(const qv &acc) {
     const qv lhs = q_carry(q_sel<0b1100>(acc, z));        // (X, Y, Z, Z), reduced
     return q_eq_nz(rhs, lhs);
 }
+template <int W> HS_HD int sc_pop_window(u32 w[8]) { return W == 4 ? sc_pop_digit(w) : sc_pop_digit3(w); }
 
 // The quad stage-2 core in the half-size form (halfscalar.h):  [w]B + [u](-A) + [v](-R) == O.  ax, ay, rx, ry (affine A
-// and R) and the recoded scalars are uniform across the four lanes of a quad; `nwin` (windows of four doublings) is uniform
-// over the wavefront.  atab / rtab: the per-signature tables j * (+-A) and j * (-R), j = 1..8, in LDS.
+// and R) and the recoded scalars are uniform across the four lanes of a quad; `nwin` (windows of W doublings) is uniform
+// over the wavefront.  atab / rtab: the per-signature tables j * (+-A) and j * (-R), j = 1 ... 2^(W-1), in LDS.
 // b16: the base point's sixteen 16-bit-window tables (verify_cached.h): T[i][j] = j 2^(16 i) B, 32,769 affine Niels entries
 // of 128 bytes per window - [w]B costs 16 additions and no doublings; they come after the window loop (absolute multiples).
 // Returns, per lane, whether this lane's part of the identity test passed; the caller ANDs the four lanes of the quad
 // with the signature-level flags.
+template <int W>
 HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe &ry, half_scalars &hs, int nwin,
                              const u32 *b16, qtab &atab, qtab &rtab) {
     {
@@ -319,30 +331,45 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
         fe nax, sx, nrx;
         fe_neg(nax, ax);
         fe_select(sx, nax, ax, ((hs.meta >> 8) & 1) != 0);
-        qtab_build(atab, sx, ay);
+        qtab_build<W>(atab, sx, ay);
         fe_neg(nrx, rx);
-        qtab_build(rtab, nrx, ry);
+        qtab_build<W>(rtab, nrx, ry);
     }
     // the recoded scalars are popped from the top: drop the windows above the wavefront's count (all zero digits)
 #pragma nounroll
-    for (int t = nwin; t < 64; t++) { (void)sc_pop_digit(hs.ru); (void)sc_pop_digit(hs.rv); }
+    for (int t = nwin; t < (W == 4 ? 64 : HS_RADIX8_DIGITS); t++) { (void)sc_pop_window<W>(hs.ru); (void)sc_pop_window<W>(hs.rv); }
     qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
+    // The entries a window adds are FETCHED ONE WINDOW AHEAD: a lone wavefront (the latency regime) has nothing else to
+    // cover an LDS or memory round trip with, and fetched at the point of use they kept it waiting 37 % of its cycles
+    // (profiles/r3_pmc_sq.json).  The digits are known from the start, so window w - 1's two entries are requested right
+    // after window w's additions have been issued and are consumed behind the next W doublings.
+    int du = sc_pop_window<W>(hs.ru), dv = sc_pop_window<W>(hs.rv);
+    qv ea = qtab_pick(atab, du < 0 ? -du : du), er = qtab_pick(rtab, dv < 0 ? -dv : dv);
 #pragma nounroll
     for (int w = nwin - 1; w >= 0; w--) {
-        // the accumulator is still the identity in the very first window: its four doublings are skipped
-        const int nd = w == nwin - 1 ? 0 : 4;
+        // the accumulator is still the identity in the very first window: its doublings are skipped
+        const int nd = w == nwin - 1 ? 0 : W;
 #pragma nounroll
         for (int d = 0; d < nd; d++) acc = q_dbl(acc);
-        const int du = sc_pop_digit(hs.ru);
-        acc = q_add_cached(acc, q_cached_signed(qtab_pick(atab, du < 0 ? -du : du), du < 0));
-        const int dv = sc_pop_digit(hs.rv);
-        acc = q_add_cached(acc, q_cached_signed(qtab_pick(rtab, dv < 0 ? -dv : dv), dv < 0));
+        const qv sa = q_cached_signed(ea, du < 0), sr = q_cached_signed(er, dv < 0);
+        if (w > 0) {
+            du = sc_pop_window<W>(hs.ru); dv = sc_pop_window<W>(hs.rv);
+            ea = qtab_pick(atab, du < 0 ? -du : du); er = qtab_pick(rtab, dv < 0 ? -dv : dv);
+        }
+        acc = q_add_cached(acc, sa);
+        acc = q_add_cached(acc, sr);
     }
+    // [w]B: the same one-ahead fetch for the sixteen gathers from the base point's tables (these come from L2 / MALL / HBM)
+    int ds = sc_pop_digit16(hs.rw);
+    qv eb = q_load_entry(b16 + ((size_t)15 * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
 #pragma nounroll
     for (int j = 15; j >= 0; j--) {
-        const int ds = sc_pop_digit16(hs.rw);
-        const qv eb = q_load_entry(b16 + ((size_t)j * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
-        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
+        const qv sb = q_cached_signed(eb, ds < 0);
+        if (j > 0) {
+            ds = sc_pop_digit16(hs.rw);
+            eb = q_load_entry(b16 + ((size_t)(j - 1) * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
+        }
+        acc = q_add_cached(acc, sb);
     }
     return q_is_identity(acc);
 }
@@ -366,6 +393,7 @@ HS_HD bool prepare_scalars(u32 kw[8], u32 sw[8], const u32 *pk, const u32 *sig, 
 
 // The same for the cold path's half-size form (halfscalar.h): hash, range check, the short pair (u, v) for k, w = v s mod L,
 // the three recodings, the window count.  Returns s < L.
+template <int W>
 HS_HD bool prepare_scalars_half(half_scalars &out, const u32 *pk, const u32 *sig, const u32 *msg) {
     u32 in[24], h[16], k[8], s[8], w[8];
 #pragma unroll
@@ -375,10 +403,18 @@ HS_HD bool prepare_scalars_half(half_scalars &out, const u32 *pk, const u32 *sig
     half_pair hp;
     half_scalar(hp, k);
     sc_mul(w, hp.v, s);
-    sc_recode16(out.ru, hp.u);
-    sc_recode16(out.rv, hp.v);
+    int nu, nv;
+    if (W == 4) {
+        sc_recode16(out.ru, hp.u);
+        sc_recode16(out.rv, hp.v);
+        nu = sc_recode16_len(out.ru); nv = sc_recode16_len(out.rv);
+    } else {
+        sc_recode8(out.ru, hp.u);
+        sc_recode8(out.rv, hp.v);
+        nu = sc_recode8_len(out.ru); nv = sc_recode8_len(out.rv);
+        sc_align8(out.ru); sc_align8(out.rv);
+    }
     sc_recode65536(out.rw, w);
-    const int nu = sc_recode16_len(out.ru), nv = sc_recode16_len(out.rv);
     out.meta = (u32)(nu > nv ? nu : nv) | (hp.u_neg << 8);
     return sc_is_canonical(s);
 }
@@ -387,6 +423,7 @@ HS_HD bool prepare_scalars_half(half_scalars &out, const u32 *pk, const u32 *sig
 // Fused stage 1 + stage 2 for one quad: lane 1 decompresses R, the other lanes decompress A
 // (one shared instruction stream), everybody hashes, DPP broadcasts hand A to the whole
 // quad, then the core.  One launch per batch and no workspace traffic.
+template <int W>
 HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const u32 *b16, qtab &atab, qtab &rtab) {
     const u32 lane = q_lane();
     u32 enc[8];
@@ -398,13 +435,13 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
     const u32 fa = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
     const u32 fr = (u32)__builtin_amdgcn_mov_dpp((int)fl, 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
     half_scalars hs;
-    bool ok = prepare_scalars_half(hs, pk, sig, msg);
+    bool ok = prepare_scalars_half<W>(hs, pk, sig, msg);
     ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
     if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
     const fe ax = q_perm<0, 0, 0, 0>(pt.X), ay = q_perm<0, 0, 0, 0>(pt.Y);
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
     const int nwin = HS_NWIN_OF(hs.meta);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
+    const qflags f = verify_quad_core<W>(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }
 
@@ -417,6 +454,7 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
 struct quad_pair_points { fe X, Y; u32 fl; half_scalars hs; };
 // lane 0: A of signature j0, lane 1: R of j0, lane 2: A of j1, lane 3: R of j1; lanes 0, 1 also hash signature j0 and
 // lanes 2, 3 signature j1 (one SHA-512 pass for both; HS_F_SCANON in fl = s < L)
+template <int W>
 HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, msg_src msgs, u32 j0, u32 j1, u32 mode) {
     const u32 lane = q_lane();
     const u32 j = (lane & 2) ? j1 : j0;
@@ -431,10 +469,11 @@ HS_Q quad_pair_points quad_pair_decompress(const u32 *pks, const u32 *sigs, msg_
     r.X = pt.X; r.Y = pt.Y;
     u32 msg[8];
     load_msg(msg, msgs, j);
-    if (prepare_scalars_half(r.hs, pk, sig, msg)) r.fl |= HS_F_SCANON;
+    if (prepare_scalars_half<W>(r.hs, pk, sig, msg)) r.fl |= HS_F_SCANON;
     return r;
 }
 // pass h (0 / 1, uniform over the wavefront): the quad's first / second signature
+template <int W>
 HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 *b16, qtab &atab, qtab &rtab) {
     fe sx = pp.X, sy = pp.Y;
     u32 sf = pp.fl;
@@ -466,7 +505,7 @@ HS_Q bool quad_pair_pass(const quad_pair_points &pp, u32 h, u32 mode, const u32 
     const fe ax = q_perm<0, 0, 0, 0>(sx), ay = q_perm<0, 0, 0, 0>(sy);
     const fe rx = q_perm<1, 1, 1, 1>(sx), ry = q_perm<1, 1, 1, 1>(sy);
     const int nwin = HS_NWIN_OF(hs.meta);
-    const qflags f = verify_quad_core(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
+    const qflags f = verify_quad_core<W>(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
     return f.f && ok;
 }
 #endif

@@ -13,6 +13,24 @@ using namespace hs;
 
 static void load_words(u32 *w, const uint8_t *b, int n) { memcpy(w, b, 4 * n); }
 
+const uint32_t *emu_base16_fwd(void);
+template <int W>
+static void verify_quad_w(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *out) {
+    const u32 *btab = emu_base16_fwd();        // the base point's 16-bit tables
+    for (size_t i = 0; i < n; i++) {
+        u32 pk[8], sig[16], msg[8];
+        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        ge_p3 A, R;
+        u32 fa = ge_decompress(A, pk) ? HS_F_ONCURVE : 0, fr = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
+        if (mode & HS_MODE_STRICT) { fa |= ge_is_small_order_affine(A.Y) ? HS_F_SMALL : 0; fr |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0; }
+        half_scalars hs;
+        bool ok = prepare_scalars_half<W>(hs, pk, sig, msg);
+        ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
+        if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+        qtab atab, rtab; qflags f = verify_quad_core<W>(A.X, A.Y, R.X, R.Y, hs, (int)(hs.meta & 0xffu), btab, atab, rtab);
+        out[i] = (ok && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
+    }
+}
 extern "C" {
 void emu_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *r) {
     u32 wa[8], wb[8], wr[8]; load_words(wa, a, 8); load_words(wb, b, 8);
@@ -98,22 +116,20 @@ void emu_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, cons
 const uint32_t *emu_base16(void);
 // the quad (4 lanes per signature) core (verify_quad_core) behind the scalar half of stage 1 (prepare_scalars) and a
 // plain decompression of A and R - what verify_quad_fused does on the device with DPP broadcasts
-void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
-                     uint32_t mode, uint8_t *out) {
-    const u32 *btab = emu_base16();        // the base point's 16-bit tables
-    for (size_t i = 0; i < n; i++) {
-        u32 pk[8], sig[16], msg[8];
-        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
-        ge_p3 A, R;
-        u32 fa = ge_decompress(A, pk) ? HS_F_ONCURVE : 0, fr = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
-        if (mode & HS_MODE_STRICT) { fa |= ge_is_small_order_affine(A.Y) ? HS_F_SMALL : 0; fr |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0; }
-        half_scalars hs;
-        bool ok = prepare_scalars_half(hs, pk, sig, msg);
-        ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
-        if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
-        qtab atab, rtab; qflags f = verify_quad_core(A.X, A.Y, R.X, R.Y, hs, (int)(hs.meta & 0xffu), btab, atab, rtab);
-        out[i] = (ok && f.f[0] && f.f[1] && f.f[2] && f.f[3]) ? 1 : 0;
-    }
+// 4-bit windows (the latency kernel k_verify_fused) and 3-bit windows (k_verify_fused3, the batch-list kernels)
+void emu_verify_quad(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *out) {
+    verify_quad_w<4>(msgs, msg_stride, pks, sigs, n, mode, out);
+}
+void emu_verify_quad3(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *out) {
+    verify_quad_w<3>(msgs, msg_stride, pks, sigs, n, mode, out);
+}
+// radix-8 recoding: digits most significant first (85 of them) and the count the kernels use
+int emu_sc_digits3(const uint8_t *x32, int8_t *digits) {
+    u32 x[8], r[8]; load_words(x, x32, 8); sc_recode8(r, x);
+    const int n = sc_recode8_len(r);
+    sc_align8(r);
+    for (int i = 0; i < HS_RADIX8_DIGITS; i++) digits[i] = (int8_t)sc_pop_digit3(r);
+    return n;
 }
 // Every finishing form must reject an all-zero accumulator (what an arithmetic fault leaves behind:
 // it is absorbing under the addition formulas and satisfies X == x*Z, Y == y*Z trivially).
@@ -248,6 +264,10 @@ static const uint32_t *g_b16 = nullptr;
 void emu_set_base16(const uint32_t *b16) { g_b16 = b16; }
 void emu_keyset_build_base(uint32_t *tab);
 // the table the verification paths below read: the one a test handed over, or one built here on first use
+const uint32_t *emu_base16(void);
+}
+const uint32_t *emu_base16_fwd(void) { return emu_base16(); }
+extern "C" {
 const uint32_t *emu_base16(void) {
     if (!g_b16) {
         static std::vector<u32> t8((size_t)HS_KS_KEY_WORDS), b16(HS_B16_WORDS);

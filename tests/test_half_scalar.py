@@ -67,3 +67,18 @@ def test_recoded_length_is_the_number_of_nonzero_windows(emu):
             assert sum(d * 16**i for i, d in enumerate(digits)) == x
             top = max(i for i, d in enumerate(digits) if d != 0)
             assert n == top + 1 and (bits + 1) // 4 <= n <= (bits + 2) // 4 + 1
+
+
+def test_radix8_recoding(emu):
+    """The quad kernels' 3-bit-window form: x = sum d_i 8^i with d_i in [-4, 3], 85 digits popped from the top, and the
+    count of windows that are really needed."""
+    rng = random.Random(9)
+    for bits in list(range(1, 30)) + [126, 127, 128, 129, 130, 131, 132, 133, 134, 200, 252, 253]:
+        for _ in range(10):
+            x = rng.randrange(2**(bits - 1), 2**bits)
+            d = (ctypes.c_int8 * 85)()
+            n = emu.emu_sc_digits3(x.to_bytes(32, "little"), d)
+            digits = list(d)[::-1]                       # least significant first
+            assert all(-4 <= v <= 3 for v in digits) and sum(v * 8**i for i, v in enumerate(digits)) == x
+            top = max(i for i, v in enumerate(digits) if v != 0)
+            assert n == top + 1

@@ -30,7 +30,35 @@ __global__ void k_probe(res *out, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) one(out[i], i);
 }
+// timing of the scalar stage on lone wavefronts (one per SIMD): hash only, hash + reduction, hash + reduction + v s mod L + recodings
+template <int WHAT>
+__global__ void k_time(u32 *sink, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 k[8]; make_k(k, i);
+    u32 acc = k[0];
+    if (WHAT >= 1) { half_pair h; half_scalar(h, k); acc ^= h.u[0] ^ h.v[0] ^ h.u_neg;
+        if (WHAT >= 2) { u32 w[8], ru[8], rv[8], rw[8]; sc_mul(w, h.v, k); sc_recode16(ru, h.u); sc_recode16(rv, h.v); sc_recode65536(rw, w);
+            acc ^= rw[3] ^ (u32)sc_recode16_len(ru) ^ (u32)sc_recode16_len(rv); } }
+    if (acc == 0x12345u) sink[0] = acc;
+}
+template <int WHAT>
+static float time_it(u32 *sink, u32 waves) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k_time<WHAT>, dim3(waves), dim3(64), 0, 0, sink, waves * 64);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k_time<WHAT>, dim3(waves), dim3(64), 0, 0, sink, waves * 64);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return ms / 10 * 1000.0f;
+}
 int main() {
+    {
+        u32 *sink = nullptr; hipMalloc((void **)&sink, 64);
+        for (u32 waves : {512u, 1024u, 2048u, 8192u})
+            printf("scalar stage, %u wavefronts: hash %.1f us, + half_scalar %.1f us, + v s mod L and recodings %.1f us\n", waves,
+                   time_it<0>(sink, waves), time_it<1>(sink, waves), time_it<2>(sink, waves));
+    }
     const u32 n = 1 << 16;
     res *d = nullptr;
     if (hipMalloc((void **)&d, n * sizeof(res)) != hipSuccess) return 1;
