@@ -579,6 +579,52 @@ def sharded_c_abi(ngpus, ndev, validators=100000, timeout_s=150):
     return json.loads(lines[-1])
 
 
+def live_traffic(kernels=("k_verify_batches", "k_prepare_batches"), timeout_s=120):
+    """HBM-side bytes per launch of the headline pair, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass; no trace domains beside the counters) over SOLO launches of the pair
+    (tools/pmc_solo.py headline: one launch at a time, the stream drained in between, so the chip-wide TCC counters of a
+    dispatch hold that dispatch's traffic only), summed over the counter's instances, the first two dispatches dropped,
+    corrected with the calibration in profiles/r3_pmc_calibration.json (FETCH_SIZE reports half of the 128-byte lines
+    fetched; WRITE_SIZE is exact for whole lines).  Returns None when rocprofv3 is not there."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_calibration.json")))["factors"]
+    f_read, f_write = cal["fetch_line_gather_16B"], cal["write_wide_16B"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {k: {} for k in kernels}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hs_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_solo.py"), "headline"],
+                           capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            dbs = glob.glob(os.path.join(d, "**", "p_results.db"), recursive=True)
+            if not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select name, dispatch_id, sum(counter_value) from pmc_events where counter_name = ? group by name, dispatch_id "
+                              "order by dispatch_id", (counter,)).fetchall()
+            for k in kernels:
+                v = [val for name, _, val in rows if name.split("(")[0] == k][2:]
+                if v:
+                    res[k][counter] = sum(v) / len(v) * 1024.0          # rocprofv3 reports KB
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k in kernels:
+        if "FETCH_SIZE" in res[k] and "WRITE_SIZE" in res[k]:
+            rd, wr = res[k]["FETCH_SIZE"] * f_read, res[k]["WRITE_SIZE"] * f_write
+            out[k] = {"read_bytes": int(rd), "write_bytes": int(wr), "bytes": int(rd + wr),
+                      "FETCH_SIZE_reported": int(res[k]["FETCH_SIZE"]), "WRITE_SIZE_reported": int(res[k]["WRITE_SIZE"])}
+    if not out:
+        return None
+    out["calibration"] = {"file": "profiles/r3_pmc_calibration.json", "fetch_factor": f_read, "write_factor": f_write}
+    return out
+
+
 def launcher_command(ngpus, argv, port=None):
     """The command `python bench.py --gpus N ...` re-executes itself as when it was started WITHOUT a launcher
     (WORLD_SIZE unset): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container's
@@ -895,11 +941,14 @@ def main():
             # bytes of table lines read per launch: one 128-byte affine entry per 8-bit window of the key's table (32) and per
             # 16-bit window of the base point's 67 MB table (16; larger than the L2s, so these come from MALL / HBM as well)
             gather = (32 + 16) * 128 * nl
-            l_traffic = None
-            try:    # HBM bytes per launch from the committed rocprofv3 PMC pass (same kernel, same launch size)
-                lp = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json"))).get("large_committee", {})
-                if lp.get("signatures_per_launch") == nl and lp.get("kernel") == _lib.lib().hs_ed25519_cached_kernel_for(nl).decode():
-                    l_traffic = lp["hbm_bytes_per_launch"]
+            l_traffic = l_src = None
+            try:    # HBM-side bytes per launch from the committed SOLO rocprofv3 pass (same kernel, same launch size), calibrated
+                lk_name = _lib.lib().hs_ed25519_cached_kernel_for(nl).decode()
+                for key, row in json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["kernels"].items():
+                    if key.split("@")[0] == lk_name and row["signatures_per_launch"] == nl:
+                        l_traffic = row["hbm_bytes_per_launch"]
+                        l_src = ("profiles/r3_pmc_traffic.json: solo launch, FETCH_SIZE x %.3f (this project's calibration of one-line 16-byte "
+                                 "gathers, profiles/r3_pmc_calibration.json) + WRITE_SIZE" % row["fetch_factor"])
             except Exception:
                 pass
             cached["large_committee"] = {
@@ -909,8 +958,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "algorithmic_bytes_per_launch": gather, "traffic": l_traffic,
-                             "traffic_source": "profiles/r2_pmc_traffic.json large_committee (rocprofv3 --pmc FETCH_SIZE, "
-                                               "uncorrected)" if l_traffic else None,
+                             "traffic_source": l_src,
                              "note": "48 table entries x 128 B (one cache line each) per verification: 32 gathered from the key set, "
                                      "16 from the base point's 16-bit table"}}
             lctx.close(); lks.close()
@@ -933,20 +981,28 @@ def main():
                    else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode())
     for c in ctxs:
         c.close()
-    traffic = traffic_src = None
-    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same launch size)
-        kname = kernel_name
-        for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
-            fp = os.path.join(ROOT, "profiles", f)
-            if not os.path.exists(fp):
-                continue
-            pmc = json.load(open(fp))
-            if pmc.get("signatures_per_launch") == n * K and kname in pmc["kernels"]:
-                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per launch)" % f
-                break
-    except Exception:
-        pass
+    # HBM-side traffic of the dominant kernel: measured in THIS run when the default workload is timed (rocprofv3 in a
+    # subprocess, solo launches, calibrated - live_traffic), else / on failure the committed solo pass of the same kernel
+    traffic = traffic_src = traffic_detail = None
+    if rank == 0 and world == 1 and not args.no_extras and kernel_name == "k_verify_batches" and n * K == 16384:
+        try:
+            traffic_detail = live_traffic()
+            if traffic_detail and kernel_name in traffic_detail:
+                traffic = traffic_detail[kernel_name]["bytes"]
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over solo launches of the pair "
+                               "(tools/pmc_solo.py headline), corrected with profiles/r3_pmc_calibration.json (fetch x %.3f, write x %.2f)"
+                               % (traffic_detail["calibration"]["fetch_factor"], traffic_detail["calibration"]["write_factor"]))
+        except Exception as e:
+            traffic_detail = {"error": "%s: %s" % (type(e).__name__, e)}
+    if traffic is None:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+            for key, row in pmc["kernels"].items():
+                if key.split("@")[0] == kernel_name and row["signatures_per_launch"] == n * K:
+                    traffic = row["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r3_pmc_traffic.json (solo-launch rocprofv3 passes of an earlier run, calibrated with profiles/r3_pmc_calibration.json)"
+        except Exception:
+            pass
     e2e = None
     if world == 1 and not args.no_extras:
         try:
@@ -984,6 +1040,7 @@ def main():
                 "bound": "hbm", "kernel": kernel_name,
                 "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_detail": traffic_detail,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
                 "event_sampling": "dispatch timestamps (hipExtLaunchKernel start/stop events, on the launch stream) of every "

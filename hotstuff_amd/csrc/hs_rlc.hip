@@ -369,9 +369,11 @@ bool g_key_set = false, g_key_pinned = false;
 std::atomic<unsigned long long> g_call_seq{1};
 
 // Below this many signatures the pipeline (five stages, the last a 248-doubling chain on one quad) costs
-// more than the per-signature kernels: the call then runs plain BATCH.  profiles/r2_sweeps.md: the RLC path wins
-// throughput from ~12,000 signatures and latency from ~20,000 (0.67 vs 0.73 ms at 24,576; 0.91 vs 1.76 ms at 66,667).
-const size_t kRlcMinBatch = 20480;
+// more than the per-signature kernels: the call then runs plain BATCH.  Round 2 switched at 20,480; the per-signature
+// kernels' half-size form (halfscalar.h) moved the latency crossover to ~45,000 signatures (profiles/r3_sweeps.md:
+// 0.65 vs 0.76 ms at 32,768, 0.85 vs 0.81 ms at 49,152), while the RLC path keeps winning THROUGHPUT from ~8,000.
+// A QC is one call on the node's critical path: the switch follows latency.
+const size_t kRlcMinBatch = 40960;
 const u32 kTabWords = HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1);
 const size_t kSmallBytes = 64 + (size_t)HS_RLC_CSUM_SLOTS * 64;
 const u32 kMinChunk = 8;

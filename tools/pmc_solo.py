@@ -29,6 +29,23 @@ def signed(n, shared, first):
 
 
 which = sys.argv[1:] or ["batches", "cached", "lane", "rlc"]
+if "headline" in which:
+    # bench.py's live traffic pass: only the headline pair (sixteen 1,024-tuple batches per launch), solo
+    n, K = 1024, 16
+    dg, pk, sg = signed(n * K, False, 50_000_000)
+    d_dg, d_pk, d_sg = t(dg), t(pk), t(sg)
+    bm = [torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev) for _ in range(K)]
+    nr = torch.zeros(K, dtype=torch.int32, device=dev)
+    ctx = _lib.DeviceContext(n)
+    st = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    torch.cuda.synchronize(dev)
+    lst = _lib.batch_array([(d_dg[32 * n * j:].data_ptr(), 32, d_pk[32 * n * j:].data_ptr(), d_sg[64 * n * j:].data_ptr(), n, _lib.STRICT,
+                             bm[j].data_ptr(), nr[j:].data_ptr()) for j in range(K)])
+    for r in range(REPS + 2):
+        ctx.verify_batches(lst)
+        st.synchronize()
+    assert int(nr.sum().item()) == 0
+    ctx.close()
 if "batches" in which:
     # the headline pair and the two quad forms: K independent 1,024-tuple batches per launch
     n, K = 1024, 16
