@@ -12,14 +12,16 @@ F = cal["factors"]
 # which calibrated pattern dominates each kernel's reads (every read pattern measured reports half the touched
 # 128-byte lines, so the choice moves the result by < 5 %) and what it moves by design per signature
 KERNELS = {
-    "k_verify_batches@256": ("headline pair, 16 x 1,024 signatures per launch", 16384, "fetch_entry160_gather_lines", 128 * 16384),
+    "k_verify_batches@256": ("headline pair, 16 x 1,024 signatures per launch", 16384, "fetch_line_gather_16B", 128 * 16384),
     "k_prepare_batches@512": ("headline pair, 16 x 1,024 signatures per launch", 16384, "fetch_dword_rows", 128 * 16384),
     "k_verify_fused_pairs_batches@128": ("pairs form, 4 x 1,024 signatures per launch", 4096, "fetch_line_gather_16B", 128 * 4096),
     "k_verify_fused_batches@128": ("one signature per quad, 2 x 1,024 signatures per launch", 2048, "fetch_line_gather_16B", 128 * 2048),
     "k_verify_cached_lane2r_batches@64": ("key cache, 4 x 1,024 signatures per launch", 4096, "fetch_line_gather_16B", (48 * 128 + 100) * 4096),
     "k_verify_cached_lane2r@1042": ("key cache, one 66,667-signature QC (N = 100,000)", 66667, "fetch_line_gather_16B", (48 * 128 + 68) * 66667),
     "k_prepare@2084": ("cold one-lane pair, 66,667 signatures", 66667, "fetch_dword_rows", 96 * 66667),
-    "k_verify@1042": ("cold one-lane pair, 66,667 signatures", 66667, "fetch_entry160_gather_lines", 0),
+    "k_verify@1024": ("cold one-lane pair, 65,536 of 66,667 signatures (the sliver of 1,131 runs through k_verify_fused@72)", 65536, "fetch_line_gather_16B", 96 * 65536),
+    "k_prepare@2048": ("cold one-lane pair, 65,536 of 66,667 signatures", 65536, "fetch_dword_rows", 96 * 65536),
+    "k_verify_fused@72": ("the 1,131-signature sliver of the 66,667-signature call", 1131, "fetch_line_gather_16B", 96 * 1131),
     "k_rlc_prepare@3126": ("RLC stage 1, 66,667 signatures", 66667, "fetch_dword_rows", 96 * 66667),
     "k_rlc_accum@133": ("RLC stage 3, 66,667 signatures: 48 record gathers per signature", 66667, "fetch_line_gather_16B", 48 * 132 * 66667),
     "k_rlc_scatter@8": ("RLC stage 2, 66,667 signatures", 66667, "fetch_dword_rows", 0),
