@@ -66,6 +66,9 @@ MAD_PER_VERIFY = {
     # fused quad, per wavefront of 16 signatures: (NWIN - 1) x 4 doublings x (55 + 100) + (2 NWIN + 16) additions x 200
     # + two tables 2 x 7 x 300 + decompress (255 sq + 21 mul), all x 64 lanes / 16 signatures
     "k_verify_fused": ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
+    # eight lanes per signature (single batches up to 8,192 signatures): every quad of the octet runs ONE table's chain -
+    # (NWIN - 1) x 4 doublings, NWIN + 8 additions, 7 table additions, the join - and all eight lanes decompress
+    "k_verify_fused8": ((NWIN - 1) * 4 * 155 + (NWIN + 8) * 200 + 7 * 300 + 300 + 255 * 55 + 21 * 100) * 64 // 8,
     # the same with 3-bit windows (NWIN3 windows of three doublings, four-entry tables): the kernels that put several
     # batches into one launch, two wavefronts per SIMD
     "k_verify_fused3": ((NWIN3 - 1) * 3 * 155 + (2 * NWIN3 + 16) * 200 + 6 * 300 + 255 * 55 + 21 * 100) * 64 // 16,

@@ -219,6 +219,42 @@ k_verify_fused(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict_
     __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(4)];    // this wavefront's tables j*(+-A) and j*(-R), j = 1..8 (verify_quad.h)
     fused_block<4>(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
 }
+// EIGHT lanes per signature (verify_oct_fused): one quad per per-signature table, 8 signatures per wavefront - single batches
+// of up to 8,192 signatures, which are at most one wavefront per SIMD even so.  15 % off the cold latency floor.
+__global__ void __launch_bounds__(64, 2)
+k_verify_fused8(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                unsigned char *__restrict__ bitmap8, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    __shared__ u32 s_tab[HS_QTAB_WORDS_OF(4)];      // per quad: the eight entries of ITS table
+    const u32 block = blockIdx.x;
+    if (skip && *skip) {
+        const u32 first = block * 8;
+        const u32 here = first < n ? min(8u, n - first) : 0u;
+        if (threadIdx.x == 0) bitmap8[block] = (unsigned char)((1u << here) - 1);
+        return;
+    }
+    qtab tab; tab.lds = s_tab;
+    const u32 i = block * 8 + (threadIdx.x >> 3);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    u32 msg[8];
+    load_msg(msg, msgs, j);
+    const bool ok = verify_oct_fused(pks + (size_t)8 * j, sigs + (size_t)16 * j, msg, mode, g_b16, tab);
+    unsigned long long m = __ballot(ok && active);
+    // signature o accepted iff all eight lanes of its octet agree; gather bit 8 o -> bit o
+    m &= m >> 1; m &= m >> 2; m &= m >> 4; m &= 0x0101010101010101ull;
+    m = (m | (m >> 7)) & 0x0003000300030003ull;
+    m = (m | (m >> 14)) & 0x0000000f0000000full;
+    m = (m | (m >> 28)) & 0xffull;
+    if (threadIdx.x == 0) {
+        bitmap8[block] = (unsigned char)m;
+        if (nreject) {
+            const u32 first = block * 8;
+            const u32 here = first < n ? min(8u, n - first) : 0u;
+            const u32 bad = here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
 // The same with 3-bit windows: four entries per table, 20,480 B of LDS, two wavefronts per SIMD - single batches between
 // 16,384 and 32,768 signatures
 __global__ void __launch_bounds__(64, 2)
@@ -637,6 +673,7 @@ static const size_t kLaneMinTotal = 8192;
 // With the half-size form the quad kernels hold TWO per-signature tables in LDS (40,960 B per wavefront: one wavefront per
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{32768};
+static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
 static const size_t kQuadMaxBatch = 32768;
 static const size_t kTailMax = 2048;         // the largest sliver past whole rounds of one-lane wavefronts that goes through the quad kernel (enqueue_cold)
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
@@ -843,6 +880,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
@@ -905,13 +943,15 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
-    const size_t one_round = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 * 16 : 16384;
-    return n <= g_quad_max_batch.load() ? (n <= one_round ? "k_verify_fused" : "k_verify_fused3") : "k_verify";
+    const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
+    if (n <= simds * 8 && n <= g_oct_max_batch.load()) return "k_verify_fused8";
+    return n <= g_quad_max_batch.load() ? (n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3") : "k_verify";
 }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 // (for `count` batches of 1,024 signatures each: the lane form also wants 8,192 signatures in the call)
 extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count) {
     const int k = ctx ? ctx->kernel : HS_K_AUTO;
+    if (k == HS_K_AUTO && count == 1) return hs_ed25519_dominant_kernel_for(1024);      // a list of one takes the single-batch kernels
     if (k == HS_K_LANE || (k == HS_K_AUTO && count >= g_lane_min_batches.load() && count * 1024 >= kLaneMinTotal)) return "k_verify_batches";
     return k == HS_K_FUSED_PAIRS || (k == HS_K_AUTO && count >= g_pairs_min_batches.load()) ? "k_verify_fused_pairs_batches" : "k_verify_fused_batches";
 }
@@ -966,9 +1006,15 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
                "launch k_verify_fused_pairs_batches");
     } else if (kern == HS_K_FUSED) {
         // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above
-        const bool w4 = n <= (size_t)g_devs[ctx->slot].cus * 4 * 16;
-        HS_HIP(launch1(w4 ? (const void *)k_verify_fused : (const void *)k_verify_fused3, dim3(np / 16), dim3(64), a3, st,
-                       ev ? ev[0] : nullptr, ev ? ev[2] : nullptr), "launch k_verify_fused");
+        const size_t simds = (size_t)g_devs[ctx->slot].cus * 4;
+        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && g_oct_max_batch.load() >= n)      // eight lanes per signature: still one wavefront per SIMD at most
+            HS_HIP(launch1((const void *)k_verify_fused8, dim3(np / 8), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+                   "launch k_verify_fused8");
+        else {
+            const bool w4 = n <= simds * 16;
+            HS_HIP(launch1(w4 ? (const void *)k_verify_fused : (const void *)k_verify_fused3, dim3(np / 16), dim3(64), a3, st,
+                           ev ? ev[0] : nullptr, ev ? ev[2] : nullptr), "launch k_verify_fused");
+        }
     } else {
         // One lane per signature: a launch is ceil(n / 64) wavefronts for the chip's 1,024 SIMDs, and its time is that of
         // the SIMD with most wavefronts - 66,667 signatures (the QC of N = 100,000) are 1,042 wavefronts, eighteen SIMDs
@@ -1123,6 +1169,13 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches: null context / list");
     { const int rc = check_batch_list(batches, count, 16, "verify_device_batches"); if (rc) return rc; }
+    if (count == 1 && ctx->kernel == HS_K_AUTO && batches[0].n) {
+        // a list of one is a single batch: it gets the single-batch kernels (the eight-lane latency form up to 8,192 signatures)
+        msg_src m;
+        const int rc = make_digest_src(m, batches[0].d_digests, batches[0].digest_stride);
+        if (rc) return rc;
+        return enqueue_cold(ctx, m, batches[0].d_pks, batches[0].d_sigs, batches[0].n, batches[0].mode, batches[0].d_bitmap, batches[0].d_nreject, stream);
+    }
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     // pairs form (two signatures per quad, 11 % less work, 1.85x a wavefront's latency) once the caller hands over

@@ -374,6 +374,55 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
     return q_is_identity(acc);
 }
 
+// ---- eight lanes per signature: one quad per per-signature table (the latency form for n <= 8,192) ----------------------
+// In verify_quad_core a quad runs TWO additions per window (one from each table), builds both tables and adds all sixteen
+// base-point entries.  With a batch this small half the chip's SIMDs idle anyway, so the signature gets a second quad:
+// quad 0 (role 0) evaluates  [u](+-A) + sum_{j < 8} T[j][w_j],  quad 1 (role 1)  [v](-R) + sum_{j >= 8} T[j][w_j]  - the same
+// instruction stream on different data: ONE addition per window, ONE table of eight entries (20,480 B of LDS per wavefront
+// again), eight base-point additions - and the two partial points are added at the end (quad_half_join).  33 windows of
+// (4 doublings + 1 addition) + 7 + 8 + 1.5 additions on the chain instead of 33 x (4 + 2) + 14 + 16.
+// (x, y): this role's affine point, sign-adjusted; rd: this role's scalar recoded radix 16 (popped from the top); rwl: this
+// role's eight radix-65536 digits of w, left-aligned (popped from the top); jbase: 0 or 8.
+HS_Q qv quad_half_chain(const fe &x, const fe &y, u32 rd[8], u32 rwl[8], u32 jbase, int nwin, const u32 *b16, qtab &tab) {
+    qtab_build<4>(tab, x, y);
+#pragma nounroll
+    for (int t = nwin; t < 64; t++) (void)sc_pop_digit(rd);
+    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
+    int d = sc_pop_digit(rd);
+    qv e = qtab_pick(tab, d < 0 ? -d : d);
+#pragma nounroll
+    for (int w = nwin - 1; w >= 0; w--) {
+        const int nd = w == nwin - 1 ? 0 : 4;
+#pragma nounroll
+        for (int k = 0; k < nd; k++) acc = q_dbl(acc);
+        const qv se = q_cached_signed(e, d < 0);
+        if (w > 0) { d = sc_pop_digit(rd); e = qtab_pick(tab, d < 0 ? -d : d); }
+        acc = q_add_cached(acc, se);
+    }
+    int ds = sc_pop_digit16(rwl);
+    qv eb = q_load_entry(b16 + ((size_t)(jbase + 7) * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
+#pragma nounroll
+    for (int j = 7; j >= 0; j--) {
+        const qv sb = q_cached_signed(eb, ds < 0);
+        if (j > 0) {
+            ds = sc_pop_digit16(rwl);
+            eb = q_load_entry(b16 + ((size_t)(jbase + (u32)j - 1) * 32769 + (size_t)(ds < 0 ? -ds : ds)) * HS_ENTRY_WORDS);
+        }
+        acc = q_add_cached(acc, sb);
+    }
+    return acc;
+}
+// the two roles' partial points added, and the identity test
+HS_Q qflags quad_half_join(const qv &mine, const qv &other) { return q_is_identity(q_add_cached(mine, q_to_cached(other))); }
+// this role's operands out of the signature's recoded scalars
+HS_HD void quad_half_operands(u32 rd[8], u32 rwl[8], const half_scalars &hs, bool role1) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        rd[t] = role1 ? hs.rv[t] : hs.ru[t];
+        rwl[t] = role1 ? hs.rw[t] : (t >= 4 ? hs.rw[t - 4] : 0u);       // digits 15..8, or digits 7..0 moved to the top
+    }
+}
+
 // The scalar half of stage 1 (hash, range check, recodings) - cheap, every lane of the quad
 // computes it redundantly so no lane diverges.  Returns s < L.
 // k is recoded in signed radix 16 (cold path: 4-bit windows on -A) or, with k_radix256, in
@@ -442,6 +491,36 @@ HS_Q bool verify_quad_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 m
     const fe rx = q_perm<1, 1, 1, 1>(pt.X), ry = q_perm<1, 1, 1, 1>(pt.Y);
     const int nwin = HS_NWIN_OF(hs.meta);
     const qflags f = verify_quad_core<W>(ax, ay, rx, ry, hs, nwin, b16, atab, rtab);
+    return f.f && ok;
+}
+
+// The eight-lane latency form (quad_half_chain): lanes 0-3 of an octet take role 0 (A), lanes 4-7 role 1 (R).  Every lane
+// decompresses its role's point and computes the scalars; the partial points cross the octet with one lane exchange.
+HS_Q bool verify_oct_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mode, const u32 *b16, qtab &tab) {
+    const bool role1 = (threadIdx.x & 4u) != 0;
+    u32 enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) enc[j] = role1 ? sig[j] : pk[j];
+    ge_p3 pt;
+    u32 fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
+    const u32 fo = (u32)__shfl_xor((int)fl, 4, 64);                  // the other role's point flags
+    half_scalars hs;
+    bool ok = prepare_scalars_half<4>(hs, pk, sig, msg);
+    ok = ok && (fl & HS_F_ONCURVE) && (fo & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL) && !(fo & HS_F_SMALL);
+    // role 0: -A, or +A when u < 0 (the digits are those of |u|); role 1: -R
+    fe nx, sx;
+    fe_neg(nx, pt.X);
+    fe_select(sx, nx, pt.X, !role1 && ((hs.meta >> 8) & 1) != 0);
+    u32 rd[8], rwl[8];
+    quad_half_operands(rd, rwl, hs, role1);
+    const int nwin = HS_NWIN_OF(hs.meta);
+    const qv mine = quad_half_chain(sx, pt.Y, rd, rwl, role1 ? 8u : 0u, nwin, b16, tab);
+    qv other;
+#pragma unroll
+    for (int i = 0; i < 10; i++) other.v[i] = (u32)__shfl_xor((int)mine.v[i], 4, 64);
+    const qflags f = quad_half_join(mine, other);
     return f.f && ok;
 }
 

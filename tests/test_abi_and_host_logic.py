@@ -106,11 +106,11 @@ def test_qc_structural_errors_precede_crypto(openssl_vectors):
 
 def test_batches_per_launch_kernel_policy():
     """hs_ed25519_verify_device_batches picks its kernel by the batch count of the call (no GPU needed to ask):
-    up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight (1,024-signature)
-    batches the one-lane pair over the batch list (throughput)."""
+    one batch the single-batch kernels (eight lanes per signature: the latency form), two or three the one-signature-per-quad
+    form, from four the pairs form, from eight (1,024-signature) batches the one-lane pair over the batch list (throughput)."""
     lib = _lib.lib()
     names = [lib.hs_ed25519_batches_kernel_for(None, k).decode() for k in (1, 2, 3, 4, 7, 8, 16)]
-    assert names == ["k_verify_fused_batches"] * 3 + ["k_verify_fused_pairs_batches"] * 2 + ["k_verify_batches"] * 2
+    assert names == ["k_verify_fused8"] + ["k_verify_fused_batches"] * 2 + ["k_verify_fused_pairs_batches"] * 2 + ["k_verify_batches"] * 2
 
 
 def test_code_object_has_no_reversed_subtract_with_dpp():

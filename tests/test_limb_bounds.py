@@ -53,7 +53,7 @@ def test_every_path_respects_the_limb_bounds(emu_check, edge_vectors, torsion_fu
     n = len(msgs)
     m, p, s = b"".join(msgs), b"".join(pks), b"".join(sigs)
     out = B(n)
-    for fn in ("emu_verify", "emu_verify_quad", "emu_verify_quad3"):
+    for fn in ("emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct"):
         for mode in (0, 1):
             getattr(emu, fn)(m, S(32), p, s, S(n), mode, out)          # aborts on a bound violation
     # field-level extremes through the loose-operand entry points
