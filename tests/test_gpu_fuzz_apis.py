@@ -5,6 +5,7 @@ unknown key indices on the key-cache forms), through a randomly chosen entry poi
 a forced RLC stage.  Every accept bitmap must equal the oracle's per-signature verdicts (STRICT / BATCH laws; BATCH_RLC
 localises with the BATCH law, and a batch it accepts outright contains no signature the BATCH law rejects)."""
 import hashlib
+import os
 import random
 import struct
 
@@ -68,7 +69,7 @@ def _corrupt(rng, dg, pk, sg, n, shared, rate, allow_key):
 
 def test_random_walk_over_the_entry_points(oracle, world):
     keys, secrets, ks, runners = world
-    rng = random.Random(20260921)
+    rng = random.Random(int(os.environ.get("HS_FUZZ_SEED", "20260921")))      # HS_FUZZ_SEED / HS_FUZZ_STEPS: longer one-off walks
     pending = []                                    # tickets of an open burst: (ticket, want, n)
     counts = {}
 
@@ -79,7 +80,7 @@ def test_random_walk_over_the_entry_points(oracle, world):
             ok, bm = t.wait()
             assert bits(bm, n) == want and ok == all(want)
 
-    for it in range(220):
+    for it in range(int(os.environ.get("HS_FUZZ_STEPS", "220"))):
         n = rng.choice(SIZES) if rng.random() < 0.7 else rng.randrange(1, 3001)
         shared = rng.random() < 0.5
         mode = rng.choice([_lib.STRICT, _lib.BATCH, _lib.BATCH_RLC])
