@@ -30,7 +30,7 @@ def _mixed(n):
     return dg, pk, sg, bad
 
 
-@pytest.mark.parametrize("n", [6667, 8384, 66667])
+@pytest.mark.parametrize("n", [6667, 8384, 20000, 66667])      # eight lanes / four lanes 4-bit / four lanes 3-bit / one-lane pair + sliver
 def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
     dg, pk, sg, bad = _mixed(n)
     keys = [pk[32 * i:32 * i + 32] for i in range(n)]
