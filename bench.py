@@ -1066,9 +1066,13 @@ def main():
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
-            for key, fn in (("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
+            # streamed_rounds first: the ring (and its 5 GB key set) built right after the process's FIRST wide pool context
+            # runs ~25 % slower until the pools are torn down - once per process, whatever the number of calls, in the
+            # round-2 tree too (tools/streamed_probe.py bisect, profiles/r3_streamed_probe.txt): an allocation-order effect,
+            # not the ring's steady state
+            for key, fn in (("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
+                            ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
-                            ("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
                             ("multi_process", lambda: multi_process(n))):
                 try:

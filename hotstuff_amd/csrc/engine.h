@@ -60,6 +60,7 @@ struct hs_ed25519_ctx {
     size_t wire_cap = 0;
     bool staging = false;
     int kernel = HS_K_AUTO;       // per-context kernel choice (tests, A/B); HS_K_AUTO = by batch size
+    bool several_in_flight = false;  // the context is one of several that run at once (a ring slot): no eight-lane latency form
     void *rlc = nullptr;          // hs_rlc.hip: this context's MSM workspace (rlc_ws *), freed by rlc_release
     // optional profiling: a ring of (start, after-prepare, after-verify) HIP events attached to the
     // kernel dispatches, read back by hs_ed25519_ctx_kernel_times after a synchronize

@@ -1007,7 +1007,10 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
     } else if (kern == HS_K_FUSED) {
         // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above
         const size_t simds = (size_t)g_devs[ctx->slot].cus * 4;
-        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && g_oct_max_batch.load() >= n)      // eight lanes per signature: still one wavefront per SIMD at most
+        // eight lanes per signature: still one wavefront per SIMD at most - for a call that has the chip to itself.  The
+        // slots of a round ring run several rounds at once (twice the wavefronts per signature then cost throughput:
+        // 41 against 53 M signatures/s from four slots), so they keep four lanes per signature.
+        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n)
             HS_HIP(launch1((const void *)k_verify_fused8, dim3(np / 8), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                    "launch k_verify_fused8");
         else {

@@ -541,6 +541,7 @@ extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, 
     for (ring_slot &s : r->slots) {
         int rc = hs_ed25519_ctx_create_on(&s.ctx, 64, ks ? ks->slot : 0);
         if (!rc) rc = ctx_reserve(s.ctx, r->cap, true);      // all allocation happens here, none under capture
+        if (!rc) s.ctx->several_in_flight = slots > 1;
         if (rc) { hs_ed25519_ring_destroy(r); return rc; }
     }
     *out = r;

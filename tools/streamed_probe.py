@@ -1,0 +1,78 @@
+import sys, os, json, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tools"))
+import torch, synth, bench
+from hotstuff_amd import _lib
+_lib.init(0, 1024)
+def show(tag):
+    r = bench.streamed_rounds(_lib, synth, seconds=0.4)
+    print(tag, {k: (round(v['signatures_per_s']/1e6,1), v['submit_to_verdict_p50_ms']) for k, v in r.items() if isinstance(v, dict)}, flush=True)
+which = sys.argv[1]
+show("fresh")
+if which == "e2e":
+    n = 1024
+    batches = [synth.make_batch(n, shared=False, first=j * n, cache_dir="/tmp/hs_synth") for j in range(16)]
+    bench.end_to_end(_lib, batches, n, 32, _lib.STRICT, seconds=0.3)
+    show("after end_to_end")
+elif which == "qc":
+    dev = torch.device("cuda", 0)
+    bench.qc_latency(_lib, torch, synth, dev, calls=50)
+    show("after qc_latency")
+    bench.rlc_ab(_lib, torch, synth, dev, calls=10)
+    show("after rlc_ab")
+if which == "streams":
+    ctxs = [_lib.DeviceContext(1024) for _ in range(int(sys.argv[2]))]
+    show("with %s idle contexts alive" % sys.argv[2])
+    for c in ctxs: c.close()
+    show("after closing them")
+if which == "hostqc":
+    import ctypes
+    n = 6667
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    for i in range(30):
+        assert _lib.lib().hs_ed25519_verify_shared(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, _lib.BATCH, None) == 1
+    show("after 30 host-API QC calls (one wide pool context)")
+    ks = _lib.KeySet([pk[32 * i:32 * i + 32] for i in range(n)] + [synth.key_seed(20_000_000 + i) for i in range(3333)])
+    show("with a 10,000-key set alive")
+    ks.close()
+    show("after closing it")
+if which == "cause":
+    import ctypes
+    def host_calls(n, reps=30):
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+        b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+        for i in range(reps):
+            assert _lib.lib().hs_ed25519_verify_shared(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, _lib.BATCH, None) == 1
+    host_calls(1024)
+    show("after host calls of 1,024 (narrow pool)")
+    host_calls(6667)
+    show("after host calls of 6,667 (wide pool, zero-copy)")
+    _lib.shutdown(); _lib.init(0, 1024)
+    show("after shutdown + init (pools destroyed)")
+    host_calls(6667, reps=1)
+    show("after ONE host call of 6,667")
+if which == "bisect":
+    import ctypes
+    def host_calls(n, reps, api="host"):
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+        if api == "host":
+            b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+            for i in range(reps):
+                assert _lib.lib().hs_ed25519_verify_shared(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, _lib.BATCH, None) == 1
+        else:       # device API: resident inputs, one context, synchronised after every call
+            dev = torch.device("cuda", 0)
+            t = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (dg, pk, sg)]
+            out = torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev)
+            ctx = _lib.DeviceContext(n)
+            for i in range(reps):
+                ctx.verify(t[0].data_ptr(), 0, t[1].data_ptr(), t[2].data_ptr(), n, _lib.BATCH, out.data_ptr(), 0, 0)
+                torch.cuda.synchronize()
+            ctx.close()
+    def fresh():
+        _lib.shutdown(); _lib.init(0, 1024)
+    for reps in (3, 10, 30, 100):
+        fresh(); host_calls(6667, reps); show("host API x%d" % reps)
+    fresh(); host_calls(6667, 30); time.sleep(1.0); show("host API x30, then 1 s idle")
+    fresh(); host_calls(6667, 30, api="device"); show("device API x30 (context closed after)")
+    fresh(); host_calls(9000, 30); show("host API x30 of 9,000 (four-lane kernel, copy engines)")
+    fresh(); show("fresh again")
