@@ -540,6 +540,8 @@ def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
             assert bool((bms[0].view(torch.int64)[: n // 64] == -1).all()), "rejected a valid QC"
             if mode == _lib.BATCH_RLC:
                 assert ctxs[0].rlc_last()[0] == 1, "the RLC stage did not accept a valid QC"
+            for c in ctxs:                     # four contexts kept busy: the caller says so (hs_ed25519_ctx_set_concurrent)
+                c.set_concurrent(True)
             for j in range(nctx):
                 call(j)
             torch.cuda.synchronize(dev)
@@ -553,6 +555,8 @@ def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
             for s_ in sts:
                 s_.synchronize()
             wall = time.perf_counter() - t0
+            for c in ctxs:
+                c.set_concurrent(False)
             lat.sort()
             row[name] = {"p50_ms": round(lat[len(lat) // 2] * 1e3, 4), "signatures_per_s_4_in_flight": round(reps * nctx * n / wall, 1)}
         row["winner_latency"] = min(("per_signature", "rlc_msm"), key=lambda k: row[k]["p50_ms"])
@@ -572,10 +576,13 @@ def sharded_c_abi(ngpus, ndev, validators=100000, timeout_s=150):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                               "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     try:
+        env["HS_SHARDED_DUMP_AFTER_S"] = str(max(10, timeout_s - 20))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_c_abi.py"), str(ngpus), str(validators), "30", str(ndev)],
                            capture_output=True, text=True, timeout=timeout_s, env=env)
-    except subprocess.TimeoutExpired:
-        return {"error": "tools/sharded_c_abi.py did not finish within %d s" % timeout_s}
+    except subprocess.TimeoutExpired as e:
+        # the tool prints a dated stage marker per step on stderr, and the stack of every thread 20 s before the limit
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        return {"error": "tools/sharded_c_abi.py did not finish within %d s" % timeout_s, "stderr_tail": err[-1500:]}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": "tools/sharded_c_abi.py exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}

@@ -131,6 +131,8 @@ def lib():
                 l.hs_ed25519_public_keys.restype = ctypes.c_int
                 l.hs_ed25519_ctx_set_kernel.argtypes = [vp, ctypes.c_int]
                 l.hs_ed25519_ctx_set_kernel.restype = ctypes.c_int
+                l.hs_ed25519_ctx_set_concurrent.argtypes = [vp, ctypes.c_int]
+                l.hs_ed25519_ctx_set_concurrent.restype = ctypes.c_int
                 l.hs_ed25519_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), sz, sz]
                 l.hs_ed25519_init_devices.restype = ctypes.c_int
                 l.hs_ed25519_device_count.argtypes = []
@@ -656,6 +658,11 @@ class DeviceContext:
     def set_kernel(self, which):
         """hs_ed25519_ctx_set_kernel; returns the previous choice."""
         return check(lib().hs_ed25519_ctx_set_kernel(self._h, int(which)), "hs_ed25519_ctx_set_kernel")
+
+    def set_concurrent(self, on=True):
+        """hs_ed25519_ctx_set_concurrent: this context is one of several the caller keeps busy on the GPU - throughput
+        forms (four lanes per signature, no side stream) instead of the lone call's latency forms.  Returns the previous setting."""
+        return check(lib().hs_ed25519_ctx_set_concurrent(self._h, 1 if on else 0), "hs_ed25519_ctx_set_concurrent")
 
     def set_rlc_min(self, n):
         """Run the RLC stage of BATCH_RLC calls from n signatures up on this context (0 = default)."""

@@ -44,8 +44,6 @@ struct hs_ed25519_ctx {
     int slot = 0, device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
-    hipStream_t side = nullptr;   // large one-lane calls: the sliver past a whole round of wavefronts runs beside them (enqueue_cold)
-    hipEvent_t fork = nullptr, join = nullptr;
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     unsigned part = 0;            // which slice (narrow pool contexts)
     size_t cap = 0;               // signatures
@@ -60,7 +58,7 @@ struct hs_ed25519_ctx {
     size_t wire_cap = 0;
     bool staging = false;
     int kernel = HS_K_AUTO;       // per-context kernel choice (tests, A/B); HS_K_AUTO = by batch size
-    bool several_in_flight = false;  // the context is one of several that run at once (a ring slot): no eight-lane latency form
+    bool several_in_flight = false;  // other whole-chip calls run beside this context's (ring slot, busy wide pool, hs_ed25519_ctx_set_concurrent): throughput forms
     void *rlc = nullptr;          // hs_rlc.hip: this context's MSM workspace (rlc_ws *), freed by rlc_release
     // optional profiling: a ring of (start, after-prepare, after-verify) HIP events attached to the
     // kernel dispatches, read back by hs_ed25519_ctx_kernel_times after a synchronize

@@ -263,6 +263,33 @@ k_verify_fused3(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict
     __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(3)];
     fused_block<3>(s_atab, blockIdx.x, msgs, pks, sigs, n, mode, bitmap16, nreject, skip);
 }
+// The one-lane stage 2 over whole rounds of wavefronts AND, in the same grid, the sliver past them through the four-lane
+// fused form with 3-bit windows (20,480 B of LDS per workgroup: two wavefronts per SIMD still fit, so the one-lane
+// wavefronts lose nothing).  The first `tail_blocks` workgroups are the sliver's (16 signatures each, dispatched first); the
+// rest are k_verify's.  One launch on one stream: no second stream, no events, the same under graph capture (enqueue_cold).
+__global__ void __launch_bounds__(64, HS_LANE_WAVES)
+k_verify_tail(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject,
+              msg_src tmsgs, const u32 *__restrict__ t_pks, const u32 *__restrict__ t_sigs, u32 tn,
+              unsigned short *__restrict__ t_bitmap16, u32 tail_blocks) {
+    __shared__ u32 s_atab[2 * HS_QTAB_WORDS_OF(3)];
+    if (blockIdx.x < tail_blocks) {
+        fused_block<3>(s_atab, blockIdx.x, tmsgs, t_pks, t_sigs, tn, mode, t_bitmap16, nreject, nullptr);
+        return;
+    }
+    const u32 block = blockIdx.x - tail_blocks;
+    const u32 i = block * 64 + threadIdx.x;
+    const bool active = i < n;
+    const bool ok = verify_lane(ws, active ? i : n - 1, mode, g_b16) && active;
+    const unsigned long long mask = __ballot(ok);
+    if (threadIdx.x == 0) {
+        bitmap[block] = mask;
+        if (nreject) {
+            const u32 lanes = min(64u, n - block * 64);
+            const u32 bad = lanes - (u32)__popcll(mask);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
 // Several independent small batches in ONE grid (hs_ed25519_verify_device_batches): a 1,024-signature
 // batch is only 64 wavefronts - at most one per SIMD of the CU slice its stream is confined to - and a lone
 // wavefront issues at about half the rate two co-resident ones reach (profiles/r1_ubench_valu.txt).
@@ -675,7 +702,11 @@ static const size_t kLaneMinTotal = 8192;
 static std::atomic<size_t> g_quad_max_batch{32768};
 static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
 static const size_t kQuadMaxBatch = 32768;
-static const size_t kTailMax = 2048;         // the largest sliver past whole rounds of one-lane wavefronts that goes through the quad kernel (enqueue_cold)
+// the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
+// (enqueue_cold): -19 % on the call's p50 up to 16,384 signatures past the round (1.03 against 1.27 ms at 66,667 ... 73,728,
+// 1.07 against 1.31 at 81,920), nothing at 32,768 (profiles/r3_concurrent_ab.txt)
+static const size_t kTailMax = 16384;
+static std::atomic<size_t> g_tail_max{kTailMax};      // HS_ED25519_TAIL_MAX: sweeps
 // Host-pointer calls of up to this many signatures (64 wavefronts of the fused kernel) are served by the NARROW
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
 // of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py `end_to_end`); one caller
@@ -782,9 +813,6 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->done) (void)hipEventDestroy(c->done);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-    if (c->fork) (void)hipEventDestroy(c->fork);
-    if (c->join) (void)hipEventDestroy(c->join);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
     hs::rlc_release(c);
@@ -795,6 +823,12 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
 // Per-context kernel choice (tests and A/B measurements; the default is by batch size):
 // HS_K_AUTO 0, HS_K_LANE 1 (cold: k_prepare + k_verify; cached: k_verify_cached_lane),
 // HS_K_FUSED 3 (cold: k_verify_fused; cached: k_verify_cached_lane2r).  Returns the previous choice.
+extern "C" int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *c, int concurrent) {
+    if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_concurrent: null context");
+    const int was = c->several_in_flight ? 1 : 0;
+    c->several_in_flight = concurrent != 0;
+    return was;
+}
 extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
     if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_kernel: null context");
     const int old = c->kernel;
@@ -881,6 +915,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
+    if (const char *e = getenv("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
@@ -945,7 +980,9 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
     if (n <= simds * 8 && n <= g_oct_max_batch.load()) return "k_verify_fused8";
-    return n <= g_quad_max_batch.load() ? (n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3") : "k_verify";
+    if (n <= g_quad_max_batch.load()) return n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3";
+    const size_t tail = n % (simds * 64);       // a sliver past whole rounds of wavefronts rides in the stage-2 launch (enqueue_cold)
+    return n > simds * 64 && tail && tail <= g_tail_max.load() ? "k_verify_tail" : "k_verify";
 }
 extern "C" const char *hs_ed25519_dominant_kernel(void) { return hs_ed25519_dominant_kernel_for(1024); }
 // (for `count` batches of 1,024 signatures each: the lane form also wants 8,192 signatures in the call)
@@ -1007,9 +1044,9 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
     } else if (kern == HS_K_FUSED) {
         // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above
         const size_t simds = (size_t)g_devs[ctx->slot].cus * 4;
-        // eight lanes per signature: still one wavefront per SIMD at most - for a call that has the chip to itself.  The
-        // slots of a round ring run several rounds at once (twice the wavefronts per signature then cost throughput:
-        // 41 against 53 M signatures/s from four slots), so they keep four lanes per signature.
+        // eight lanes per signature: still one wavefront per SIMD at most - for a call that has the chip to itself.  With
+        // several whole-chip calls at once (the slots of a round ring, hs_ed25519_ctx_set_concurrent) twice the wavefronts
+        // per signature cost throughput (41 against 53 M signatures/s from four ring slots): four lanes per signature then.
         if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n)
             HS_HIP(launch1((const void *)k_verify_fused8, dim3(np / 8), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                    "launch k_verify_fused8");
@@ -1022,39 +1059,28 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         // One lane per signature: a launch is ceil(n / 64) wavefronts for the chip's 1,024 SIMDs, and its time is that of
         // the SIMD with most wavefronts - 66,667 signatures (the QC of N = 100,000) are 1,042 wavefronts, eighteen SIMDs
         // carry two, and the call took 1.49 ms where 65,536 signatures take 0.85.  When such a sliver
-        // is left over (up to one round of the quad kernel: 16 signatures per wavefront, a third of the one-lane
-        // wavefront's time), it goes through k_verify_fused instead - on a side stream, beside the one-lane pair.
+        // is left over it goes through the four-lane fused form instead (16 signatures per wavefront, a third of the one-lane
+        // wavefront's time) - as the first workgroups of the stage-2 launch itself (k_verify_tail): 0.96 ms.  (It first ran as
+        // k_verify_fused on a side stream between two events: 0.87 ms when the side stream had a hardware queue of its own,
+        // 1.26 ms when the runtime had mapped it onto the main stream's; a side stream of higher priority: 1.2 ms every
+        // time - profiles/r3_concurrent_ab.txt.)
+        // Not behind an RLC stage (d_skip: the kernels here are its rare fallback and return at once when it accepted), and
+        // not when several whole-chip calls run at once (the sliver's wavefronts then only compete with the other calls').
         const size_t round_sigs = (size_t)g_devs[ctx->slot].cus * 4 * 64;
         const size_t tail = round_sigs ? n % round_sigs : 0;
-        if (ctx->kernel == HS_K_AUTO && n > round_sigs && tail && tail <= kTailMax) {
+        if (ctx->kernel == HS_K_AUTO && !d_skip && !ctx->several_in_flight && n > round_sigs && tail && tail <= g_tail_max.load()) {
             const size_t main_n = n - tail;                      // a multiple of 64: the tail's bitmap starts on a word
             msg_src tmsgs = msgs;
             tmsgs.digests = msgs.digests + (size_t)msgs.stride_words * main_n;
             const u32 *t_pk = p_pk + (size_t)8 * main_n, *t_sg = p_sg + (size_t)16 * main_n;
-            unsigned long long *t_bm = p_bm + main_n / 64;
-            u32 tn = (u32)tail;
-            void *at[] = { &tmsgs, &t_pk, &t_sg, &tn, &mode_, &t_bm, &p_nr, &p_skip };
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cap);
-            hipStream_t side = st;
-            if (cap == hipStreamCaptureStatusNone) {             // (under graph capture the two parts simply follow each other)
-                if (!ctx->side) {
-                    HS_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking), "hipStreamCreate (side stream)");
-                    HS_HIP(hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming), "hipEventCreate");
-                    HS_HIP(hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming), "hipEventCreate");
-                }
-                side = ctx->side;
-                HS_HIP(hipEventRecord(ctx->fork, st), "hipEventRecord");         // the inputs' producers were ordered on st
-                HS_HIP(hipStreamWaitEvent(side, ctx->fork, 0), "hipStreamWaitEvent");
-            }
-            HS_HIP(launch1((const void *)k_verify_fused, dim3((unsigned)(round_up(tail, 64) / 16)), dim3(64), at, side, nullptr, nullptr),
-                   "launch k_verify_fused (tail)");
-            if (side != st) HS_HIP(hipEventRecord(ctx->join, side), "hipEventRecord");
+            unsigned short *t_bm = (unsigned short *)(p_bm + main_n / 64);
+            u32 tn = (u32)tail, tblocks = (u32)(round_up(tail, 64) / 16);
             nn_ = (u32)main_n;
+            void *at[] = { &ws, &nn_, &mode_, &p_bm, &p_nr, &tmsgs, &t_pk, &t_sg, &tn, &t_bm, &tblocks };
             HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn_ + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
                    "launch k_prepare");
-            HS_HIP(launch1((const void *)k_verify, dim3(nn_ / 64), dim3(64), a2, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify");
-            if (side != st) HS_HIP(hipStreamWaitEvent(st, ctx->join, 0), "hipStreamWaitEvent");
+            HS_HIP(launch1((const void *)k_verify_tail, dim3(nn_ / 64 + tblocks), dim3(64), at, st, nullptr, ev ? ev[2] : nullptr),
+                   "launch k_verify_tail");
             return 0;
         }
         HS_HIP(launch1((const void *)k_prepare, dim3((2 * nn + 63) / 64), dim3(64), a1, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),

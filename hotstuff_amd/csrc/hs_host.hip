@@ -57,6 +57,8 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
             hs_ed25519_ctx *c = d.free_ctx[k][pick];
             d.free_ctx[k].erase(d.free_ctx[k].begin() + (long)pick);
             if (k == 1) d.part_busy[c->part % 64]++;
+            // a whole-chip call that finds another one in flight on its device runs the throughput forms (enqueue_cold)
+            else c->several_in_flight = d.live[0] - (int)d.free_ctx[0].size() > 1;
             *out = c;
             return 0;
         }
@@ -64,6 +66,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
         g_cv.wait(lk);
     }
     const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
+    const bool others_busy = k == 0 && g_devs[slot].live[0] - (int)g_devs[slot].free_ctx[0].size() > 1;
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
     int rc = -1;
@@ -80,6 +83,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }
     c->narrow = k == 1;
     c->part = part;
+    c->several_in_flight = others_busy;
     if (k == 1) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].part_busy[part % 64]++; lk.unlock(); }
     *out = c;
     return 0;

@@ -291,8 +291,8 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
                                 size_t *launches);
 
 /* Per-context kernel choice, for tests and A/B measurements (the host-pointer calls always use
- * the default): 0 = by batch size (cold: fused 4-lanes-per-signature kernel up to 32,768
- * signatures, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 98,304, the
+ * the default): 0 = by batch size (cold: eight lanes per signature up to 8,192 signatures, the fused
+ * four-lanes-per-signature kernels up to 32,768, k_prepare + k_verify above; key cache: k_verify_cached_lane2r up to 98,304, the
  * one-lane kernel above), 1 = the one-lane-per-signature kernels, 3 = the fused / two-lane
  * kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
  * the batch count (3 pins it to the one-signature-per-quad form, 1 to the one-lane pair over the
@@ -300,6 +300,16 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
  * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
  * with -DHS_AB_VARIANTS and are not part of the shipped library.) */
 int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
+
+/* Latency form or throughput form.  By default a context assumes its call has the GPU to itself (the reference's
+ * node verifies one certificate at a time: consensus/src/core.rs:379 -> messages.rs:197) and picks the forms with the
+ * shortest time for ONE call: eight lanes per signature up to 8,192 signatures, and - above 65,536 - the sliver past
+ * whole rounds of wavefronts on a side stream.  Both cost throughput when several whole-chip calls run at once
+ * (profiles/r3_oct_ab.txt, r3_concurrent_ab.txt).  A caller that keeps several contexts busy says so here
+ * (concurrent != 0) and gets four lanes per signature and no side stream; the verdicts are the same.  The library
+ * sets it by itself where it knows: the slots of a round ring, and host-pointer calls that find another large call
+ * of the same device in flight.  Returns the previous setting (0 / 1) or HS_ED25519_E_ARG. */
+int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *ctx, int concurrent);
 
 /* The dominant kernel's symbol name (what to look for in a rocprofv3 kernel trace). */
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */

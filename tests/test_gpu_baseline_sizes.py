@@ -30,7 +30,7 @@ def _mixed(n):
     return dg, pk, sg, bad
 
 
-@pytest.mark.parametrize("n", [6667, 8384, 20000, 66667])      # eight lanes / four lanes 4-bit / four lanes 3-bit / one-lane pair + sliver
+@pytest.mark.parametrize("n", [6667, 8384, 20000, 66667])      # eight lanes / four lanes 4-bit / four lanes 3-bit / one-lane pair with the sliver in its stage-2 grid
 def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
     dg, pk, sg, bad = _mixed(n)
     keys = [pk[32 * i:32 * i + 32] for i in range(n)]
@@ -43,7 +43,7 @@ def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
         assert not ok and bits(bm, n) == expect, "cold path, mode %d" % mode
         ok, bm = ks.verify_packed(dg, packed, sg, n, mode, shared=True, want_bitmap=True)
         assert not ok and bits(bm, n) == expect, "key-cache path, mode %d" % mode
-    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() == ("k_verify_fused8" if n <= 8192 else ("k_verify_fused" if n <= 16384 else ("k_verify_fused3" if n <= 32768 else "k_verify")))
+    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() == ("k_verify_fused8" if n <= 8192 else ("k_verify_fused" if n <= 16384 else ("k_verify_fused3" if n <= 32768 else "k_verify_tail")))
     assert _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane2r"
     ks.close()
 
@@ -87,3 +87,35 @@ def test_one_lane_cached_kernel_reached_by_size(oracle):
         ok, bm = ks.verify_packed(dg2, packed, sg_t, n, mode, shared=True, want_bitmap=True)
         assert not ok and bits(bm, n) == bytes(expect)
     ks.close()
+
+
+@pytest.mark.parametrize("n", [6667, 66667])
+def test_concurrent_hint_changes_the_form_not_the_verdicts(oracle, n):
+    """hs_ed25519_ctx_set_concurrent: four lanes per signature instead of eight at 6,667, no side-stream sliver at 66,667 -
+    and the same accept bits as the oracle, both modes, RLC stage in front included (which never splits the sliver off)."""
+    from gpu_helpers import DeviceRunner
+    dg, pk, sg, bad = _mixed(n)
+    runs = [DeviceRunner(n), DeviceRunner(n), DeviceRunner(n, rlc_min=1)]
+    assert runs[1].ctx.set_concurrent(True) == 0 and runs[1].ctx.set_concurrent(True) == 1      # returns the previous setting
+    for mode in (_lib.BATCH, _lib.STRICT):
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+        for r in runs[:2]:
+            assert r.bits(dg, pk, sg, n, mode, True) == expect
+    expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, _lib.BATCH)
+    assert runs[2].bits(dg, pk, sg, n, _lib.BATCH_RLC, True) == expect                         # rejected by the RLC, localised behind it
+    vdg, vpk, vsg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    assert all(runs[2].bits(vdg, vpk, vsg, n, _lib.BATCH_RLC, True)) and runs[2].ctx.rlc_last()[0] == 1
+    for r in runs:
+        r.close()
+
+
+@pytest.mark.parametrize("n,kernel", [(65536 + 16384, "k_verify_tail"), (65536 + 16448, "k_verify"), (2 * 65536 + 100, "k_verify_tail")])
+def test_sliver_past_whole_rounds_of_wavefronts(oracle, n, kernel):
+    """Large one-lane calls: a sliver of up to 16,384 signatures past whole rounds of wavefronts rides in the stage-2 launch
+    as four-lane workgroups (k_verify_tail); a larger one does not.  Cold path, both modes, ~3 % corrupted, vs the oracle."""
+    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() == kernel
+    dg, pk, sg, bad = _mixed(n)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+        ok, bm = _lib.verify_packed(dg, pk, sg, n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect, "mode %d" % mode

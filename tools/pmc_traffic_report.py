@@ -19,7 +19,8 @@ KERNELS = {
     "k_verify_cached_lane2r_batches@64": ("key cache, 4 x 1,024 signatures per launch", 4096, "fetch_line_gather_16B", (48 * 128 + 100) * 4096),
     "k_verify_cached_lane2r@1042": ("key cache, one 66,667-signature QC (N = 100,000)", 66667, "fetch_line_gather_16B", (48 * 128 + 68) * 66667),
     "k_prepare@2084": ("cold one-lane pair, 66,667 signatures", 66667, "fetch_dword_rows", 96 * 66667),
-    "k_verify@1024": ("cold one-lane pair, 65,536 of 66,667 signatures (the sliver of 1,131 runs through k_verify_fused@72)", 65536, "fetch_line_gather_16B", 96 * 65536),
+    "k_verify_tail@1096": ("cold stage 2 of one 66,667-signature QC: 1,024 one-lane wavefronts + the 1,131-signature sliver as 72 four-lane wavefronts of the same grid", 66667, "fetch_line_gather_16B", 96 * 66667),
+    "k_verify@1024": ("(earlier form) cold one-lane pair, 65,536 of 66,667 signatures (the sliver of 1,131 ran through k_verify_fused@72 on a side stream)", 65536, "fetch_line_gather_16B", 96 * 65536),
     "k_prepare@2048": ("cold one-lane pair, 65,536 of 66,667 signatures", 65536, "fetch_dword_rows", 96 * 65536),
     "k_verify_fused@72": ("the 1,131-signature sliver of the 66,667-signature call", 1131, "fetch_line_gather_16B", 96 * 1131),
     "k_rlc_prepare@3126": ("RLC stage 1, 66,667 signatures", 66667, "fetch_dword_rows", 96 * 66667),

@@ -55,6 +55,10 @@ def measure(n, mode, kernel=_lib.KERNEL_AUTO, shared=True, nctx=4, calls=25, rep
     assert bool((bms[0].view(torch.int64)[: n // 64] == -1).all()) and int(nrs[0].item()) == 0
     if mode == _lib.BATCH_RLC:
         assert ctxs[0].rlc_last()[0] == 1
+    # several contexts kept busy: the caller says so (throughput forms); HS_SWEEP_NO_HINT=1 measures without the hint
+    if os.environ.get("HS_SWEEP_NO_HINT") != "1":
+        for c in ctxs:
+            c.set_concurrent(True)
     for j in range(nctx):
         call(j)
     for s in sts:

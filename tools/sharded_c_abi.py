@@ -20,7 +20,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+T0 = time.perf_counter()
+
+
+def note(stage):
+    """One dated line per stage on stderr: when the caller's timeout fires, its tail says where the time went."""
+    sys.stderr.write("[sharded_c_abi %7.2f s] %s\n" % (time.perf_counter() - T0, stage))
+    sys.stderr.flush()
+
+
 def main():
+    dump_after = float(os.environ.get("HS_SHARDED_DUMP_AFTER_S", "0"))
+    if dump_after > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(dump_after, exit=False)      # every thread's Python stack, once, if still running then
     ngpus = int(sys.argv[1])
     validators = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
@@ -28,7 +41,9 @@ def main():
     from hotstuff_amd import _lib
     ndev = int(sys.argv[4]) if len(sys.argv) > 4 else ngpus
     n = 2 * validators // 3 + 1
+    note("init_devices %r" % [s % ndev for s in range(ngpus)])
     _lib.init_devices([s % ndev for s in range(ngpus)], 8192)
+    note("signing %d signatures on the GPU" % n)
     lib = _lib.lib()
     # the synthetic QC is signed on the GPU (hs_ed25519_public_keys / hs_ed25519_sign_batch): milliseconds instead of seconds
     seeds = b"".join(synth.key_seed(9_000_000 + i) for i in range(n))
@@ -43,6 +58,7 @@ def main():
            "signatures_per_shard": _lib.shard_plan(n, ngpus, 0)[1]}
     for name, how in (("host_exchange", _lib.EXCHANGE_HOST), ("rccl_all_gather", _lib.EXCHANGE_RCCL)):
         try:
+            note("sharded QC, exchange = %s" % name)
             lib.hs_ed25519_set_shard_exchange(how)
             for mode_name, mode in (("per_signature", _lib.BATCH), ("rlc_msm", _lib.BATCH_RLC)):
                 times = []
@@ -78,6 +94,7 @@ def main():
         vix = struct.pack("<%dI" % nq, *voters)
         for pname, placement in (("replicate", _lib.KEYS_REPLICATE), ("by_owner", _lib.KEYS_BY_OWNER)):
             try:
+                note("key sets on every GPU: %s, %d keys" % (pname, nv))
                 t0 = time.perf_counter()
                 kss = _lib.ShardedKeySet(committee, placement)
                 build_ms = (time.perf_counter() - t0) * 1e3
@@ -101,6 +118,7 @@ def main():
         out["key_cache"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # one corrupted signature must be localised across the shards
     try:
+        note("localisation check")
         lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
         victim = n - 5
         s2 = bytearray(sg); s2[64 * victim + 40] ^= 1
@@ -124,6 +142,7 @@ def main():
         aa = [ctypes.addressof(x) for x in bb]
         rows = []
         for th, k in ((16, 2), (16, 2 * ngpus), (16, 4 * ngpus)):
+            note("small batches over every GPU: %d threads x %d tickets" % (th, k))
             cv, pv, ev = _lib.loadgen(None, aa[0], 32, aa[1], aa[2], bn, nb, _lib.STRICT, th, k, 2, 1.0)
             rows.append({"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": 2, "call_p50_ms": round(pv, 4),
                          "verifies_per_s": round(cv * bn / ev, 1)})
@@ -132,7 +151,9 @@ def main():
         out["small_batches_all_gpus"] = {"signatures_per_call": bn, "api": "hs_ed25519_submit bursts of two + hs_ed25519_ticket_wait", "rows": rows}
     except Exception as e:
         out["small_batches_all_gpus"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    note("shutdown")
     _lib.shutdown()
+    note("done")
     print(json.dumps(out))
 
 
