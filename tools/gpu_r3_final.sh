@@ -60,7 +60,7 @@ print('sharded_committee', json.dumps(j.get('sharded_committee'))[:700])
 print('sharded_c_abi', json.dumps(j.get('sharded_c_abi'))[:1600])
 "
 echo "== rehearsal: 1 rank, forced exchange (RCCL one rank)"; HS_BENCH_FORCE_EXCHANGE=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-qc --no-cached --large-committee 20000 > $O/r3_bench_force_exchange.json.txt 2> $O/r3_bench_force_exchange.err; echo "rc=$?"
-if [ -z "$HS_FINAL_LITE" ]; then echo "== sweeps"; timeout 1200 python tools/r2_sweeps.py > $O/r3_sweeps.md 2> $O/r3_sweeps.err; echo "rc=$?"; cat $O/r3_sweeps.md; fi
-echo "== tail rows"; HS_SWEEP_SIZES=65536,66667,67584,69632 timeout 300 python tools/r2_sweeps.py 2>/dev/null | grep -E "^\| [0-9]" | tee $O/r3_tail_rows.md
+if [[ "$HS_FINAL_SKIP" != *sweeps* ]]; then echo "== sweeps"; timeout 1200 python tools/r2_sweeps.py > $O/r3_sweeps.md 2> $O/r3_sweeps.err; echo "rc=$?"; cat $O/r3_sweeps.md; fi
+echo "== tail rows"; HS_SWEEP_SIZES=65536,66667,67584,69632,81920,98304 timeout 300 python tools/r2_sweeps.py 2>/dev/null | grep -E "^\| [0-9]" | tee $O/r3_tail_rows.md
 echo "== streamed 10 s"; timeout 120 python tools/streamed_10s.py > $O/r3_streamed_10s.md 2>/dev/null; tail -6 $O/r3_streamed_10s.md
-if [ -z "$HS_FINAL_LITE" ]; then echo "== full GPU suite"; timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "rc=$?"; grep -E " passed| failed" $O/pytest_gpu.txt | tail -2; fi
+if [[ "$HS_FINAL_SKIP" != *suite* ]]; then echo "== full GPU suite"; timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "rc=$?"; grep -E " passed| failed" $O/pytest_gpu.txt | tail -2; fi
