@@ -113,6 +113,19 @@ def test_batches_per_launch_kernel_policy():
     assert names == ["k_verify_fused8"] + ["k_verify_fused_batches"] * 2 + ["k_verify_fused_pairs_batches"] * 2 + ["k_verify_batches"] * 2
 
 
+def test_single_batch_kernel_policy_by_size():
+    """hs_ed25519_dominant_kernel_for (what to look for in a rocprofv3 trace) follows enqueue_cold's choice for a context's lone
+    call on a 256-CU device: eight lanes per signature up to 8,192 signatures, four lanes with 4-bit windows up to 16,384, with
+    3-bit windows up to 32,768, the one-lane pair above - with the sliver past whole rounds of 1,024 wavefronts (up to 16,384
+    signatures) inside the stage-2 launch."""
+    f = lambda n: _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
+    expect = {1: "k_verify_fused8", 8192: "k_verify_fused8", 8193: "k_verify_fused", 16384: "k_verify_fused",
+              16385: "k_verify_fused3", 32768: "k_verify_fused3", 32769: "k_verify", 65536: "k_verify",
+              65537: "k_verify_tail", 66667: "k_verify_tail", 65536 + 16384: "k_verify_tail", 65536 + 16385: "k_verify",
+              131072: "k_verify", 131072 + 100: "k_verify_tail"}
+    assert {n: f(n) for n in expect} == expect
+
+
 def test_code_object_has_no_reversed_subtract_with_dpp():
     """gfx950 applies the lane permutation of v_subrev_u32_dpp to the wrong operand
     (tools/dpp_subrev_check.hip, profiles/r1_dpp_subrev.txt) and LLVM's DPP combiner emits that
