@@ -1090,10 +1090,10 @@ def main():
         if world == 1 and not args.no_cached:
             out["committee_cached"] = cached
         if world == 1 and not args.no_qc:
-            # streamed_rounds first: the ring (and its 5 GB key set) built right after the process's FIRST wide pool context
-            # runs ~25 % slower until the pools are torn down - once per process, whatever the number of calls, in the
-            # round-2 tree too (tools/streamed_probe.py bisect, profiles/r3_streamed_probe.txt): an allocation-order effect,
-            # not the ring's steady state
+            # streamed_rounds first: a ring (and its 5 GB key set) built while the process's first extra context of QC size is
+            # alive - the wide pool context qc_latency creates - runs ~25 % slower until that context goes (DESIGN.md 8.2,
+            # tools/streamed_probe.py, profiles/r3_streamed_probe.txt; the round-2 tree behaves identically): a coupling in the
+            # runtime, not the ring's steady state
             for key, fn in (("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
                             ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),

@@ -76,3 +76,73 @@ if which == "bisect":
     fresh(); host_calls(6667, 30, api="device"); show("device API x30 (context closed after)")
     fresh(); host_calls(9000, 30); show("host API x30 of 9,000 (four-lane kernel, copy engines)")
     fresh(); show("fresh again")
+if which == "alive":
+    # is it a LIVE extra context (stream + buffers) that slows the ring built after it, or something the host-pointer path does?
+    import ctypes
+    n = 6667
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    dev = torch.device("cuda", 0)
+    t = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (dg, pk, sg)]
+    out = torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev)
+    ctx = _lib.DeviceContext(n)
+    for i in range(3):
+        ctx.verify(t[0].data_ptr(), 0, t[1].data_ptr(), t[2].data_ptr(), n, _lib.BATCH, out.data_ptr(), 0, 0)
+        torch.cuda.synchronize()
+    show("a device-API context of 6,667 ALIVE (3 calls made)")
+    ctx.close()
+    show("after closing it")
+    pb = [_lib.PinnedBuffer(x) for x in (dg, pk, sg)]
+    for i in range(3):
+        assert _lib.lib().hs_ed25519_verify_shared(pb[0].addr, pb[1].addr, pb[2].addr, n, _lib.BATCH, None) == 1
+    show("after 3 host-pointer calls from CALLER-PINNED buffers (wide pool context alive, no staging copy)")
+    _lib.shutdown(); _lib.init(0, 1024)
+    show("after shutdown + init")
+    b = [ctypes.create_string_buffer(x, len(x)) for x in (dg, pk, sg)]
+    for i in range(3):
+        assert _lib.lib().hs_ed25519_verify_shared(ctypes.addressof(b[0]), ctypes.addressof(b[1]), ctypes.addressof(b[2]), n, _lib.BATCH, None) == 1
+    show("after 3 host-pointer calls from ordinary buffers (second wide context of the process)")
+if which == "regions":
+    # does the key-cache kernel's rate depend on WHICH memory a key set landed in?  Two sets alive at once, then a third after a small
+    # allocation took a piece of the first one's freed region.  Device-resident, four contexts in flight, 6,667-signature calls.
+    n = 6667
+    dev = torch.device("cuda", 0)
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)] + [synth.key_seed(20_000_000 + i) for i in range(3333)]
+    t = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (dg, sg)]
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+
+    def rate(ks, tag, nctx=4, reps=60):
+        ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+        bms = [torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev) for _ in range(nctx)]
+        sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        torch.cuda.synchronize(dev)
+        def call(j):
+            ctxs[j].verify_cached(ks, t[0].data_ptr(), 0, d_ki.data_ptr(), t[1].data_ptr(), n, _lib.BATCH, bms[j].data_ptr(), 0, 0)
+        for j in range(nctx):
+            call(j)
+        for s in sts:
+            s.synchronize()
+        lat = []
+        for i in range(30):
+            t0 = time.perf_counter(); call(0); sts[0].synchronize(); lat.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            for j in range(nctx):
+                call(j)
+        for s in sts:
+            s.synchronize()
+        wall = time.perf_counter() - t0
+        for c in ctxs:
+            c.close()
+        lat.sort()
+        print("%-70s p50 %.4f ms, %.1f M sig/s with four in flight" % (tag, lat[15] * 1e3, reps * nctx * n / wall / 1e6), flush=True)
+
+    ks_a = _lib.KeySet(keys); rate(ks_a, "set A (first 5.3 GB allocation of its kind)")
+    ks_b = _lib.KeySet(keys); rate(ks_b, "set B, A still alive"); rate(ks_a, "set A again")
+    ks_a.close()
+    small = _lib.DeviceContext(6667)
+    ks_c = _lib.KeySet(keys); rate(ks_c, "set C: A freed, a small context allocated, then C"); rate(ks_b, "set B again")
+    ks_c.close(); small.close()
+    ks_d = _lib.KeySet(keys); rate(ks_d, "set D: C and the small context freed, then D")
+    ks_d.close(); ks_b.close()
+    show("rings after all that")
