@@ -304,9 +304,9 @@ int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
 /* Latency form or throughput form.  By default a context assumes its call has the GPU to itself (the reference's
  * node verifies one certificate at a time: consensus/src/core.rs:379 -> messages.rs:197) and picks the forms with the
  * shortest time for ONE call: eight lanes per signature up to 8,192 signatures, and - above 65,536 - the sliver past
- * whole rounds of wavefronts on a side stream.  Both cost throughput when several whole-chip calls run at once
- * (profiles/r3_oct_ab.txt, r3_concurrent_ab.txt).  A caller that keeps several contexts busy says so here
- * (concurrent != 0) and gets four lanes per signature and no side stream; the verdicts are the same.  The library
+ * whole rounds of wavefronts as four-lane workgroups inside the second launch.  Both cost throughput when several
+ * whole-chip calls run at once (profiles/r3_oct_ab.txt, r3_concurrent_ab.txt).  A caller that keeps several contexts
+ * busy says so here (concurrent != 0) and gets four lanes per signature and no sliver; the verdicts are the same.  The library
  * sets it by itself where it knows: the slots of a round ring, and host-pointer calls that find another large call
  * of the same device in flight.  Returns the previous setting (0 / 1) or HS_ED25519_E_ARG. */
 int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *ctx, int concurrent);
