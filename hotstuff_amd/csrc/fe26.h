@@ -230,7 +230,14 @@ HS_HD void fe_sq(fe &r, const fe &f) {
     for (int i = 0; i < 10; i++) {
         HS_CHECK((u64)19 * f.v[i] < (1ull << 32), "fe_sq: 19*f does not fit 32 bits");
         HS_CHECK(!(i & 1) || (u64)38 * f.v[i] < (1ull << 32), "fe_sq: 38*f (odd limb) does not fit 32 bits");
-        f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i];
+        f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // 38 f as a shift of 19 f: left to itself the compiler multiplies again (v_mul_lo_u32 issues at 4.8 cycles per
+        // wavefront instruction, a plain shift at 2.5 - profiles/r1_ubench_valu.txt); only limbs 5, 7, 9 are ever used
+        if (i & 1) asm("v_lshlrev_b32 %0, 1, %1" : "=v"(f38[i]) : "v"(f19[i])); else f38[i] = 0;
+#else
+        f38[i] = 38u * f.v[i];
+#endif
     }
 #if HS_FE_SERIAL_CARRY
     u64 acc = 0;                               // carry into the next column

@@ -35,12 +35,14 @@ HS_HD void ge_identity(ge_p3 &r) { fe_0(r.X); fe_1(r.Y); fe_1(r.Z); fe_0(r.T); }
 
 // completed -> extended.  Operand bounds (fe26.h): from ge_dbl X 3x, Y 1x, Z 1x, T 4x;
 // from ge_add/ge_madd X 3x, Y 2x, Z and T 2x or 3x.  T is always the first (<=4x) operand.
+// Only X and Z ever stand second: a multiplication pre-scales its SECOND operand by 19 (nine v_mul_lo_u32) and the odd limbs
+// of its first by 2, and the compiler shares those between the products of one call - two pre-scaled operands instead of three.
 HS_HD void ge_p1p1_to_p3(ge_p3 &r, const ge_p1p1 &p, bool want_t) {
     fe x, y, z;
     fe_mul(x, p.T, p.X);
-    fe_mul(y, p.Z, p.Y);
+    fe_mul(y, p.Y, p.Z);
     fe_mul(z, p.T, p.Z);
-    if (want_t) fe_mul(r.T, p.X, p.Y);
+    if (want_t) fe_mul(r.T, p.Y, p.X);
     r.X = x; r.Y = y; r.Z = z;
 }
 
