@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <vector>
+#include <chrono>
 #include "engine.h"
 
 using namespace hs;
@@ -31,11 +32,14 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
+static const std::chrono::milliseconds kPoolPatience(50);      // two orders of magnitude above a call's duration
 int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     const int k = n <= kPartitionMaxBatch ? 1 : 0;
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
+    bool waiting = false;
+    std::chrono::steady_clock::time_point deadline;
     for (;;) {
         if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
         dev_state &d = g_devs[slot];
@@ -63,7 +67,15 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
             return 0;
         }
         if (nowait) return HS_ED25519_E_BUSY;       // not an error worth a message: the caller retries after a wait
-        g_cv.wait(lk);
+        // A synchronous call waits for a context to come back - but not for ever: the contexts may all be out as tickets
+        // the CALLING thread has not collected yet (four large ones are enough), and then nobody else will ever return one.
+        // After kPoolPatience without a context of its pool the call runs on one context over the cap; pool_put
+        // destroys it instead of pooling it (tests/test_gpu_tickets.py: a thread holding every wide context, then verifying).
+        if (!waiting) { waiting = true; deadline = std::chrono::steady_clock::now() + kPoolPatience; }
+        if (g_cv.wait_until(lk, deadline) == std::cv_status::timeout) {          // (other pools' returns wake it too: one deadline per call)
+            if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
+            if (g_devs[slot].free_ctx[k].empty()) { g_devs[slot].live[k]++; break; }
+        }
     }
     const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
     const bool others_busy = k == 0 && g_devs[slot].live[0] - (int)g_devs[slot].free_ctx[0].size() > 1;
@@ -91,8 +103,15 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
 void hs::pool_put(hs_ed25519_ctx *c) {
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
+    const int k = c->narrow ? 1 : 0;
     if (c->narrow && g_devs[c->slot].part_busy[c->part % 64]) g_devs[c->slot].part_busy[c->part % 64]--;
-    g_devs[c->slot].free_ctx[c->narrow ? 1 : 0].push_back(c);
+    if (g_devs[c->slot].live[k] > kMaxPool[k]) {        // a context over the cap (pool_get's patience ran out): not kept
+        g_devs[c->slot].live[k]--;
+        lk.unlock();
+        hs_ed25519_ctx_destroy(c);
+        return;
+    }
+    g_devs[c->slot].free_ctx[k].push_back(c);
     g_cv.notify_all();
 }
 

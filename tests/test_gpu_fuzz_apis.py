@@ -67,9 +67,10 @@ def _corrupt(rng, dg, pk, sg, n, shared, rate, allow_key):
             sg[64 * i + rng.randrange(64)] ^= bit
 
 
-def test_random_walk_over_the_entry_points(oracle, world):
+@pytest.mark.parametrize("seed", [20260921, 31])       # 31: the walk that holds every wide context as uncollected tickets and then calls synchronously
+def test_random_walk_over_the_entry_points(oracle, world, seed):
     keys, secrets, ks, runners = world
-    rng = random.Random(int(os.environ.get("HS_FUZZ_SEED", "20260921")))      # HS_FUZZ_SEED / HS_FUZZ_STEPS: longer one-off walks
+    rng = random.Random(int(os.environ.get("HS_FUZZ_SEED", seed)))      # HS_FUZZ_SEED / HS_FUZZ_STEPS: longer one-off walks
     pending = []                                    # tickets of an open burst: (ticket, want, n)
     counts = {}
 
@@ -126,4 +127,5 @@ def test_random_walk_over_the_entry_points(oracle, world):
                 got = r.bits(dg, pk, sg, n, mode if api in ("dev_auto", "dev_rlc") else law, shared)
             assert got == want, (it, api, n, mode)
     collect_all()
-    assert len(counts) == 9 and min(counts.values()) >= 8, counts
+    if seed == 20260921 and "HS_FUZZ_SEED" not in os.environ and "HS_FUZZ_STEPS" not in os.environ:
+        assert len(counts) == 9 and min(counts.values()) >= 8, counts

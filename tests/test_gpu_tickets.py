@@ -153,3 +153,31 @@ def test_tickets_from_many_threads(oracle):
         t.join(120)
     assert not any(t.is_alive() for t in th), "deadlock"
     assert not errors, errors[:3]
+
+
+def test_a_thread_holding_every_wide_context_can_still_call_synchronously(oracle):
+    """Four large tickets out and not collected = every wide pool context held by THIS thread.  A synchronous call (or a batch
+    signing, or another large ticket's wait) must not wait for ever for a context only the caller itself could return: after a
+    bounded wait the pool lends one context over its cap.  (Found by a seeded walk of tests/test_gpu_fuzz_apis.py, seed 31.)"""
+    import time
+    n = 2000
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    want = bytes(oracle_verify_many(oracle, dg, 0, pk, sg, n, _lib.BATCH))
+    held = []
+    while True:                                  # take wide contexts until the pool says busy
+        try:
+            held.append(_lib.Ticket(dg, pk, sg, n, mode=_lib.BATCH, shared=True))
+        except _lib.PoolBusy:
+            break
+        assert len(held) <= 8
+    assert len(held) >= 1
+    t0 = time.perf_counter()
+    ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)        # used to block for ever
+    assert ok and bits(bm, n) == want and time.perf_counter() - t0 < 2.0
+    seeds = b"".join(synth.key_seed(i) for i in range(1500))
+    assert len(_lib.public_keys(seeds, 1500)) == 32 * 1500                                        # so did this (a wide context too)
+    for t in held:
+        ok, bm = t.wait()
+        assert ok and bits(bm, n) == want
+    ok, _ = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True)                            # and the pool is whole again
+    assert ok
