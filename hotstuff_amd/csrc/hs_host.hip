@@ -32,7 +32,9 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
-static const std::chrono::milliseconds kPoolPatience(50);      // two orders of magnitude above a call's duration
+// three orders of magnitude above a call's duration: ordinary contention (more synchronous callers than contexts) never gets
+// near it and behaves exactly as before - the pools stay at their caps, which is what keeps the streams within the 16 hardware queues
+static const std::chrono::milliseconds kPoolPatience(1000);
 int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     const int k = n <= kPartitionMaxBatch ? 1 : 0;
     std::unique_lock<std::mutex> lk(g_mu);

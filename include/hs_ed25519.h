@@ -399,8 +399,8 @@ int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out);
  * is free, submit returns HS_ED25519_E_BUSY WITHOUT blocking (a thread that holds every ticket itself
  * would otherwise deadlock) - wait on an outstanding ticket and retry.  Every ticket must be waited on.
  * The SYNCHRONOUS calls (verify_shared / _multi / _tc, sign_batch, public_keys ...) wait for a context instead - for at
- * most 50 ms: a thread may itself hold every context as uncollected tickets, and then runs on one context over the
- * pool's cap, which is destroyed afterwards.
+ * most one second: a thread may itself hold every context as uncollected tickets (collect them first), and then runs
+ * on one context over the pool's cap, which is destroyed afterwards.
  * flags: HS_ED25519_SUBMIT_MORE on every batch but the last of a burst lets calls of n <= 1,024 signatures share
  * one launch (the TCP_CORK idea): a 1,024-signature batch alone is one wavefront per SIMD of its CU slice, two per
  * launch reach the chip's full multiply-add issue rate.  Without the flag the call launches at once.  A batch

@@ -173,7 +173,7 @@ def test_a_thread_holding_every_wide_context_can_still_call_synchronously(oracle
     assert len(held) >= 1
     t0 = time.perf_counter()
     ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)        # used to block for ever
-    assert ok and bits(bm, n) == want and time.perf_counter() - t0 < 2.0
+    assert ok and bits(bm, n) == want and time.perf_counter() - t0 < 4.0      # the pool's patience is one second
     seeds = b"".join(synth.key_seed(i) for i in range(1500))
     assert len(_lib.public_keys(seeds, 1500)) == 32 * 1500                                        # so did this (a wide context too)
     for t in held:
