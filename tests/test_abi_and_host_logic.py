@@ -61,6 +61,15 @@ def test_no_gpu_means_loud_failure_never_success():
         TC(3, [(PublicKey(bytes([i]) * 32), Signature(), 1) for i in range(3)]).verify(c)
 
 
+def test_context_hints_reject_a_null_context():
+    """The per-context setters answer HS_ED25519_E_ARG on a null context (no GPU needed) - the concurrency hint included."""
+    lib = _lib.lib()
+    E_ARG = -3          # HS_ED25519_E_ARG (include/hs_ed25519.h)
+    assert lib.hs_ed25519_ctx_set_concurrent(None, 1) == E_ARG
+    assert lib.hs_ed25519_ctx_set_kernel(None, 0) == E_ARG
+    assert lib.hs_ed25519_ctx_set_rlc_min(None, 1) == E_ARG
+
+
 def _fixture(openssl_vectors):
     fx = openssl_vectors["reference_fixture"]
     keys = [PublicKey(H(k["pk"])) for k in fx["keys"]]
