@@ -146,3 +146,50 @@ if which == "regions":
     ks_d = _lib.KeySet(keys); rate(ks_d, "set D: C and the small context freed, then D")
     ks_d.close(); ks_b.close()
     show("rings after all that")
+if which == "coupling":
+    # NEXT PROBE (not run yet: the round's GPU budget was spent): what about an idle context slows other queues - its stream, or
+    # its buffers?  Key-cache kernel, device-resident, four contexts in flight (as in `regions`), one key set, with in turn:
+    # nothing extra / an idle torch stream / 24 MB of device buffers / pinned host memory / an idle engine context / that context
+    # after one call.  Run under GPU_MAX_HW_QUEUES=8, 16 (default), 24 to see whether the hardware-queue count matters.
+    n = 6667
+    dev = torch.device("cuda", 0)
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)] + [synth.key_seed(20_000_000 + i) for i in range(3333)]
+    t = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (dg, sg)]
+    tp = torch.frombuffer(bytearray(pk), dtype=torch.uint8).to(dev)
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+    ks = _lib.KeySet(keys)
+
+    def rate(tag, nctx=4, reps=60):
+        ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+        bms = [torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev) for _ in range(nctx)]
+        sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        torch.cuda.synchronize(dev)
+        def call(j):
+            ctxs[j].verify_cached(ks, t[0].data_ptr(), 0, d_ki.data_ptr(), t[1].data_ptr(), n, _lib.BATCH, bms[j].data_ptr(), 0, 0)
+        for j in range(nctx):
+            call(j)
+        for s in sts:
+            s.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            for j in range(nctx):
+                call(j)
+        for s in sts:
+            s.synchronize()
+        wall = time.perf_counter() - t0
+        for c in ctxs:
+            c.close()
+        print("%-64s %.1f M sig/s with four in flight" % (tag, reps * nctx * n / wall / 1e6), flush=True)
+
+    for rnd in range(2):
+        rate("nothing extra")
+        s_idle = torch.cuda.Stream(device=dev); rate("+ an idle torch stream"); del s_idle
+        buf = torch.empty(24 << 20, dtype=torch.uint8, device=dev); rate("+ 24 MB of device buffers, no stream"); del buf
+        pin = torch.empty(1 << 20, dtype=torch.uint8).pin_memory(); rate("+ 1 MB of pinned host memory"); del pin
+        c = _lib.DeviceContext(n); rate("+ an idle engine context of 6,667 signatures (never used)")
+        bm = torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev)
+        c.verify(t[0].data_ptr(), 0, tp.data_ptr(), t[1].data_ptr(), n, _lib.BATCH, bm.data_ptr(), 0, 0); torch.cuda.synchronize(dev)
+        rate("+ that context after one cold call"); c.close()
+        rate("nothing extra again")
+    ks.close()
