@@ -14,8 +14,16 @@ try:
     _tenants = max(1, min(8, int(os.environ.get("HS_ED25519_TENANTS", "1"))))
 except ValueError:
     _tenants = 1
+def hw_queue_budget(tenants):
+    """The value hs_ed25519_init_devices gives GPU_MAX_HW_QUEUES (hs_ed25519.hip: narrow pool + wide pool + 2, at most 16).
+    The runtime reads the variable at its first device call, which in a Python process is torch's - before the library's own
+    setenv can matter - so the wrapper sets it at import, from the SAME formula (the two used to differ)."""
+    t = max(1, min(8, int(tenants)))
+    return min(16, max(2, 16 // t) + max(1, 4 // t) + 2) if t > 1 else 16
+
+
 if os.environ.get("HS_ED25519_KEEP_ENV") != "1":
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if _tenants == 1 else str(max(4, 16 // _tenants + 2)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(hw_queue_budget(_tenants)))
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HS_ED25519_LIB") or os.path.join(_HERE, "libhs_ed25519.so")   # override: A/B measurements
@@ -202,6 +210,10 @@ def lib():
                 l.hs_ed25519_ring_wait.restype = ctypes.c_int
                 l.hs_ed25519_ring_stats.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
                 l.hs_ed25519_ring_stats.restype = ctypes.c_int
+                l.hs_ed25519_hw_queue_budget.argtypes = [ctypes.c_uint]
+                l.hs_ed25519_hw_queue_budget.restype = ctypes.c_uint
+                l.hs_ed25519_ring_slot_ctx.argtypes = [vp, ctypes.c_uint]
+                l.hs_ed25519_ring_slot_ctx.restype = vp
                 _lib = l
     return _lib
 
@@ -307,6 +319,10 @@ def loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, i
 
 
 def set_rlc_key(key):
+    """Pin the coefficient key of BATCH_RLC (reproducible runs); None = back to a fresh OS secret + per-call counters."""
+    if key is None:
+        check(lib().hs_ed25519_set_rlc_key(None), "hs_ed25519_set_rlc_key")
+        return
     buf, keep = _buf(key)
     check(lib().hs_ed25519_set_rlc_key(buf), "hs_ed25519_set_rlc_key")
 
@@ -746,6 +762,17 @@ class RoundRing:
         rc = check(lib().hs_ed25519_ring_wait(self._h, int(slot), ctypes.cast(bm, ctypes.c_void_p) if bm is not None else None),
                    "hs_ed25519_ring_wait")
         return rc == 1, (bytes(bm) if bm is not None else None)
+
+    def slot_ctx(self, slot):
+        """hs_ed25519_ring_slot_ctx: the slot's context, BORROWED (closing the returned object does nothing) - for the
+        per-context knobs and read-outs (set_rlc_min, rlc_last, set_concurrent) while the slot has nothing in flight."""
+        h = lib().hs_ed25519_ring_slot_ctx(self._h, int(slot))
+        if not h:
+            raise EngineError("hs_ed25519_ring_slot_ctx: " + last_error())
+        c = DeviceContext.__new__(DeviceContext)
+        c._h = ctypes.c_void_p(h)
+        c.close = lambda: None
+        return c
 
     def stats(self):
         """(graph captures / updates, rounds submitted)"""

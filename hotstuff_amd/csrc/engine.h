@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include "verify.h"
@@ -46,6 +47,8 @@ struct hs_ed25519_ctx {
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     unsigned part = 0;            // which slice (narrow pool contexts)
+    bool overflow = false;        // lent over the pool's cap (pool_get's escape from a self-deadlock): destroyed on return, never pooled
+    std::shared_ptr<std::atomic<int>> held;   // taken for a TICKET: the submitting thread's count of contexts it has out (pool_put drops it)
     size_t cap = 0;               // signatures
     hs::u32 *d_ws = nullptr;      // workspace of the two-kernel cold path
     uint8_t *d_in = nullptr;      // digests | keys | sigs   (host API only)

@@ -212,14 +212,19 @@ HS_HD bool mp_abs8(u32 out[8], const u32 *x) {
     return neg;
 }
 
-// The pair must be usable before it is trusted: v odd and non-zero, |u|, v < 2^253 (what the recodings take), and
-// u = v k modulo L and modulo 8 (together: modulo 8L).
+// The pair must be usable before it is trusted: v odd and 0 < v < L (so gcd(v, 8L) = 1: [v]D = O <=> D = O), |u| < 2^253
+// (what the recodings take), and u = v k modulo L and modulo 8 (together: modulo 8L).
+// v < L is not implied by the rest: (u, v) = (0, L) satisfies every congruence whenever k = 0 (mod 8) (L is odd, L k = 0 mod L,
+// L k = 5 k = 0 mod 8) and would turn the check into [L]R == O - accept for every torsion-free R.  It is where Euclid on
+// (8L, k) ends for such k; half_reduce stops 120 bits earlier and its cofactors hold 192 bits, so it never produced it, but this
+// predicate is the safety net and must not lean on that.
+static_assert(HS_HALF_COF_WORDS <= 7, "cofactors wider than 224 bits could reach L: keep v < L provable");
 HS_HD bool half_scalar_ok(const half_pair &h, const u32 k[8]) {
-    bool ok = (h.v[0] & 1) != 0 && (h.v[7] >> 29) == 0 && (h.u[7] >> 29) == 0;
+    const u32 Lw[8] = HS_L_WORDS;
+    bool ok = (h.v[0] & 1) != 0 && mp_less<8>(h.v, Lw) && (h.u[7] >> 29) == 0;
     u32 vk[8];
     sc_mul(vk, h.v, k);                                  // v k mod L
     // u mod L: |u| < 2^253 < 2 L ... reduce by one conditional subtraction, then negate modulo L when u < 0
-    const u32 Lw[8] = HS_L_WORDS;
     u32 um[8], t[8];
     mp_addsub<8>(t, h.u, Lw, true);
     const bool lt = mp_less<8>(h.u, Lw);

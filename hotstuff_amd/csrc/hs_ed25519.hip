@@ -881,6 +881,16 @@ static int build_base_tables(dev_state &d) {
     if (rc) free_base_tables(d);
     return rc;
 }
+// pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for (one per stream context
+// + 2 for the host's own streams, never more than the 16 beyond which in-flight queues collapse, profiles/r1_stream_sweep.txt)
+static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : ((int)(16 / tenants) < 2 ? 2 : (int)(16 / tenants)); }
+static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : ((int)(4 / tenants) < 1 ? 1 : (int)(4 / tenants)); }
+extern "C" unsigned hs_ed25519_hw_queue_budget(unsigned tenants) {
+    if (tenants < 1) tenants = 1;
+    if (tenants > 8) tenants = 8;
+    const int want = pool_narrow_for(tenants) + pool_wide_for(tenants) + 2;
+    return (unsigned)(want < 16 ? want : 16);
+}
 extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
     if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -902,14 +912,14 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (const char *e = getenv("HS_ED25519_TENANT_INDEX")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < kTenants) kTenantIndex = (unsigned)v; }
     kMaxPool[0] = 4; kMaxPool[1] = 16; kPoolPartitions = 8;
     if (kTenants > 1) {
-        kMaxPool[1] = (int)(16 / kTenants) < 2 ? 2 : (int)(16 / kTenants);
-        kMaxPool[0] = (int)(4 / kTenants) < 1 ? 1 : (int)(4 / kTenants);
+        kMaxPool[1] = pool_narrow_for(kTenants);
+        kMaxPool[0] = pool_wide_for(kTenants);
         kPoolPartitions = 8 / kTenants < 1 ? 1 : 8 / kTenants;
     }
     const char *keep = getenv("HS_ED25519_KEEP_ENV");
     if (!(keep && keep[0] == '1')) {
         char q[8];
-        snprintf(q, sizeof q, "%d", kMaxPool[0] + kMaxPool[1] < 16 ? kMaxPool[0] + kMaxPool[1] + 2 : 16);
+        snprintf(q, sizeof q, "%u", hs_ed25519_hw_queue_budget(kTenants));
         setenv("GPU_MAX_HW_QUEUES", q, 0);
     }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }

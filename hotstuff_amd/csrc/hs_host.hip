@@ -32,15 +32,26 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
     for (size_t i = 64 * words; i < n; i++) if (!((bm[i >> 3] >> (i & 7)) & 1)) return false;
     return true;
 }
-// three orders of magnitude above a call's duration: ordinary contention (more synchronous callers than contexts) never gets
-// near it and behaves exactly as before - the pools stay at their caps, which is what keeps the streams within the 16 hardware queues
+// How long a synchronous call waits for a context of its pool before it asks whether waiting can end at all: three orders
+// of magnitude above a call's duration, so ordinary contention (more synchronous callers than contexts) never gets near it
+// and the pools stay at their caps - which is what keeps the streams within the 16 hardware queues.
 static const std::chrono::milliseconds kPoolPatience(1000);
+// Contexts this thread has out as TICKETS (hs_ed25519_submit), per pool.  Counted on the context, not on the ticket: a ticket
+// may be collected by another thread, and the count must follow the context back to the pool wherever that happens - hence
+// a shared counter that outlives the thread.
+namespace {
+struct held_counts {
+    std::shared_ptr<std::atomic<int>> n[2];
+    held_counts() { n[0] = std::make_shared<std::atomic<int>>(0); n[1] = std::make_shared<std::atomic<int>>(0); }
+};
+thread_local held_counts t_held;
+}
 int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     const int k = n <= kPartitionMaxBatch ? 1 : 0;
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "no such device slot");
-    bool waiting = false;
+    bool waiting = false, overflow = false;
     std::chrono::steady_clock::time_point deadline;
     for (;;) {
         if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
@@ -65,18 +76,27 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
             if (k == 1) d.part_busy[c->part % 64]++;
             // a whole-chip call that finds another one in flight on its device runs the throughput forms (enqueue_cold)
             else c->several_in_flight = d.live[0] - (int)d.free_ctx[0].size() > 1;
+            if (nowait) { c->held = t_held.n[k]; c->held->fetch_add(1, std::memory_order_relaxed); }
             *out = c;
             return 0;
         }
         if (nowait) return HS_ED25519_E_BUSY;       // not an error worth a message: the caller retries after a wait
-        // A synchronous call waits for a context to come back - but not for ever: the contexts may all be out as tickets
-        // the CALLING thread has not collected yet (four large ones are enough), and then nobody else will ever return one.
-        // After kPoolPatience without a context of its pool the call runs on one context over the cap; pool_put
-        // destroys it instead of pooling it (tests/test_gpu_tickets.py: a thread holding every wide context, then verifying).
+        // A synchronous call waits for a context to come back.  Whoever holds them will return them - unless that is the
+        // CALLING thread itself: contexts it has out as tickets it has not collected yet (four large ones are enough) come
+        // back only after this call returns.  So: after kPoolPatience without a context, a caller that HOLDS contexts of this
+        // pool is lent one over the cap (marked `overflow`: pool_put destroys exactly that one, so the pool and its CU slices
+        // stay as they were); a caller that holds none keeps waiting, as it always did - under genuine saturation by other
+        // threads' long calls the pools must not grow past the hardware-queue budget (the
+        // escape used to fire for ANY caller after one second, without bound).  At most one overflow context per calling
+        // thread exists at a time: the call that got it returns it before the thread can make another.
+        // tests/test_gpu_tickets.py: a thread holding every wide context, then verifying; other threads waiting meanwhile.
         if (!waiting) { waiting = true; deadline = std::chrono::steady_clock::now() + kPoolPatience; }
-        if (g_cv.wait_until(lk, deadline) == std::cv_status::timeout) {          // (other pools' returns wake it too: one deadline per call)
+        if (g_cv.wait_until(lk, deadline) == std::cv_status::timeout) {          // (other pools' returns wake it too: one deadline per wait)
             if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
-            if (g_devs[slot].free_ctx[k].empty()) { g_devs[slot].live[k]++; break; }
+            if (g_devs[slot].free_ctx[k].empty()) {
+                if (t_held.n[k]->load(std::memory_order_relaxed) > 0) { g_devs[slot].live[k]++; overflow = true; break; }
+                waiting = false;                     // others hold them: wait on
+            }
         }
     }
     const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
@@ -97,17 +117,20 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }
     c->narrow = k == 1;
     c->part = part;
+    c->overflow = overflow;
     c->several_in_flight = others_busy;
+    if (nowait) { c->held = t_held.n[k]; c->held->fetch_add(1, std::memory_order_relaxed); }
     if (k == 1) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].part_busy[part % 64]++; lk.unlock(); }
     *out = c;
     return 0;
 }
 void hs::pool_put(hs_ed25519_ctx *c) {
+    if (c->held) { c->held->fetch_sub(1, std::memory_order_relaxed); c->held.reset(); }
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
     const int k = c->narrow ? 1 : 0;
     if (c->narrow && g_devs[c->slot].part_busy[c->part % 64]) g_devs[c->slot].part_busy[c->part % 64]--;
-    if (g_devs[c->slot].live[k] > kMaxPool[k]) {        // a context over the cap (pool_get's patience ran out): not kept
+    if (c->overflow) {                                  // lent over the cap: exactly this one goes, the pool keeps its own
         g_devs[c->slot].live[k]--;
         lk.unlock();
         hs_ed25519_ctx_destroy(c);
@@ -681,6 +704,11 @@ extern "C" int hs_ed25519_ring_wait(hs_ed25519_ring *r, unsigned slot, uint8_t *
     if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "ring stream sync", e);
     if (bitmap) memcpy(bitmap, s.ctx->h_out, (s.n + 7) / 8);
     return bitmap_all_ones(s.ctx->h_out, s.n) ? 1 : 0;
+}
+
+extern "C" hs_ed25519_ctx *hs_ed25519_ring_slot_ctx(hs_ed25519_ring *r, unsigned slot) {
+    if (!r || slot >= r->slots.size()) { (void)fail(HS_ED25519_E_ARG, "ring_slot_ctx: bad arguments"); return nullptr; }
+    return r->slots[slot].ctx;
 }
 
 extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {

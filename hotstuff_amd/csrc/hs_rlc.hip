@@ -59,8 +59,14 @@ struct rlc_keys_src {            // where signature i's key bytes / curve flag c
 #define HS_RLC_PREPARE_WAVES 2
 #endif
 __global__ void __launch_bounds__(64, HS_RLC_PREPARE_WAVES)
-k_rlc_prepare(rlc_view v, rlc_key key, msg_src msgs, rlc_keys_src keys, const u32 *__restrict__ sigs, u32 n) {
+k_rlc_prepare(rlc_view v, rlc_key key, const u32 *__restrict__ epoch, msg_src msgs, rlc_keys_src keys,
+              const u32 *__restrict__ sigs, u32 n) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
+    // The coefficient key of THIS EXECUTION: the host mixed its call number into `key` at enqueue time, but a launch
+    // replayed from a captured graph (the round ring's GRAPH form) carries that by-value argument unchanged for ever.
+    // `epoch` is a 64-bit counter in the workspace that k_rlc_final bumps at the end of every execution, so a replay
+    // draws fresh coefficients too.  Null when the key is pinned (hs_ed25519_set_rlc_key: reproducible runs).
+    if (epoch) { key.w[4] ^= epoch[0]; key.w[5] ^= epoch[1]; }
     if (t == 0) rlc_store_identity_record(v.rec + (size_t)HS_RLC_REC_WORDS * 2 * v.np);
     u32 kind = t / v.np;                                     // np lanes per kind: whole wavefronts are of one kind
     const u32 i0 = t - kind * v.np;
@@ -346,11 +352,18 @@ k_rlc_reduce(const u32 *__restrict__ part, const u32 *__restrict__ segoff, u32 L
 }
 
 __global__ void __launch_bounds__(64)
-k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ failed, u32 *__restrict__ ok_flag) {
+k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ failed, u32 *__restrict__ ok_flag, u32 *__restrict__ epoch) {
     if (threadIdx.x >= 4) return;      // one quad
     const qflags f = rlc_final_quad(wsum);
     const bool all = q_quad_all(f);
-    if (threadIdx.x == 0) *ok_flag = (all && *failed == 0) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        *ok_flag = (all && *failed == 0) ? 1u : 0u;
+        if (epoch) {                   // the next execution on this workspace (a graph replay included) gets other coefficients
+            const u32 lo = epoch[0] + 1;
+            epoch[0] = lo;
+            if (lo == 0) epoch[1] += 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -359,7 +372,7 @@ struct rlc_ws {
     size_t np = 0;                 // capacity in (padded) signatures
     u32 *rec = nullptr; uint8_t *dig = nullptr; u32 *sorted = nullptr, *part = nullptr, *wsum = nullptr;
     u32 *tabs = nullptr;           // ghist | boff | segoff | gcur, each [32][129]
-    uint8_t *small = nullptr;      // failed (4) | ok (4) | pad to 64 | csum[HS_RLC_CSUM_SLOTS][8] (64 B each)
+    uint8_t *small = nullptr;      // failed (4) | ok (4) | pad to 64 | csum[HS_RLC_CSUM_SLOTS][8] (64 B each) | epoch (8, never cleared per call)
     size_t min_batch = 0;          // 0 = the library default
     size_t calls = 0;
 };
@@ -423,14 +436,15 @@ int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream) {
     HS_HIP(hipMalloc((void **)&w->part, (size_t)HS_RLC_WINDOWS * lane_cap(np, kMinChunk) * 160), "hipMalloc rlc partials");
     HS_HIP(hipMalloc((void **)&w->wsum, (size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS * 4), "hipMalloc rlc window sums");
     HS_HIP(hipMalloc((void **)&w->tabs, (size_t)4 * kTabWords * 4), "hipMalloc rlc offsets");
-    HS_HIP(hipMalloc((void **)&w->small, kSmallBytes), "hipMalloc rlc flags");
+    HS_HIP(hipMalloc((void **)&w->small, kSmallBytes + 64), "hipMalloc rlc flags");
+    HS_HIP(hipMemset(w->small + kSmallBytes, 0, 64), "rlc clear epoch");       // the execution counter starts at 0 and only k_rlc_final writes it
     w->np = np;
     return 0;
 }
 
 extern "C" int hs_ed25519_set_rlc_key(const uint8_t key[32]) {
-    if (!key) return fail(HS_ED25519_E_ARG, "set_rlc_key: null");
     std::lock_guard<std::mutex> lk(k_mu);
+    if (!key) { g_key_set = false; g_key_pinned = false; return 0; }      // unpin: a fresh secret at the next call
     memcpy(g_key.w, key, 32);
     g_key_set = true;
     g_key_pinned = true;           // pinned: the same coefficients on every call
@@ -442,8 +456,9 @@ extern "C" int hs_ed25519_set_rlc_key(const uint8_t key[32]) {
 // (ADVICE r2).  So unless the key was pinned with hs_ed25519_set_rlc_key (tests, reproducible runs), every call mixes its
 // own 64-bit sequence number into the process secret: z_i = SHA-512(secret ^ call || h_i || s_i || i) - a keyed PRF on a
 // never-repeating input, i.e. coefficients independent from call to call.
-static int current_key(rlc_key &out) {
+static int current_key(rlc_key &out, bool &pinned) {
     std::lock_guard<std::mutex> lk(k_mu);
+    pinned = g_key_pinned;
     if (!g_key_set) {              // dalek: thread_rng(); here 32 bytes from the OS, once per process
         FILE *f = fopen("/dev/urandom", "rb");
         const bool ok = f && fread(g_key.w, 1, 32, f) == 32;
@@ -497,7 +512,8 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     int rc = rlc_reserve(ctx, n, stream);
     if (rc) return rc;
     rlc_key key;
-    rc = current_key(key);
+    bool pinned = false;
+    rc = current_key(key, pinned);
     if (rc) return rc;
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -506,6 +522,7 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     rlc_view v;
     v.rec = w->rec; v.dig = w->dig; v.csum = (unsigned long long *)(w->small + 64); v.failed = (u32 *)w->small; v.np = np;
     u32 *ok_flag = (u32 *)(w->small + 4);
+    u32 *epoch = pinned ? nullptr : (u32 *)(w->small + kSmallBytes);
     u32 *ghist = w->tabs, *boff = w->tabs + kTabWords, *segoff = w->tabs + 2 * kTabWords, *gcur = w->tabs + 3 * kTabWords;
     HS_HIP(hipMemsetAsync(w->small, 0, kSmallBytes, st), "rlc clear flags");
     HS_HIP(hipMemsetAsync(ghist, 0, (size_t)kTabWords * 4, st), "rlc clear histograms");
@@ -517,7 +534,8 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     const u32 tasks = (ks ? 2u : 3u) * np;                  // np lanes per task kind (k_rlc_prepare)
     const uint8_t *p_dig = w->dig;
     {
-        void *a[] = { &v, &key, &msgs, &keys, &p_sg, (void *)&nn };
+        const u32 *p_epoch = epoch;
+        void *a[] = { &v, &key, &p_epoch, &msgs, &keys, &p_sg, (void *)&nn };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_prepare, dim3((tasks + 63) / 64), dim3(64), a, 0, st), "launch k_rlc_prepare");
     }
     {
@@ -547,7 +565,7 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     }
     {
         const u32 *p_wsum = w->wsum; const u32 *p_fail = v.failed;
-        void *a[] = { &p_wsum, &p_fail, &ok_flag };
+        void *a[] = { &p_wsum, &p_fail, &ok_flag, &epoch };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_final, dim3(1), dim3(64), a, 0, st), "launch k_rlc_final");
     }
     w->calls++;

@@ -134,10 +134,11 @@ class VoteIngest:
         qc = None
         if self._pend_count.get(vote.author, 0) >= self.per_author_cap:
             qc = self.flush()      # settle this author's waiting candidates before queueing another
+            if qc is not None or self.done:
+                return qc          # the flush completed the certificate: it MUST reach the caller (the certificate is
+                                   # made once; raising AuthorityReuse here instead lost it - ADVICE r3)
             if vote.author in self.used:
                 raise AuthorityReuse(vote.author)   # one of them verified: this vote is late, as in the reference
-            if qc is not None or self.done:
-                return qc
         self._pending_keys.add(key)
         self.pending.append(vote)
         c = self._pend_count.get(vote.author, 0)

@@ -474,8 +474,9 @@ struct VoteIngest {
         if (it != pend_count.end() && it->second >= per_author_cap) {
             Outcome o = flush();                           // settle this author's waiting candidates before queueing another
             if (!o.status.is_ok()) return o;
-            if (used.count(v.author)) return {ConsensusResult::Err(ConsensusError::AuthorityReuse, v.author), std::move(o.qc)};
-            if (o.qc || done) return o;
+            if (o.qc || done) return o;                    // the flush completed the certificate: hand it over with Ok, never
+                                                           // beside an error a caller may stop at
+            if (used.count(v.author)) return {ConsensusResult::Err(ConsensusError::AuthorityReuse, v.author), nullptr};
         }
         pending.push_back(v);
         if (pend_count[v.author]++ == 0) pend_weight += committee.stake(v.author);

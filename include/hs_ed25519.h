@@ -99,6 +99,10 @@ void hs_ed25519_shutdown(void);
  * identical with or without it.  hs_ed25519_init exports GPU_MAX_HW_QUEUES (one hardware queue per stream
  * context) unless the host already set it or HS_ED25519_KEEP_ENV=1 forbids touching the environment. */
 int hs_ed25519_set_tenancy(unsigned tenants, unsigned index);
+/* The GPU_MAX_HW_QUEUES value hs_ed25519_init exports for a process that is one of `tenants` (1..8) on its GPU:
+ * one hardware queue per pool context + 2, at most 16.  Pure function, no device needed - a host whose runtime is
+ * initialised before this library (PyTorch, hotstuff_amd/_lib.py) sets the variable itself from it. */
+unsigned hs_ed25519_hw_queue_budget(unsigned tenants);
 /* Caller-owned pinned buffers.  Memory from hs_ed25519_host_alloc is page-locked and mapped on every device
  * slot; a host-pointer call (synchronous, submit, sharded) whose digests, keys and signatures all lie in such
  * memory (16-byte aligned; key indices 4-byte) is NOT staged - the kernels read it in place over PCIe - so the
@@ -113,8 +117,10 @@ void hs_ed25519_host_free(void *p);
  * crossover (`small_batch_crossover`); env HS_ED25519_MIN_GPU_BATCH overrides. */
 size_t hs_ed25519_min_gpu_batch(int keys_registered);
 /* HS_ED25519_BATCH_RLC draws its 127-bit coefficients from SHA-512 keyed with a 32-byte secret taken
- * from the OS at first use, mixed with a per-call sequence number; this pins the key and switches the
- * sequence number off (tests, reproducible runs). */
+ * from the OS at first use, mixed with a per-call sequence number (host side, at enqueue) and a per-execution
+ * counter kept in the context's workspace on the device (so a round replayed from a captured hipGraph draws fresh
+ * coefficients as well); this pins the key and switches both counters off (tests, reproducible runs).
+ * key == NULL: back to the default - a fresh secret from the OS, counters on. */
 int hs_ed25519_set_rlc_key(const uint8_t key[32]);
 /* HS_ED25519_BATCH_RLC calls below this size run as plain HS_ED25519_BATCH (the five-stage MSM pipeline
  * only pays from a few thousand signatures up; profiles/r2_rlc_ab.md).  A context can override the
@@ -276,6 +282,10 @@ int hs_ed25519_ring_poll(hs_ed25519_ring *ring, unsigned slot);
 int hs_ed25519_ring_wait(hs_ed25519_ring *ring, unsigned slot, uint8_t *bitmap);
 /* Number of graph captures / updates and of rounds submitted so far. */
 int hs_ed25519_ring_stats(const hs_ed25519_ring *ring, size_t *graph_captures, size_t *launches);
+/* The context a slot runs on - BORROWED: it dies with the ring, never destroy it, and use it only while the slot
+ * has nothing in flight.  For the per-context knobs and read-outs (hs_ed25519_ctx_set_rlc_min,
+ * hs_ed25519_ctx_rlc_last, hs_ed25519_ctx_set_concurrent, hs_ed25519_ctx_set_kernel).  NULL on bad arguments. */
+hs_ed25519_ctx *hs_ed25519_ring_slot_ctx(hs_ed25519_ring *ring, unsigned slot);
 
 /* Profiling: keep a ring of `slots` HIP-event triples attached to the kernel dispatches of each
  * hs_ed25519_verify_device* call on `ctx` (hipExtLaunchKernel start/stop events, on the launch

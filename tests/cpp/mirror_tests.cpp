@@ -263,6 +263,29 @@ int main(int argc, char **argv) {
         CHECK("VoteIngest: a forgery stream is verified in groups, the honest last vote completes the QC",
               calls1 - calls0 == 2 && waited && !t0.qc && no_call_yet && ing.verify_calls == calls1 + 1 && last.qc && last.qc->votes.size() == 3);
     }
+    {
+        // the per-author cap's flush completes the certificate for the very author whose third vote triggered it:
+        // the QC must come back with Ok (it was returned beside AuthorityReuse, in Python it was lost altogether)
+        static double now2 = 0;
+        VoteIngest ing(committee);
+        ing.clock = +[]() { return now2; };
+        ing.max_wait_s = 1.0;
+        auto forged = [&](int i, uint8_t tag) { Vote f = vote(i); f.signature.part1[0] ^= 1; f.signature.part1[1] ^= tag; return f; };
+        ing.add_vote(vote(0)); ing.add_vote(vote(1));
+        ing.add_vote(forged(2, 1));                        // miss 1
+        ing.add_vote(forged(3, 1));                        // miss 2: groups of two
+        ing.add_vote(forged(2, 2)); ing.add_vote(forged(3, 2));   // miss 3: groups of four
+        const bool staged = ing.misses == 3 && ing.pending.empty() && ing.valid.size() == 2;
+        auto w0 = ing.add_vote(forged(2, 3));
+        auto w1 = ing.add_vote(vote(2));                   // the genuine vote waits beside the forgery
+        const bool waiting = !w0.qc && !w1.qc && ing.pending.size() == 2 && !ing.done;
+        auto o = ing.add_vote(forged(2, 4));               // cap reached -> flush -> quorum
+        CHECK("VoteIngest: a cap flush that completes the quorum returns the QC with Ok", staged && waiting && o.status.is_ok() && o.qc
+              && o.qc->votes.size() == 3 && ing.done && o.qc->verify(committee).is_ok());
+        const auto again = ing.add_vote(vote(2));
+        CHECK("VoteIngest: ... and the author counts as reused only afterwards", again.status.is_err()
+              && again.status.err.kind == ConsensusError::AuthorityReuse);
+    }
     // ---- Timeout::verify and the verified-QC cache (messages.rs:250-265, core.rs:227-238)
     {
         VerifiedQCCache cache;

@@ -78,6 +78,12 @@ int emu_half_scalar(const uint8_t *k32, uint8_t *u32_out, int *u_neg, uint8_t *v
     bool same = h.u_neg == 0; for (int i = 0; i < 8; i++) same = same && h.u[i] == k[i] && h.v[i] == (i == 0 ? 1u : 0u);
     return same ? 0 : 1;
 }
+// the predicate alone on a CHOSEN pair: 1 = half_scalar_ok would let (u, v) be used for k
+int emu_half_scalar_ok(const uint8_t *k32, const uint8_t *absu32, int u_neg, const uint8_t *v32) {
+    u32 k[8]; load_words(k, k32, 8);
+    half_pair h; load_words(h.u, absu32, 8); load_words(h.v, v32, 8); h.u_neg = u_neg ? 1u : 0u;
+    return half_scalar_ok(h, k) ? 1 : 0;
+}
 int emu_recode16_len(const uint8_t *x32) { u32 x[8], r[8]; load_words(x, x32, 8); sc_recode16(r, x); return sc_recode16_len(r); }
 int emu_sc_is_canonical(const uint8_t *s) { u32 w[8]; load_words(w, s, 8); return sc_is_canonical(w); }
 void emu_sc_digits8(const uint8_t *s, int16_t *digits) {

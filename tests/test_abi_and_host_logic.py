@@ -188,3 +188,14 @@ def test_tenancy_and_pinned_alloc_need_the_right_moment():
         assert lib.hs_ed25519_set_tenancy(4, 1) == 0 and lib.hs_ed25519_set_tenancy(1, 0) == 0     # before init: accepted
         assert not lib.hs_ed25519_host_alloc(4096)              # no engine, no pinned memory
         assert lib.hs_ed25519_shard_rccl_ranks() == 0
+
+
+def test_wrapper_and_library_agree_on_the_hardware_queue_budget():
+    """under tenancy the Python wrapper and the C init computed different GPU_MAX_HW_QUEUES values (10 against 12
+    for two tenants) and the wrapper's, set first, won.  One formula now, exported by the library and mirrored by the wrapper
+    (which must set the variable before torch initialises the runtime, i.e. before the library is even loaded)."""
+    lib = _lib.lib()
+    for t in range(1, 9):
+        assert _lib.hw_queue_budget(t) == lib.hs_ed25519_hw_queue_budget(t), t
+    assert [_lib.hw_queue_budget(t) for t in (1, 2, 4, 8)] == [16, 12, 7, 5]
+    assert lib.hs_ed25519_hw_queue_budget(0) == 16 and lib.hs_ed25519_hw_queue_budget(99) == 5      # clamped

@@ -68,7 +68,7 @@ def _run(tmp_path):
 def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
     assert torch.cuda.is_available()
     rc, cases = _run(tmp_path)
-    assert len(cases) == 47, cases
+    assert len(cases) == 49, cases
     assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
 
 

@@ -111,3 +111,51 @@ def test_small_calls_skip_the_pipeline():
     assert all(r.bits(dg, pk, sg, n, _lib.BATCH_RLC, True))
     assert r.ctx.rlc_last() == (_lib.RLC_NOT_RUN, 0)
     r.close()
+
+
+def test_coefficients_are_fresh_per_call_and_per_graph_replay(edge_vectors):
+    """dalek draws new coefficients for every verify_batch call, so on a class-(iii) input (torsion in A or R) its verdict
+    is an independent chance per call.  Here the key of an execution = process secret ^ host call number ^ a counter on the
+    device that every execution bumps - the last one because a round REPLAYED from a captured hipGraph carries the host's
+    by-value key unchanged (the ring's GRAPH form gave the same signature the same z_i for ever).  Observable
+    through the RLC stage's own verdict on a one-signature batch whose combination holds for one z in eight."""
+    import numpy as np
+    v = next(v for v in edge_vectors if v["name"].startswith("mixedorder:A k=0mod8"))
+    dg, pk, sg = H(v["msg"]), H(v["pk"]), H(v["sig"])
+    trials = 128                                      # P(no accept at 1/8 each) = 4e-8
+    _lib.set_rlc_key(None)                            # the default: OS secret + counters
+    try:
+        r = DeviceRunner(64, rlc_min=1)
+        stages = []
+        for _ in range(trials):
+            assert r.bits(dg, pk, sg, 1, _lib.BATCH_RLC, True)[0]             # the call's verdict: per-signature, always accept
+            stages.append(r.ctx.rlc_last()[0])
+        r.close()
+        assert set(stages) == {0, 1}, "device API: the RLC stage gave the same verdict on every call"
+        ring = _lib.RoundRing(64, slots=1, kind="graph")
+        ctx = ring.slot_ctx(0)
+        ctx.set_rlc_min(1)
+        stages = []
+        for _ in range(trials):
+            d, k, s = ring.begin(0, 1, shared=True)
+            d[:] = np.frombuffer(dg, np.uint8); k[:] = np.frombuffer(pk, np.uint8); s[:] = np.frombuffer(sg, np.uint8)
+            ring.submit(0, _lib.BATCH_RLC)
+            ok, bm = ring.wait(0)
+            assert ok and bm[0] & 1
+            stages.append(ctx.rlc_last()[0])
+        captures, launches = ring.stats()
+        assert captures == 1 and launches == trials   # one capture, 127 replays
+        assert set(stages) == {0, 1}, "graph replays: the RLC stage gave the same verdict on every replay"
+        # pinned key: the same verdict every time (reproducible runs), replayed or not
+        _lib.set_rlc_key(bytes(range(32)))
+        stages = []
+        for _ in range(16):
+            d, k, s = ring.begin(0, 1, shared=True)
+            d[:] = np.frombuffer(dg, np.uint8); k[:] = np.frombuffer(pk, np.uint8); s[:] = np.frombuffer(sg, np.uint8)
+            ring.submit(0, _lib.BATCH_RLC)
+            assert ring.wait(0)[0]
+            stages.append(ctx.rlc_last()[0])
+        assert len(set(stages)) == 1
+        ring.close()
+    finally:
+        _lib.set_rlc_key(bytes(range(32)))

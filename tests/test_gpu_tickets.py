@@ -181,3 +181,52 @@ def test_a_thread_holding_every_wide_context_can_still_call_synchronously(oracle
         assert ok and bits(bm, n) == want
     ok, _ = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True)                            # and the pool is whole again
     assert ok
+
+
+def test_a_caller_that_holds_nothing_waits_for_the_pool_instead_of_growing_it(oracle):
+    """The escape above is for a caller that waits on ITSELF.  A synchronous caller that holds no ticket waits for the holders
+    to return a context, however long that takes: under genuine saturation by other threads' long calls the pools must not
+    grow past the hardware-queue budget (the escape used to fire for any caller after one second).
+    Thread A takes every wide context as tickets and collects them after 2.5 s; thread B's synchronous call must return
+    only after that - and with the right verdict."""
+    import threading
+    import time
+    n = 2000
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    want = bytes(oracle_verify_many(oracle, dg, 0, pk, sg, n, _lib.BATCH))
+    state = {}
+    took, release = threading.Event(), threading.Event()
+
+    def holder():
+        held = []
+        while True:
+            try:
+                held.append(_lib.Ticket(dg, pk, sg, n, mode=_lib.BATCH, shared=True))
+            except _lib.PoolBusy:
+                break
+            if len(held) > 8:
+                break
+        state["held"] = len(held)
+        took.set()
+        release.wait(30)
+        state["released_at"] = time.perf_counter()
+        state["holder_ok"] = all(t.wait()[0] for t in held)
+
+    def caller():
+        took.wait(30)
+        t0 = time.perf_counter()
+        ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.BATCH, shared=True, want_bitmap=True)
+        state["caller_done_at"] = time.perf_counter()
+        state["caller_waited"] = state["caller_done_at"] - t0
+        state["caller_ok"] = ok and bits(bm, n) == want
+
+    a, b = threading.Thread(target=holder), threading.Thread(target=caller)
+    a.start(); b.start()
+    assert took.wait(30)
+    time.sleep(2.5)                                   # two and a half patience periods
+    assert b.is_alive(), "the caller got a context although every one was held by ANOTHER thread: the pool grew"
+    release.set()
+    a.join(60); b.join(60)
+    assert not a.is_alive() and not b.is_alive(), "deadlock"
+    assert 1 <= state["held"] <= 8 and state["holder_ok"] and state["caller_ok"]
+    assert state["caller_waited"] >= 2.4 and state["caller_done_at"] >= state["released_at"]

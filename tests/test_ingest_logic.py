@@ -190,3 +190,29 @@ def test_default_max_pending_is_finite(oracle):
     committee = Committee({v.author: 1 for v in votes})
     ing = VoteIngest(committee, verify_fn=oracle_fn(oracle))
     assert ing.max_pending == committee.size() + 64
+
+
+def test_cap_flush_that_completes_the_quorum_hands_the_certificate_over(oracle):
+    """while coalescing, the per-author cap's flush can complete the certificate - for the very
+    author whose extra vote triggered it.  add_vote then raised AuthorityReuse (the author had just become `used`) and the
+    QC was lost: done = True, every later add_vote / tick returned None, the round stalled until its timeout."""
+    votes = make_votes(7)
+    committee = Committee({v.author: 1 for v in votes})          # quorum 5
+    now = [0.0]
+    ing = VoteIngest(committee, verify_fn=oracle_fn(oracle), per_author_cap=2, clock=lambda: now[0], max_wait=1.0)
+    for v in votes[:4]:
+        assert ing.add_vote(v) is None
+    t = iter(range(1000))
+    assert ing.add_vote(_garbage(votes[4], next(t))) is None      # could complete, does not: miss 1
+    assert ing.add_vote(_garbage(votes[5], next(t))) is None      # miss 2: groups of 2 from here
+    assert ing.add_vote(_garbage(votes[4], next(t))) is None
+    assert ing.add_vote(_garbage(votes[5], next(t))) is None      # group of 2 verified: miss 3, groups of 4
+    assert ing._misses == 3 and ing.valid_weight == 4 and not ing.pending
+    assert ing.add_vote(_garbage(votes[6], next(t))) is None
+    assert ing.add_vote(votes[6]) is None                         # the genuine vote waits with the forgery (group of 4)
+    assert len(ing.pending) == 2 and not ing.done
+    qc = ing.add_vote(_garbage(votes[6], next(t)))                # third vote naming author 6: the cap's flush completes the QC
+    assert qc is not None and len(qc.votes) == 5 and ing.done
+    assert votes[6].author in [a for a, _ in qc.votes]
+    with pytest.raises(AuthorityReuse):
+        ing.add_vote(votes[6])                                    # and only now is the author "reused"
