@@ -168,6 +168,97 @@ def main():
     # ---- non-canonical y on R for a NON-small-order point cannot be built (needs y < 19 with
     # known dlog); covered by the small-order non-canonical forms above.
 
+
+    # ---- round 4: classes on which two verifiers this project did not write can referee the labels
+    # (tests/referees.py: libsodium == strict, OpenSSL == cofactorless wherever R's bytes are canonical)
+    canon_tors = [(t, E.compress(t)) for t in tors]
+    order = {}
+    for t, c in canon_tors:
+        o = 1
+        q = t
+        while not E.pt_is_identity(q):
+            q = E.pt_add(q, t); o += 1
+        order[c] = o
+    # (a) small-order A x every canonical small-order R, s = 0: everything is torsion, the equation reads [k]A + R == O.
+    #     Where R lies in the subgroup A generates a message with the right k mod ord(A) exists (cofactorless-valid, never
+    #     strict); where it does not, no message can help (cofactored-valid only: class iii).
+    for ta, ea in canon_tors:
+        for tr, er in canon_tors:
+            hit = None
+            for j in range(64):
+                m2 = H(b"edge-tors-pair" + ea + er, j)[:32]
+                k = E.sha512_modl(er, ea, m2)
+                if E.pt_is_identity(E.pt_add(E.pt_mul(k, ta), tr)):
+                    hit = m2
+                    break
+            tag = "ord%d x ord%d %s/%s" % (order[ea], order[er], ea.hex()[:6] + ea.hex()[-2:], er.hex()[:6] + er.hex()[-2:])
+            if hit is not None:
+                add("torsionpair:A,R small-order s=0 equation holds " + tag, "small-order-pair", hit, ea, er + le32(0))
+            else:
+                add("torsionpair:A,R small-order s=0 R outside <A> " + tag, "small-order-pair", H(b"edge-tors-pair-x" + ea + er)[:32],
+                    ea, er + le32(0))
+    # the same with a NON-canonical encoding of A (y + p; the hash sees these bytes) against canonical R
+    for kind, ea in enc:
+        if kind == "canon":
+            continue
+        ta = E.decompress(ea)
+        for tr, er in canon_tors[:4]:
+            hit = None
+            for j in range(64):
+                m2 = H(b"edge-tors-pair-nc" + ea + er, j)[:32]
+                if E.pt_is_identity(E.pt_add(E.pt_mul(E.sha512_modl(er, ea, m2), ta), tr)):
+                    hit = m2
+                    break
+            if hit is not None:
+                add("torsionpair:A=%s %s R canon %s s=0 equation holds" % (kind, ea.hex()[:6] + ea.hex()[-2:], er.hex()[:6] + er.hex()[-2:]),
+                    "small-order-pair", hit, ea, er + le32(0))
+    # (b) small-order A, R = [s]B + T' crafted so that the cofactorless equation holds, at the top of the scalar range:
+    #     s = L - 1 is the largest acceptable scalar; the same R with s = L, 2L - 1 must fail the range check
+    for ta, ea in canon_tors[1:]:
+        sv = E.L - 1
+        done = False
+        for j in range(64):
+            m2 = H(b"edge-top-s" + ea, j)[:32]
+            for tp in tors:
+                Rb = E.compress(E.pt_add(E.pt_mul(sv, E.B), tp))
+                k = E.sha512_modl(Rb, ea, m2)
+                if E.pt_eq(E.pt_neg(E.pt_mul(k, ta)), tp):      # [s]B - [k]A == [s]B + T' == R
+                    tag = ea.hex()[:6] + ea.hex()[-2:]
+                    add("toprange:A small-order %s crafted s=L-1" % tag, "small-order-crafted", m2, ea, Rb + le32(sv))
+                    add("toprange:A small-order %s same R s=L" % tag, "scalar-range", m2, ea, Rb + le32(E.L))
+                    add("toprange:A small-order %s same R s=2L-1" % tag, "scalar-range", m2, ea, Rb + le32(2 * E.L - 1))
+                    done = True
+                    break
+            if done:
+                break
+        assert done
+    # (c) mixed-order A AND mixed-order R together: A = aB + Ta, R = rB + Tr, s = r + k a;  sB - kA - R = -(k Ta + Tr).
+    #     Cancelling torsion: accepted by strict too (neither point is of SMALL order); otherwise class iii.
+    for na, ta in (("ord8", T8), ("ord4", E.pt_mul(2, T8)), ("ord2", E.pt_mul(4, T8))):
+        for nr, tr in (("ord8", T8), ("ord8'", E.pt_mul(3, T8)), ("ord4", E.pt_mul(2, T8)), ("ord2", E.pt_mul(4, T8))):
+            Ab = E.compress(E.pt_add(A, ta))
+            want = {True: None, False: None}
+            j = 0
+            while (want[True] is None or want[False] is None) and j < 400:
+                m2 = H(b"edge-mixAR" + na.encode() + nr.encode(), j)[:32]
+                j += 1
+                rr = E.sha512_modl(prefix, m2)
+                Rb = E.compress(E.pt_add(E.pt_mul(rr, E.B), tr))
+                k = E.sha512_modl(Rb, Ab, m2)
+                cancels = E.pt_is_identity(E.pt_add(E.pt_mul(k, ta), tr))
+                if want[cancels] is None:
+                    want[cancels] = (m2, Rb + le32((rr + k * a) % E.L))
+            for cancels, v in want.items():
+                if v is None:
+                    continue
+                add("mixedorder:A %s + R %s torsion %s" % (na, nr, "cancels" if cancels else "remains (dalek-nondeterministic in batch)"),
+                    "mixed-order", v[0], Ab, v[1])
+                if cancels:      # the scalar range under a mixed-order pair that verifies: s + L, and s with the top bit set
+                    sv = int.from_bytes(v[1][32:], "little")
+                    add("mixedorder:A %s + R %s torsion cancels, s+L" % (na, nr), "scalar-range", v[0], Ab, v[1][:32] + le32(sv + E.L))
+                    if na == "ord8" and nr == "ord8":
+                        add("mixedorder:A %s + R %s torsion cancels, s|2^255" % (na, nr), "scalar-range", v[0], Ab, v[1][:32] + le32(sv | (1 << 255)))
+
     # ---- wrong key / wrong message / swapped halves
     seed2 = H(b"edge-seed2")[:32]
     add("wrong-key", "tamper", msg, E.public_key(seed2), sig)

@@ -179,3 +179,70 @@ def test_openssl_bracket_agrees_with_the_oracle_on_synthetic_batches(oracle):
         bad = bytearray(sg); bad[64 * 3 + 5] ^= 2
         with pytest.raises(RuntimeError):
             synth.openssl_verify_rate(dg, pk, bytes(bad), 24, 0 if shared else 32, budget_s=0.05)
+
+
+# ---- independent referees for the edge-class labels ("Next round" #3) ---------------------------
+# The reference holds no vector beyond honest / wrong-message / zero-signature (crypto_tests.rs:50-115) and dalek cannot be
+# built here, so the labels of tests/golden/*.json come from this project's own big-int restatement.  Two verifiers this
+# project did not write are in the image; each coincides with one of dalek's two laws on a well-defined set of inputs
+# (tests/referees.py says why).  What stays unpinned by anything independent is listed in the last test below.
+def _all_labelled(edge_vectors, torsion_fuzz):
+    return [(v.get("name") or "fuzz:" + v["kind"], H(v["msg"]), H(v["pk"]), H(v["sig"]), v) for v in list(edge_vectors) + list(torsion_fuzz)]
+
+
+def test_libsodium_agrees_with_every_strict_label(edge_vectors, torsion_fuzz):
+    """libsodium's crypto_sign_verify_detached == the `strict` label (Signature::verify, crypto/src/lib.rs:200-204) on every
+    edge and torsion-fuzz vector: s >= L, small-order A and R (canonical or not), mixed-order A and R, both together,
+    off-curve points, top-of-range scalars."""
+    import pytest
+    import referees
+    if referees.libsodium() is None:
+        pytest.skip("no libsodium in this image")
+    cases = _all_labelled(edge_vectors, torsion_fuzz)
+    assert len(cases) >= 350
+    wrong = [name for name, m, p, s, v in cases if referees.sodium_verify(m, p, s) != v["strict"]]
+    assert not wrong, wrong
+    assert sum(v["strict"] for *_, v in cases) >= 20 and sum(not v["strict"] for *_, v in cases) >= 250      # both verdicts well represented
+
+
+def test_openssl_agrees_with_every_cofactorless_label_where_bytes_can_decide(edge_vectors, torsion_fuzz):
+    """OpenSSL's EVP_DigestVerify == the `cofactorless` label (the per-signature law of HS_ED25519_BATCH) on every vector
+    whose R bytes are the canonical encoding of the point they decode to.  The others (y >= p, or "-0": x = 0 with the sign
+    bit) OpenSSL always rejects - it compares the ENCODING of [s]B - [k]A with R's bytes, dalek compares points - and they
+    are asserted as exactly that, by name."""
+    import pytest
+    import referees
+    if referees.libcrypto() is None:
+        pytest.skip("no OpenSSL with Ed25519 in this image")
+    cases = _all_labelled(edge_vectors, torsion_fuzz)
+    decided, wrong, noncanon = 0, [], []
+    for name, m, p, s, v in cases:
+        got = referees.openssl_verify(m, p, s)
+        if referees.encoding_is_canonical(s[:32], E.decompress):
+            decided += 1
+            if got != v["cofactorless"]:
+                wrong.append(name)
+        else:
+            assert not got, name                       # a byte comparison can never accept a non-canonical R
+            noncanon.append((name, v["cofactorless"]))
+    assert not wrong, wrong
+    assert decided >= 340
+    # the points-vs-bytes divergence, named: non-canonical R encodings dalek accepts in BATCH mode
+    diverge = sorted(n for n, cl in noncanon if cl)
+    assert diverge == sorted(["smallorder:R=noncanon-y+p s=k*a eeffffff..ff7f", "smallorder:R=noncanon-y+p s=k*a eeffffff..ffff",
+                              "smallorder:R=neg-zero-y=1 s=k*a 01000000..0080"]), diverge
+    assert len(noncanon) == 6
+
+
+def test_what_no_independent_implementation_pins(edge_vectors, torsion_fuzz):
+    """The remainder, stated so that it cannot grow unnoticed: (1) the six vectors with a non-canonical R encoding in BATCH
+    mode (dalek decodes leniently and compares points; no other implementation in the image does), three of which the
+    oracle accepts; (2) dalek's randomised verdict on class (iii) (torsion in A or R, cofactored-valid): by construction no
+    deterministic referee exists - the oracle's RLC restatement and the GPU's are compared on it statistically
+    (tests/test_gpu_rlc.py).  Everything else in tests/golden is pinned by libsodium (strict) and OpenSSL (cofactorless)."""
+    import referees
+    cases = _all_labelled(edge_vectors, torsion_fuzz)
+    unpinned_batch = [n for n, m, p, s, v in cases if not referees.encoding_is_canonical(s[:32], E.decompress)]
+    assert len(unpinned_batch) == 6 and all(n.startswith("smallorder:R=") for n in unpinned_batch)
+    class_iii = [n for n, m, p, s, v in cases if v["cofactored"] and not (v["cofactorless"] and v.get("torsion_free", False))]
+    assert len(class_iii) >= 100
