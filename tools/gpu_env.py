@@ -1,0 +1,100 @@
+"""What distinguishes one GPU box from another, recorded beside every latency number (VERDICT r3 "Next round" #1):
+clocks, power cap, performance level, partition modes, hardware-queue budget, and the MEASURED clock of a lone wavefront
+(tools/clock_probe: the thing a QC's latency is proportional to).  `python tools/gpu_env.py` prints one JSON object;
+bench.py embeds `snapshot()` as `qc_verify_latency.env`.  Everything is best-effort: a missing tool or field is recorded
+as null, never an error."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, timeout=20):
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        return r.stdout if r.returncode == 0 else None
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+
+
+def rocm_smi():
+    """sclk / mclk / fclk / socclk current levels, performance level, power (average, cap), partition modes - card 0."""
+    out = {}
+    txt = _run(["rocm-smi", "-d", "0", "--showclocks", "--showperflevel", "--showpower", "--showmaxpower", "--showcomputepartition",
+                "--showmemorypartition", "--showsclkrange", "--showtemp", "--json"])
+    if not txt:
+        return None
+    try:
+        j = json.loads(txt)
+    except ValueError:
+        return {"raw": txt[:2000]}
+    card = j.get("card0") or (list(j.values())[0] if j else {})
+    for k, v in card.items():
+        kl = k.lower()
+        if "sclk clock level" in kl or kl.startswith("sclk"):
+            out.setdefault("sclk", v)
+        elif "mclk" in kl:
+            out.setdefault("mclk", v)
+        elif "fclk" in kl:
+            out.setdefault("fclk", v)
+        elif "socclk" in kl:
+            out.setdefault("socclk", v)
+        elif "performance level" in kl:
+            out["perf_level"] = v
+        elif "max graphics package power" in kl or "power cap" in kl:
+            out["power_cap_w"] = v
+        elif "power" in kl and "average" in kl or "socket graphics package power" in kl:
+            out.setdefault("power_w", v)
+        elif "compute partition" in kl:
+            out["compute_partition"] = v
+        elif "memory partition" in kl:
+            out["memory_partition"] = v
+        elif "valid sclk range" in kl:
+            out["sclk_range"] = v
+        elif "temperature" in kl and "junction" in kl:
+            out["temp_junction_c"] = v
+    out["fields_seen"] = len(card)
+    return out
+
+
+def clock_probe(idle_ms=100):
+    """tools/clock_probe: effective MHz of a lone wavefront cold / spaced / back-to-back / under load (None when not built)."""
+    exe = os.path.join(ROOT, "tools", "clock_probe")
+    if not os.path.exists(exe):
+        return None
+    txt = _run([exe, str(idle_ms)], timeout=60)
+    if not txt:
+        return None
+    res = {}
+    for line in txt.splitlines():
+        m = re.match(r"(\S+)\s+n=\d+\s+chain p50\s+([\d.]+) us.*effective\s+([\d.]+) MHz.*?([\d.]+) cycles/instruction", line)
+        if m:
+            res[m.group(1)] = {"chain_us": float(m.group(2)), "mhz": float(m.group(3)), "cycles_per_instruction": float(m.group(4))}
+        elif line.startswith("device 0"):
+            res["device"] = line.strip()
+    return res or None
+
+
+def snapshot(with_probe=True):
+    s = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "HS_ED25519_TENANTS": os.environ.get("HS_ED25519_TENANTS"),
+         "HSA_ENABLE_SDMA": os.environ.get("HSA_ENABLE_SDMA"), "host_cores": os.cpu_count()}
+    s["rocm_smi"] = rocm_smi()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            p = torch.cuda.get_device_properties(0)
+            s["device"] = {"name": p.name, "cus": p.multi_processor_count, "clock_rate_mhz": getattr(p, "clock_rate", 0) // 1000 or None,
+                           "hbm_gb": round(p.total_memory / 2**30, 1), "gcn_arch": getattr(p, "gcnArchName", None)}
+    except Exception:      # noqa: BLE001
+        pass
+    if with_probe:
+        s["lone_wavefront_clock"] = clock_probe()
+    return s
+
+
+if __name__ == "__main__":
+    json.dump(snapshot("--no-probe" not in sys.argv), sys.stdout, indent=1)
+    print()

@@ -171,6 +171,10 @@ if which == "coupling":
             call(j)
         for s in sts:
             s.synchronize()
+        lat = []
+        for i in range(60):                       # the metric's own number: p50 of a LONE call
+            t0 = time.perf_counter(); call(0); sts[0].synchronize(); lat.append(time.perf_counter() - t0)
+        lat.sort()
         t0 = time.perf_counter()
         for i in range(reps):
             for j in range(nctx):
@@ -180,7 +184,7 @@ if which == "coupling":
         wall = time.perf_counter() - t0
         for c in ctxs:
             c.close()
-        print("%-64s %.1f M sig/s with four in flight" % (tag, reps * nctx * n / wall / 1e6), flush=True)
+        print("%-64s lone p50 %.4f ms (p10 %.4f)  %.1f M sig/s with four in flight" % (tag, lat[30] * 1e3, lat[6] * 1e3, reps * nctx * n / wall / 1e6), flush=True)
 
     for rnd in range(2):
         rate("nothing extra")
@@ -191,5 +195,7 @@ if which == "coupling":
         bm = torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev)
         c.verify(t[0].data_ptr(), 0, tp.data_ptr(), t[1].data_ptr(), n, _lib.BATCH, bm.data_ptr(), 0, 0); torch.cuda.synchronize(dev)
         rate("+ that context after one cold call"); c.close()
+        c = _lib.DeviceContext(n, partition=(0, 8)); rate("+ an idle CU-MASKED engine context (never used)"); c.close()
+        c = _lib.DeviceContext(64); rate("+ an idle engine context of 64 signatures (stream, tiny buffers)"); c.close()
         rate("nothing extra again")
     ks.close()
