@@ -451,25 +451,26 @@ def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
     return out
 
 
-def multi_process(n=1024, procs=(1, 2, 4), seconds=1.0, timeout_s=120):
+def multi_process(n=1024, procs=(1, 2, 4), seconds=1.0, timeout_s=120, shape=(4, 8, 4), extra_env=None, tenancy_modes=None):
     """several node processes share one GPU (the reference's `fab local` starts four node processes on one
     host, benchmark/benchmark/local.py:94-104).  k independent PROCESSES (tools/mp_worker.py, each its own HIP context,
     pools and streams on device 0) run the end-to-end host-buffer load at once - ticket bursts of four 1,024-signature
     batches from 4 native threads each - started together; aggregate verifies/s and the median call latency, without and
     with the tenancy hint (hs_ed25519_set_tenancy: each process 1/k of the stream budget and its own slice of the CUs)."""
-    out = {"signatures_per_call": n, "seconds": seconds, "worker": "tools/mp_worker.py: 4 native threads x 8 tickets, bursts of four",
-           "rows": []}
+    out = {"signatures_per_call": n, "seconds": seconds,
+           "worker": "tools/mp_worker.py: %d native threads x %d tickets, bursts of %d" % tuple(shape), "rows": []}
     env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                               "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     for k in procs:
-        for tenancy in ((False,) if k == 1 else (False, True)):
+        for tenancy in (tenancy_modes or ((False,) if k == 1 else (False, True))):
             ps = []
             try:
                 for i in range(k):
                     env = dict(env0)
+                    env.update(extra_env or {})
                     if tenancy:
                         env["HS_ED25519_TENANTS"], env["HS_ED25519_TENANT_INDEX"] = str(k), str(i)
-                    ps.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "mp_worker.py"), str(n), str(seconds), str(i)],
+                    ps.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "mp_worker.py"), str(n), str(seconds), str(i)] + [str(x) for x in shape],
                                                stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env))
                 t_end = time.time() + timeout_s
                 for p in ps:            # every worker has initialised, registered nothing else, and waits for the start signal

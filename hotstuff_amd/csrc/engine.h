@@ -98,6 +98,7 @@ extern std::atomic<size_t> g_max_batch;
 extern int kMaxPool[2];                      // contexts per pool: [0] wide, [1] narrow
 extern unsigned kPoolPartitions;             // CU slices the narrow pool's streams are spread over
 extern unsigned kTenants, kTenantIndex;      // this process is tenant kTenantIndex of kTenants on its GPU (hs_ed25519_set_tenancy)
+extern bool kTenantWide;                     // co-tenants: confine the wide pool's streams to the tenant's CU share as well
 constexpr size_t kPartitionMaxBatch = 1024;  // host calls up to this many signatures are served by the narrow pool
 constexpr size_t kZeroCopyMax = 16384;       // host-pointer calls up to this size let the kernels read pinned memory directly
 int ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words);

@@ -725,6 +725,7 @@ unsigned hs::kPoolPartitions = 8;               // HS_ED25519_POOL_PARTITIONS ov
 // queues nor stack their small batches on the same CUs.  hs_ed25519_set_tenancy before init, or the environment
 // (HS_ED25519_TENANTS / HS_ED25519_TENANT_INDEX); default 1 / 0 = the whole chip.
 unsigned hs::kTenants = 1, hs::kTenantIndex = 0;
+bool hs::kTenantWide = true;
 extern "C" int hs_ed25519_set_tenancy(unsigned tenants, unsigned index) {
     if (tenants == 0 || tenants > 8 || index >= tenants) return hs::hs_fail(HS_ED25519_E_ARG, "set_tenancy: tenants in [1, 8], index < tenants");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -916,6 +917,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         kMaxPool[0] = pool_wide_for(kTenants);
         kPoolPartitions = 8 / kTenants < 1 ? 1 : 8 / kTenants;
     }
+    if (const char *e = getenv("HS_ED25519_TENANT_WIDE")) kTenantWide = e[0] != '0';
     const char *keep = getenv("HS_ED25519_KEEP_ENV");
     if (!(keep && keep[0] == '1')) {
         char q[8];

@@ -104,14 +104,21 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
     int rc = -1;
-    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the CUs
+    // this tenant's share of the chip (the whole of it by default)
+    const unsigned t_lo = cus * kTenantIndex / kTenants, t_cus = cus * (kTenantIndex + 1) / kTenants - t_lo;
+    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the tenant's CUs
         std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-        // this tenant's share of the chip (the whole of it by default), cut into the pool's partitions
-        const unsigned t_lo = cus * kTenantIndex / kTenants, t_cus = cus * (kTenantIndex + 1) / kTenants - t_lo;
         const unsigned lo = t_lo + t_cus * part / kPoolPartitions, hi = t_lo + t_cus * (part + 1) / kPoolPartitions;
         for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
         rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
         if (rc) (void)hipGetLastError();          // CU masking unavailable: a plain stream serves as well
+    } else if (k == 0 && kTenants > 1 && kTenantWide && t_cus > 0 && t_cus < cus) {
+        // co-tenants: the whole-chip calls of this process stay on its own share too, or four tenants' QC-sized calls
+        // stack their wavefronts on the same SIMDs while each tenant's small calls queue behind them
+        std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+        for (unsigned u = t_lo; u < t_lo + t_cus; u++) mask[u / 32] |= 1u << (u % 32);
+        rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
+        if (rc) (void)hipGetLastError();
     }
     if (rc) rc = hs_ed25519_ctx_create_on(&c, 64, slot);
     if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }

@@ -383,8 +383,9 @@ HS_Q qflags verify_quad_core(const fe &ax, const fe &ay, const fe &rx, const fe 
 // (4 doublings + 1 addition) + 7 + 8 + 1.5 additions on the chain instead of 33 x (4 + 2) + 14 + 16.
 // (x, y): this role's affine point, sign-adjusted; rd: this role's scalar recoded radix 16 (popped from the top); rwl: this
 // role's eight radix-65536 digits of w, left-aligned (popped from the top); jbase: 0 or 8.
-HS_Q qv quad_half_chain(const fe &x, const fe &y, u32 rd[8], u32 rwl[8], u32 jbase, int nwin, const u32 *b16, qtab &tab) {
-    qtab_build<4>(tab, x, y);
+// The walk over a table that is ALREADY BUILT: `flip` negates every table entry picked (uniform over the quad), so that a table of
+// j (-A) serves u < 0 as well - which is what lets the table be built before the scalars are known (the split form below).
+HS_Q qv quad_half_walk(u32 rd[8], u32 rwl[8], u32 jbase, int nwin, bool flip, const u32 *b16, qtab &tab) {
 #pragma nounroll
     for (int t = nwin; t < 64; t++) (void)sc_pop_digit(rd);
     qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
@@ -395,7 +396,7 @@ HS_Q qv quad_half_chain(const fe &x, const fe &y, u32 rd[8], u32 rwl[8], u32 jba
         const int nd = w == nwin - 1 ? 0 : 4;
 #pragma nounroll
         for (int k = 0; k < nd; k++) acc = q_dbl(acc);
-        const qv se = q_cached_signed(e, d < 0);
+        const qv se = q_cached_signed(e, (d < 0) != flip);
         if (w > 0) { d = sc_pop_digit(rd); e = qtab_pick(tab, d < 0 ? -d : d); }
         acc = q_add_cached(acc, se);
     }
@@ -411,6 +412,10 @@ HS_Q qv quad_half_chain(const fe &x, const fe &y, u32 rd[8], u32 rwl[8], u32 jba
         acc = q_add_cached(acc, sb);
     }
     return acc;
+}
+HS_Q qv quad_half_chain(const fe &x, const fe &y, u32 rd[8], u32 rwl[8], u32 jbase, int nwin, const u32 *b16, qtab &tab) {
+    qtab_build<4>(tab, x, y);
+    return quad_half_walk(rd, rwl, jbase, nwin, false, b16, tab);
 }
 // the two roles' partial points added, and the identity test
 HS_Q qflags quad_half_join(const qv &mine, const qv &other) { return q_is_identity(q_add_cached(mine, q_to_cached(other))); }
@@ -517,6 +522,60 @@ HS_Q bool verify_oct_fused(const u32 *pk, const u32 *sig, const u32 *msg, u32 mo
     quad_half_operands(rd, rwl, hs, role1);
     const int nwin = HS_NWIN_OF(hs.meta);
     const qv mine = quad_half_chain(sx, pt.Y, rd, rwl, role1 ? 8u : 0u, nwin, b16, tab);
+    qv other;
+#pragma unroll
+    for (int i = 0; i < 10; i++) other.v[i] = (u32)__shfl_xor((int)mine.v[i], 4, 64);
+    const qflags f = quad_half_join(mine, other);
+    return f.f && ok;
+}
+
+// The eight-lane form SPLIT over two wavefronts of one workgroup (k_verify_fused8h).  On verify_oct_fused's chain the hash
+// (13 us on a lone wavefront) and the lattice reduction (38 us) come before the square root (70 us) and the table (13 us)
+// although neither needs the other: the table of j (-P) depends on the point alone once the sign of u is applied at the
+// lookup (quad_half_walk's `flip`), and the scalars depend on the bytes alone.  So a HELPER wavefront computes this octet-
+// wavefront's scalars - lane for lane what the main wavefront's lanes would have computed - while the main one decompresses and
+// builds its tables; they meet at one barrier, the scalars cross in LDS (17 words per lane), and the main wavefront walks.
+// A lone call has the SIMDs for it: 6,667 signatures are 834 + 834 wavefronts on 1,024 SIMDs, and two wavefronts on one SIMD
+// barely slow each other (profiles/r1_ubench_valu.txt: 11.4 cycles per multiply-add alone, 5.9 per SIMD for two).
+#define HS_OCT_SC_WORDS 17
+// helper wavefront: the scalars of lane `lane`'s signature and role -> LDS
+HS_Q void oct_split_scalars(u32 *s_sc, u32 lane, const u32 *pk, const u32 *sig, const u32 *msg) {
+    half_scalars hs;
+    const bool ok = prepare_scalars_half<4>(hs, pk, sig, msg);
+    u32 rd[8], rwl[8];
+    quad_half_operands(rd, rwl, hs, (lane & 4u) != 0);
+    const u32 nwin = (u32)HS_NWIN_OF(hs.meta);
+#pragma unroll
+    for (int t = 0; t < 8; t++) { s_sc[t * 64 + lane] = rd[t]; s_sc[(8 + t) * 64 + lane] = rwl[t]; }
+    s_sc[16 * 64 + lane] = nwin | (hs.meta & 0x100u) | (ok ? 0x200u : 0u);
+}
+// main wavefront, before the barrier: this role's point and its table j (-P), j = 1 ... 8; returns the point's flags
+HS_Q u32 oct_split_point(const u32 *pk, const u32 *sig, u32 mode, qtab &tab) {
+    const bool role1 = (threadIdx.x & 4u) != 0;
+    u32 enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) enc[j] = role1 ? sig[j] : pk[j];
+    ge_p3 pt;
+    u32 fl = ge_decompress(pt, enc) ? HS_F_ONCURVE : 0;
+    if (mode & HS_MODE_STRICT) fl |= ge_is_small_order_affine(pt.Y) ? HS_F_SMALL : 0;
+    fe nx;
+    fe_neg(nx, pt.X);
+    qtab_build<4>(tab, nx, pt.Y);
+    return fl;
+}
+// main wavefront, after the barrier
+HS_Q bool oct_split_walk(const u32 *s_sc, u32 fl, u32 mode, const u32 *b16, qtab &tab) {
+    const u32 lane = threadIdx.x & 63u;
+    const bool role1 = (lane & 4u) != 0;
+    u32 rd[8], rwl[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) { rd[t] = s_sc[t * 64 + lane]; rwl[t] = s_sc[(8 + t) * 64 + lane]; }
+    const u32 meta = s_sc[16 * 64 + lane];
+    const u32 fo = (u32)__shfl_xor((int)fl, 4, 64);                  // the other role's point flags
+    bool ok = (meta & 0x200u) != 0 && (fl & HS_F_ONCURVE) && (fo & HS_F_ONCURVE);
+    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL) && !(fo & HS_F_SMALL);
+    const int nwin = (int)(meta & 0xffu);                            // the helper wavefront's maximum: uniform
+    const qv mine = quad_half_walk(rd, rwl, role1 ? 8u : 0u, nwin, !role1 && (meta & 0x100u) != 0, b16, tab);
     qv other;
 #pragma unroll
     for (int i = 0; i < 10; i++) other.v[i] = (u32)__shfl_xor((int)mine.v[i], 4, 64);

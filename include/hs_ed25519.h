@@ -119,8 +119,8 @@ size_t hs_ed25519_min_gpu_batch(int keys_registered);
 /* HS_ED25519_BATCH_RLC draws its 127-bit coefficients from SHA-512 keyed with a 32-byte secret taken
  * from the OS at first use, mixed with a per-call sequence number (host side, at enqueue) and a per-execution
  * counter kept in the context's workspace on the device (so a round replayed from a captured hipGraph draws fresh
- * coefficients as well); this pins the key and switches both counters off (tests, reproducible runs).
- * key == NULL: back to the default - a fresh secret from the OS, counters on. */
+ * coefficients as well); this pins the key and switches both counters off (tests, reproducible runs) for every call
+ * enqueued - or graph captured - afterwards.  key == NULL: back to the default - a fresh secret from the OS, counters on. */
 int hs_ed25519_set_rlc_key(const uint8_t key[32]);
 /* HS_ED25519_BATCH_RLC calls below this size run as plain HS_ED25519_BATCH (the five-stage MSM pipeline
  * only pays from a few thousand signatures up; profiles/r2_rlc_ab.md).  A context can override the
@@ -408,9 +408,10 @@ int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out);
  * per device slot): when none
  * is free, submit returns HS_ED25519_E_BUSY WITHOUT blocking (a thread that holds every ticket itself
  * would otherwise deadlock) - wait on an outstanding ticket and retry.  Every ticket must be waited on.
- * The SYNCHRONOUS calls (verify_shared / _multi / _tc, sign_batch, public_keys ...) wait for a context instead - for at
- * most one second: a thread may itself hold every context as uncollected tickets (collect them first), and then runs
- * on one context over the pool's cap, which is destroyed afterwards.
+ * The SYNCHRONOUS calls (verify_shared / _multi / _tc, sign_batch, public_keys ...) wait for a context instead, however
+ * long the holders take - unless the calling thread itself has contexts out as uncollected tickets (then nobody else may
+ * ever return one): after one second such a caller runs on one context lent over the pool's cap, destroyed afterwards.
+ * A caller that holds none never grows the pools (they are sized to the GPU's hardware queues).
  * flags: HS_ED25519_SUBMIT_MORE on every batch but the last of a burst lets calls of n <= 1,024 signatures share
  * one launch (the TCP_CORK idea): a 1,024-signature batch alone is one wavefront per SIMD of its CU slice, two per
  * launch reach the chip's full multiply-add issue rate.  Without the flag the call launches at once.  A batch

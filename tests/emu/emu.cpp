@@ -159,6 +159,39 @@ void emu_verify_oct(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, 
         out[i] = all ? 1 : 0;
     }
 }
+// the same as the split form computes it (k_verify_fused8h): the table is ALWAYS j (-P), built before the scalars are known, and
+// the sign of u is applied at the lookup (quad_half_walk's flip)
+void emu_verify_oct_split(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *out) {
+    const u32 *btab = emu_base16();
+    for (size_t i = 0; i < n; i++) {
+        u32 pk[8], sig[16], msg[8];
+        load_words(pk, pks + 32 * i, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        ge_p3 A, R;
+        u32 fa = ge_decompress(A, pk) ? HS_F_ONCURVE : 0, fr = ge_decompress(R, sig) ? HS_F_ONCURVE : 0;
+        if (mode & HS_MODE_STRICT) { fa |= ge_is_small_order_affine(A.Y) ? HS_F_SMALL : 0; fr |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0; }
+        qtab tabs[2];
+        for (int role = 0; role < 2; role++) {          // before the "barrier": points and tables only
+            const ge_p3 &P = role ? R : A;
+            fe nx; fe_neg(nx, P.X);
+            qtab_build<4>(tabs[role], nx, P.Y);
+        }
+        half_scalars hs;
+        bool ok = prepare_scalars_half<4>(hs, pk, sig, msg);
+        ok = ok && (fa & HS_F_ONCURVE) && (fr & HS_F_ONCURVE);
+        if (mode & HS_MODE_STRICT) ok = ok && !(fa & HS_F_SMALL) && !(fr & HS_F_SMALL);
+        const int nwin = (int)(hs.meta & 0xffu);
+        qv part[2];
+        for (int role = 0; role < 2; role++) {
+            u32 rd[8], rwl[8];
+            quad_half_operands(rd, rwl, hs, role != 0);
+            part[role] = quad_half_walk(rd, rwl, role ? 8u : 0u, nwin, !role && ((hs.meta >> 8) & 1) != 0, btab, tabs[role]);
+        }
+        const qflags f0 = quad_half_join(part[0], part[1]), f1 = quad_half_join(part[1], part[0]);
+        bool all = ok;
+        for (int l = 0; l < 4; l++) all = all && f0.f[l] && f1.f[l];
+        out[i] = all ? 1 : 0;
+    }
+}
 // radix-8 recoding: digits most significant first (85 of them) and the count the kernels use
 int emu_sc_digits3(const uint8_t *x32, int8_t *digits) {
     u32 x[8], r[8]; load_words(x, x32, 8); sc_recode8(r, x);

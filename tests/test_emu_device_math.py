@@ -125,7 +125,7 @@ def test_decompress_matches_dalek_rules(emu, edge_vectors):
     assert seen_small >= 14      # 8 canonical + the non-canonical spellings of y = 0, 1 (and -0)
 
 
-@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct"])
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct", "emu_verify_oct_split"])
 def test_verify_stages_on_edge_vectors(emu, edge_vectors, fn):
     """fn = the one-lane-per-signature stage 2 or the quad (4 lanes per signature) stage 2."""
     verify = getattr(emu, fn)
@@ -140,7 +140,7 @@ def test_verify_stages_on_edge_vectors(emu, edge_vectors, fn):
     assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in edge_vectors]
 
 
-@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct"])
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct", "emu_verify_oct_split"])
 def test_verify_stages_vs_c_oracle_random(emu, oracle, fn):
     import synth
     verify = getattr(emu, fn)
@@ -269,7 +269,7 @@ def test_cached_path_vs_c_oracle_random(emu, oracle):
     assert not got[2] and got[:2] == oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)[:2]
 
 
-@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct"])
+@pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct", "emu_verify_oct_split"])
 def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
     vec = torsion_fuzz
     n = len(vec)

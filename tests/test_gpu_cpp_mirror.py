@@ -95,3 +95,13 @@ def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
                  "hs_ed25519_verify_shared_sharded on one device slot"):
         assert not cases[name], name          # would need the GPU: must not be Ok
     assert rc != 0
+
+
+if __name__ == "__main__":      # python tests/test_gpu_cpp_mirror.py fixture <path>: the fixture file alone (the sanitizer runs of the mirror)
+    import pathlib
+    import shutil
+    import sys
+    import tempfile
+    if len(sys.argv) == 3 and sys.argv[1] == "fixture":
+        with tempfile.TemporaryDirectory() as td:
+            shutil.copy(_fixture(pathlib.Path(td)), sys.argv[2])

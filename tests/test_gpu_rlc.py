@@ -146,8 +146,13 @@ def test_coefficients_are_fresh_per_call_and_per_graph_replay(edge_vectors):
         captures, launches = ring.stats()
         assert captures == 1 and launches == trials   # one capture, 127 replays
         assert set(stages) == {0, 1}, "graph replays: the RLC stage gave the same verdict on every replay"
-        # pinned key: the same verdict every time (reproducible runs), replayed or not
+        # pinned key: the same verdict every time (reproducible runs), replayed or not.  The pin applies to what is enqueued -
+        # or captured - after it, so the ring is built anew (a graph captured before keeps the arguments it was captured with)
+        ring.close()
         _lib.set_rlc_key(bytes(range(32)))
+        ring = _lib.RoundRing(64, slots=1, kind="graph")
+        ctx = ring.slot_ctx(0)
+        ctx.set_rlc_min(1)
         stages = []
         for _ in range(16):
             d, k, s = ring.begin(0, 1, shared=True)

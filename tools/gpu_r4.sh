@@ -32,4 +32,20 @@ print("multi_process", json.dumps(j.get("multi_process"))[:600])
 PY
     env_record end
     ;;
+b)  # the rest of the suite after visit a's one failure, the four-tenant sweep, the sanitizer runs
+    env_record start
+    timeout 900 python -m pytest tests -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    timeout 600 python tools/mp_sweep.py 0.8 > ${O}_mp_sweep.txt 2>${O}_mp_sweep.err; echo "mp_sweep rc=$?"; cat ${O}_mp_sweep.txt | cut -c1-230
+    for kind in tsan asan; do
+        d=build/san/$kind
+        [ -x $d/stress_host ] || { echo "no $kind build"; continue; }
+        if [ $kind = tsan ]; then export TSAN_OPTIONS="suppressions=$PWD/tests/cpp/tsan.supp history_size=4 second_deadlock_stack=1 exitcode=66 log_path=$PWD/${O}_tsan_report"
+        else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"; fi
+        timeout 400 $d/stress_host 6 > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
+        PYTHONPATH=tools:tests python tests/test_gpu_cpp_mirror.py fixture /tmp/mirror_fixture.bin && timeout 200 $d/mirror_tests /tmp/mirror_fixture.bin > ${O}_${kind}_mirror.txt 2>&1; echo "$kind mirror_tests rc=$?"; grep -c "^ok" ${O}_${kind}_mirror.txt; grep "^FAIL" ${O}_${kind}_mirror.txt | head
+        unset TSAN_OPTIONS ASAN_OPTIONS UBSAN_OPTIONS
+        ls ${O}_${kind}_report* 2>/dev/null | head -5
+        grep -h "SUMMARY" ${O}_${kind}_report* 2>/dev/null | sort | uniq -c | sort -rn | head -20
+    done
+    ;;
 esac
