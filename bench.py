@@ -68,6 +68,7 @@ MAD_PER_VERIFY = {
     "k_verify_fused": ((NWIN - 1) * 4 * 155 + (2 * NWIN + 16) * 200 + 14 * 300 + 255 * 55 + 21 * 100) * 64 // 16,
     # eight lanes per signature (single batches up to 8,192 signatures): every quad of the octet runs ONE table's chain -
     # (NWIN - 1) x 4 doublings, NWIN + 8 additions, 7 table additions, the join - and all eight lanes decompress
+    "k_verify_fused8h": ((NWIN - 1) * 4 * 155 + (NWIN + 8) * 200 + 7 * 300 + 300 + 255 * 55 + 21 * 100) * 64 // 8,      # the same arithmetic on the main wavefront; the helper adds none of it (hash + reduction are not multiply-adds of the field)
     "k_verify_fused8": ((NWIN - 1) * 4 * 155 + (NWIN + 8) * 200 + 7 * 300 + 300 + 255 * 55 + 21 * 100) * 64 // 8,
     # the same with 3-bit windows (NWIN3 windows of three doublings, four-entry tables): the kernels that put several
     # batches into one launch, two wavefronts per SIMD
@@ -759,6 +760,17 @@ def main():
         args.partitions = int(env) if env is not None else ((4 if lane_form else 8) if args.batch <= 4096 else 0)
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # `multi_process` (four node PROCESSES on the GPU, BASELINE configs[0]'s topology) runs FIRST, before this process touches
+    # the GPU: `fab local` has no fifth GPU process, and a bench that already holds ~20 hardware queues of its own beside the
+    # tenants pushed the driver's runlist into oversubscription - the tenants were then time-sliced (round 3's 39-46 M
+    # verifies/s and the 2.8x spread between identical tenants; tools/queue_probe.py, profiles/r4_queue_probe.md)
+    mp_early = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_extras or args.no_qc):
+        try:
+            mp_early = multi_process(args.batch)
+            mp_early["ran"] = "before this process initialised the GPU (no fifth GPU process beside the tenants)"
+        except Exception as e:        # extras never cost the headline line
+            mp_early = {"error": "%s: %s" % (type(e).__name__, e)}
     # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to
     # fd 1 (RCCL prints an info banner there through C stdio) is routed to stderr until the end.
     sys.stdout.flush()
@@ -1135,7 +1147,7 @@ def main():
                             ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
-                            ("multi_process", lambda: multi_process(n))):
+                            ("multi_process", lambda: mp_early if mp_early is not None else multi_process(n))):
                 try:
                     out[key] = fn()
                 except Exception as e:        # extras never cost the headline line

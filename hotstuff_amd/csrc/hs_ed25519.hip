@@ -255,6 +255,53 @@ k_verify_fused8(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict
         }
     }
 }
+// The eight-lane form split over TWO wavefronts per eight signatures (verify_quad.h, oct_split_*): the helper wavefront hashes
+// and reduces while the main one takes the square roots and builds its tables - 51 us of scalar work off a 273 us chain.  The
+// lone call's default (hs_ed25519_ctx_set_concurrent and ring slots keep four lanes per signature, as for k_verify_fused8).
+__global__ void __launch_bounds__(128, 2)
+k_verify_fused8h(msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                 unsigned char *__restrict__ bitmap8, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    __shared__ u32 s_tab[HS_QTAB_WORDS_OF(4)];      // per quad of the main wavefront: the eight entries of ITS table
+    __shared__ u32 s_sc[HS_OCT_SC_WORDS * 64];      // the scalars, helper -> main, [word][lane]
+    const u32 block = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (skip && *skip) {
+        const u32 first = block * 8;
+        const u32 here = first < n ? min(8u, n - first) : 0u;
+        if (threadIdx.x == 0) bitmap8[block] = (unsigned char)((1u << here) - 1);
+        return;
+    }
+    qtab tab; tab.lds = s_tab;
+    const u32 i = block * 8 + (lane >> 3);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const u32 *pk = pks + (size_t)8 * j, *sig = sigs + (size_t)16 * j;
+    u32 fl = 0;
+    if (wave == 1) {
+        u32 msg[8];
+        load_msg(msg, msgs, j);
+        oct_split_scalars(s_sc, lane, pk, sig, msg);
+    } else {
+        fl = oct_split_point(pk, sig, mode, tab);
+    }
+    __syncthreads();
+    if (wave == 1) return;
+    const bool ok = oct_split_walk(s_sc, fl, mode, g_b16, tab);
+    unsigned long long m = __ballot(ok && active);
+    // signature o accepted iff all eight lanes of its octet agree; gather bit 8 o -> bit o
+    m &= m >> 1; m &= m >> 2; m &= m >> 4; m &= 0x0101010101010101ull;
+    m = (m | (m >> 7)) & 0x0003000300030003ull;
+    m = (m | (m >> 14)) & 0x0000000f0000000full;
+    m = (m | (m >> 28)) & 0xffull;
+    if (lane == 0) {
+        bitmap8[block] = (unsigned char)m;
+        if (nreject) {
+            const u32 first = block * 8;
+            const u32 here = first < n ? min(8u, n - first) : 0u;
+            const u32 bad = here - (u32)__popcll(m);
+            if (bad) atomicAdd(nreject, bad);
+        }
+    }
+}
 // The same with 3-bit windows: four entries per table, 20,480 B of LDS, two wavefronts per SIMD - single batches between
 // 16,384 and 32,768 signatures
 __global__ void __launch_bounds__(64, 2)
@@ -701,6 +748,7 @@ static const size_t kLaneMinTotal = 8192;
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{32768};
 static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
+static std::atomic<bool> g_oct_split{true};            // HS_ED25519_OCT_SPLIT=0: the one-wavefront eight-lane form (k_verify_fused8) instead of the split one
 static const size_t kQuadMaxBatch = 32768;
 // the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
 // (enqueue_cold): -19 % on the call's p50 up to 16,384 signatures past the round (1.03 against 1.27 ms at 66,667 ... 73,728,
@@ -926,6 +974,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0');
     if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
@@ -991,7 +1040,7 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
-    if (n <= simds * 8 && n <= g_oct_max_batch.load()) return "k_verify_fused8";
+    if (n <= simds * 8 && n <= g_oct_max_batch.load()) return g_oct_split.load() ? "k_verify_fused8h" : "k_verify_fused8";
     if (n <= g_quad_max_batch.load()) return n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3";
     const size_t tail = n % (simds * 64);       // a sliver past whole rounds of wavefronts rides in the stage-2 launch (enqueue_cold)
     return n > simds * 64 && tail && tail <= g_tail_max.load() ? "k_verify_tail" : "k_verify";
@@ -1059,9 +1108,14 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         // eight lanes per signature: still one wavefront per SIMD at most - for a call that has the chip to itself.  With
         // several whole-chip calls at once (the slots of a round ring, hs_ed25519_ctx_set_concurrent) twice the wavefronts
         // per signature cost throughput (41 against 53 M signatures/s from four ring slots): four lanes per signature then.
-        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n)
-            HS_HIP(launch1((const void *)k_verify_fused8, dim3(np / 8), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-                   "launch k_verify_fused8");
+        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n) {
+            if (g_oct_split.load())
+                HS_HIP(launch1((const void *)k_verify_fused8h, dim3(np / 8), dim3(128), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+                       "launch k_verify_fused8h");
+            else
+                HS_HIP(launch1((const void *)k_verify_fused8, dim3(np / 8), dim3(64), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+                       "launch k_verify_fused8");
+        }
         else {
             const bool w4 = n <= simds * 16;
             HS_HIP(launch1(w4 ? (const void *)k_verify_fused : (const void *)k_verify_fused3, dim3(np / 16), dim3(64), a3, st,

@@ -257,7 +257,22 @@ static void ctx_churn_worker() {      // contexts created and destroyed beside e
     }
 }
 
+// `stress_host canary`: a deliberate data race and a deliberate heap overflow of one byte - run once per sanitizer build to show
+// that the detector is alive in this process on this box (exit code 66 / 67 from TSAN_OPTIONS / ASAN_OPTIONS exitcode=...)
+static int g_canary;
+static int canary() {
+    std::thread a([] { for (int i = 0; i < 100000; i++) g_canary++; }), b([] { for (int i = 0; i < 100000; i++) g_canary++; });
+    a.join(); b.join();
+    volatile char *p = (volatile char *)malloc(16);
+    p[16] = 1;                                          // one past the end
+    const int v = p[16];
+    free((void *)p);
+    printf("stress_host: canary ran (%d, %d)\n", g_canary, v);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "canary")) return canary();
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
     const unsigned scale = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     const int ordinals[2] = {0, 0};                     // two virtual device slots on one GPU: the sharded paths and the round-robin of cold calls

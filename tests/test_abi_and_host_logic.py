@@ -119,7 +119,7 @@ def test_batches_per_launch_kernel_policy():
     form, from four the pairs form, from eight (1,024-signature) batches the one-lane pair over the batch list (throughput)."""
     lib = _lib.lib()
     names = [lib.hs_ed25519_batches_kernel_for(None, k).decode() for k in (1, 2, 3, 4, 7, 8, 16)]
-    assert names == ["k_verify_fused8"] + ["k_verify_fused_batches"] * 2 + ["k_verify_fused_pairs_batches"] * 2 + ["k_verify_batches"] * 2
+    assert names == ["k_verify_fused8h"] + ["k_verify_fused_batches"] * 2 + ["k_verify_fused_pairs_batches"] * 2 + ["k_verify_batches"] * 2
 
 
 def test_single_batch_kernel_policy_by_size():
@@ -128,7 +128,7 @@ def test_single_batch_kernel_policy_by_size():
     3-bit windows up to 32,768, the one-lane pair above - with the sliver past whole rounds of 1,024 wavefronts (up to 16,384
     signatures) inside the stage-2 launch."""
     f = lambda n: _lib.lib().hs_ed25519_dominant_kernel_for(n).decode()
-    expect = {1: "k_verify_fused8", 8192: "k_verify_fused8", 8193: "k_verify_fused", 16384: "k_verify_fused",
+    expect = {1: "k_verify_fused8h", 8192: "k_verify_fused8h", 8193: "k_verify_fused", 16384: "k_verify_fused",
               16385: "k_verify_fused3", 32768: "k_verify_fused3", 32769: "k_verify", 65536: "k_verify",
               65537: "k_verify_tail", 66667: "k_verify_tail", 65536 + 16384: "k_verify_tail", 65536 + 16385: "k_verify",
               131072: "k_verify", 131072 + 100: "k_verify_tail"}

@@ -60,6 +60,29 @@ def rocm_smi():
     return out
 
 
+def kfd_params():
+    """How the kernel driver schedules user queues: with the hardware scheduler (sched_policy 0) a GPU runs at most a fixed
+    number of user queues at once; more than that across ALL processes and the runlist is oversubscribed - queues are then
+    time-sliced, which is what a fifth idle GPU process (or a few idle stream contexts too many) costs everybody else."""
+    out = {}
+    for name in ("sched_policy", "hws_max_conc_proc", "num_kcq", "max_num_of_queues_per_device", "queue_preemption_timeout_ms", "mes", "halt_if_hws_hang"):
+        try:
+            out[name] = open("/sys/module/amdgpu/parameters/" + name).read().strip()
+        except OSError:
+            out[name] = None
+    try:
+        import glob
+        procs = glob.glob("/sys/class/kfd/kfd/proc/*")
+        out["kfd_processes"] = len(procs)
+        q = 0
+        for p in procs:
+            q += len(glob.glob(p + "/queues/*"))
+        out["kfd_queues_total"] = q
+    except OSError:
+        pass
+    return out
+
+
 def clock_probe(idle_ms=100):
     """tools/clock_probe: effective MHz of a lone wavefront cold / spaced / back-to-back / under load (None when not built)."""
     exe = os.path.join(ROOT, "tools", "clock_probe")
@@ -82,6 +105,7 @@ def snapshot(with_probe=True):
     s = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "HS_ED25519_TENANTS": os.environ.get("HS_ED25519_TENANTS"),
          "HSA_ENABLE_SDMA": os.environ.get("HSA_ENABLE_SDMA"), "host_cores": os.cpu_count()}
     s["rocm_smi"] = rocm_smi()
+    s["kfd"] = kfd_params()
     try:
         import torch
         if torch.cuda.is_available():

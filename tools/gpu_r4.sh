@@ -48,4 +48,26 @@ b)  # the rest of the suite after visit a's one failure, the four-tenant sweep, 
         grep -h "SUMMARY" ${O}_${kind}_report* 2>/dev/null | sort | uniq -c | sort -rn | head -20
     done
     ;;
+c)  # the split eight-lane kernel A/B, the queue-oversubscription probe, sanitizer canaries, the suite, the driver's bench
+    env_record start
+    timeout 600 python tools/oct_split_ab.py > ${O}_oct_split_ab.txt 2>${O}_oct_split_ab.err; echo "oct_split_ab rc=$?"; cat ${O}_oct_split_ab.txt
+    timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    timeout 600 python tools/queue_probe.py 0.6 > ${O}_queue_probe.txt 2>${O}_queue_probe.err; echo "queue_probe rc=$?"; cat ${O}_queue_probe.txt | cut -c1-200
+    for kind in tsan asan; do
+        d=build/san/$kind
+        if [ $kind = tsan ]; then export TSAN_OPTIONS="suppressions=$PWD/tests/cpp/tsan.supp exitcode=66"; else export ASAN_OPTIONS="detect_leaks=0 exitcode=67"; fi
+        timeout 60 $d/stress_host canary > ${O}_${kind}_canary.txt 2>&1; echo "$kind canary rc=$? (66 / 67 = the detector fired)"; grep -E "SUMMARY|WARNING: ThreadSanitizer|ERROR: AddressSanitizer" ${O}_${kind}_canary.txt | head -3
+        timeout 400 $d/stress_host 6 > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -1 ${O}_${kind}_stress.txt
+        unset TSAN_OPTIONS ASAN_OPTIONS
+    done
+    timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench_default.json.txt 2>${O}_bench_default.err; echo "bench rc=$?"
+    python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r4_c_bench_default.json.txt").read().strip().splitlines()[-1])
+q = j.get("qc_verify_latency", {})
+print("headline %.2f M | qc cold %s cached %s | kfd %s" % (j["value"] / 1e6, q.get("p10_p50_p99_ms_device_resident"),
+      q.get("committee_cached", {}).get("p10_p50_p99_ms_device_resident"), q.get("env", {}).get("kfd")))
+for r in j.get("multi_process", {}).get("rows", []): print(r)
+PY
+    ;;
 esac
