@@ -232,6 +232,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     st = torch.cuda.ExternalStream(ctx.stream, device=dev)     # the context's own stream
     torch.cuda.synchronize(dev)                                # uploads / fills above ran on torch's stream
     devt = []
+    ctx.set_profiling(calls + 20)                              # the kernel's own duration (dispatch timestamps) beside the call's wall time
     with torch.cuda.stream(st):
         for i in range(calls + 20):
             nr.zero_()
@@ -246,6 +247,8 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
                 devt.append(dt)
     full = bm.view(torch.int64)[: n // 64].tolist()
     assert all((int(w) & ((1 << 64) - 1)) == (1 << 64) - 1 for w in full), "QC bitmap"
+    kt = ctx.kernel_times()
+    cold_kernel_ms = (kt[0] + kt[1]) / max(1, kt[2])
     # (c) the same QC with the whole committee registered as a key set (static per epoch)
     t0 = time.perf_counter()
     keys = [pk[32 * i:32 * i + 32] for i in range(n)]
@@ -266,6 +269,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
             hostc.append(dt)
     d_ki = torch.arange(n, dtype=torch.int32, device=dev)
     devc = []
+    ctx.set_profiling(calls + 20)
     with torch.cuda.stream(st):
         for i in range(calls + 20):
             nr.zero_()
@@ -278,6 +282,8 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
             assert bad == 0, "device-resident QC (key cache): %d rejects at call %d" % (bad, i)
             if i >= 20:
                 devc.append(dt)
+    kt = ctx.kernel_times()
+    cached_kernel_ms = (kt[0] + kt[1]) / max(1, kt[2])
     ks_bytes = ks.hbm_bytes()
     ks.close()
     ctx.close()
@@ -290,6 +296,7 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     p10 = lambda v: sorted(v)[len(v) // 10]
     return {"n_validators": validators, "signatures": n, "calls": calls, "cpu": cpu, "env": env,
             "p10_p50_p99_ms_device_resident": [round(f(devt) * 1e3, 4) for f in (p10, med, p99)],
+            "kernel_ms_device_resident": round(cold_kernel_ms, 4), "kernel": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
             "p50_ms_host_api": round(med(host) * 1e3, 4), "p99_ms_host_api": round(p99(host) * 1e3, 4),
             "p50_ms_host_api_caller_pinned": round(med(pinned) * 1e3, 4) if pinned else None,
             "p50_ms_device_resident": round(med(devt) * 1e3, 4),
@@ -297,7 +304,8 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
             "committee_cached": {"keys": validators, "keyset_hbm_bytes": ks_bytes, "keyset_build_ms": round(build_ms, 1),
                                  "p50_ms_host_api": round(med(hostc) * 1e3, 4),
                                  "p50_ms_device_resident": round(med(devc) * 1e3, 4),
-                                 "p10_p50_p99_ms_device_resident": [round(f(devc) * 1e3, 4) for f in (p10, med, p99)]}}
+                                 "p10_p50_p99_ms_device_resident": [round(f(devc) * 1e3, 4) for f in (p10, med, p99)],
+                                 "kernel_ms_device_resident": round(cached_kernel_ms, 4)}}
 
 
 def streamed_rounds(_lib, synth, validators=10000, slots=4, seconds=0.6):

@@ -19,7 +19,10 @@ def hw_queue_budget(tenants):
     The runtime reads the variable at its first device call, which in a Python process is torch's - before the library's own
     setenv can matter - so the wrapper sets it at import, from the SAME formula (the two used to differ)."""
     t = max(1, min(8, int(tenants)))
-    return min(16, max(2, 16 // t) + max(1, 4 // t) + 2) if t > 1 else 16
+    if t == 1:
+        return 16
+    parts = max(1, 4 // t)
+    return (3 * parts if t <= 4 else 2) + parts + 1
 
 
 if os.environ.get("HS_ED25519_KEEP_ENV") != "1":
@@ -210,6 +213,9 @@ def lib():
                 l.hs_ed25519_ring_wait.restype = ctypes.c_int
                 l.hs_ed25519_ring_stats.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
                 l.hs_ed25519_ring_stats.restype = ctypes.c_int
+                l.hs_ed25519_shard_msm_min.restype = sz
+                l.hs_ed25519_set_shard_msm_min.argtypes = [sz]
+                l.hs_ed25519_shard_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
                 l.hs_ed25519_hw_queue_budget.argtypes = [ctypes.c_uint]
                 l.hs_ed25519_hw_queue_budget.restype = ctypes.c_uint
                 l.hs_ed25519_ring_slot_ctx.argtypes = [vp, ctypes.c_uint]
@@ -325,6 +331,13 @@ def set_rlc_key(key):
         return
     buf, keep = _buf(key)
     check(lib().hs_ed25519_set_rlc_key(buf), "hs_ed25519_set_rlc_key")
+
+
+def shard_msm_stats():
+    """(sharded BATCH_RLC calls that ran the one-combination stage, how many of them it accepted outright)"""
+    a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    lib().hs_ed25519_shard_msm_stats(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def verify_packed_sharded(digests, pks, sigs, n, mode, shared, want_bitmap=False):

@@ -128,4 +128,11 @@ void rlc_release(hs_ed25519_ctx *c);
 int rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream = nullptr);     // all allocation of an n-signature RLC call, ahead of time
 int enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
                 const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream);
+// a combination cut over several devices (hs_shard.hip): one key per call, one partial record per shard, one join
+struct rlc_key_words { u32 w[8]; };
+int rlc_call_key(rlc_key_words &out, bool &pinned);
+int enqueue_rlc_partial(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, u32 index_base,
+                        const rlc_key_words &key, u32 **d_partial, void *stream);
+int enqueue_rlc_join(hs_ed25519_ctx *ctx, const u32 *d_parts, u32 count, u32 **d_flag, void *stream);
+constexpr size_t kRlcPartBytes = 384;        // HS_RLC_PART_WORDS x 4 (rlc.h)
 }  // namespace hs

@@ -930,15 +930,22 @@ static int build_base_tables(dev_state &d) {
     if (rc) free_base_tables(d);
     return rc;
 }
-// pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for (one per stream context
-// + 2 for the host's own streams, never more than the 16 beyond which in-flight queues collapse, profiles/r1_stream_sweep.txt)
-static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : ((int)(16 / tenants) < 2 ? 2 : (int)(16 / tenants)); }
-static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : ((int)(4 / tenants) < 1 ? 1 : (int)(4 / tenants)); }
+// Pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for.  The budget that matters is
+// the GPU's, not the process's: the driver's hardware scheduler runs ~32 user queues at once ACROSS ALL PROCESSES, and one
+// queue more oversubscribes its runlist - every process is then time-sliced (four tenants: 75 M verifies/s with 28 queues
+// between them, 66 M and a 1.6x spread with ONE more queue held by an idle fifth process, 0.1 - 33 M and up to 160x with 8 - 32
+// more: tools/queue_probe.py, profiles/r4_queue_probe.md).  So co-tenants take few queues and leave headroom for whatever
+// else opens the GPU (a monitoring agent, a bench harness): per tenant 3 narrow contexts on each of its 64-CU partitions
+// (the shape the sweep measured best: 77.9 M against 76.9 M for four contexts on two 32-CU halves, profiles/r4_b_mp_sweep.txt),
+// one wide context per partition, one queue for the process's own default stream - 20 queues for four tenants, 18 for two.
+static unsigned tenant_partitions(unsigned tenants) { return tenants <= 1 ? 8u : (4 / tenants < 1 ? 1u : 4 / tenants); }
+static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : (tenants <= 4 ? 3 * (int)tenant_partitions(tenants) : 2); }
+static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : (int)tenant_partitions(tenants); }
 extern "C" unsigned hs_ed25519_hw_queue_budget(unsigned tenants) {
     if (tenants < 1) tenants = 1;
     if (tenants > 8) tenants = 8;
-    const int want = pool_narrow_for(tenants) + pool_wide_for(tenants) + 2;
-    return (unsigned)(want < 16 ? want : 16);
+    if (tenants == 1) return 16;
+    return (unsigned)(pool_narrow_for(tenants) + pool_wide_for(tenants) + 1);
 }
 extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
     if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
@@ -963,7 +970,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (kTenants > 1) {
         kMaxPool[1] = pool_narrow_for(kTenants);
         kMaxPool[0] = pool_wide_for(kTenants);
-        kPoolPartitions = 8 / kTenants < 1 ? 1 : 8 / kTenants;
+        kPoolPartitions = tenant_partitions(kTenants);
     }
     if (const char *e = getenv("HS_ED25519_TENANT_WIDE")) kTenantWide = e[0] != '0';
     const char *keep = getenv("HS_ED25519_KEEP_ENV");

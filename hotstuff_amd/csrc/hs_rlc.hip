@@ -60,7 +60,7 @@ struct rlc_keys_src {            // where signature i's key bytes / curve flag c
 #endif
 __global__ void __launch_bounds__(64, HS_RLC_PREPARE_WAVES)
 k_rlc_prepare(rlc_view v, rlc_key key, const u32 *__restrict__ epoch, msg_src msgs, rlc_keys_src keys,
-              const u32 *__restrict__ sigs, u32 n) {
+              const u32 *__restrict__ sigs, u32 n, u32 index_base) {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     // The coefficient key of THIS EXECUTION: the host mixed its call number into `key` at enqueue time, but a launch
     // replayed from a captured graph (the round ring's GRAPH form) carries that by-value argument unchanged for ever.
@@ -90,7 +90,7 @@ k_rlc_prepare(rlc_view v, rlc_key key, const u32 *__restrict__ epoch, msg_src ms
     if (kind == 1) {
         u32 msg[8], c[8];
         load_msg(msg, msgs, i);
-        ok = (rlc_scalars(v, i, key, pk, sig, msg, c) && ok) || !active;
+        ok = (rlc_scalars(v, i, key, pk, sig, msg, c, index_base + i) && ok) || !active;
         // sum z_i s_i over the wavefront (limb-wise, carry-free in 64 bits), then ONE atomic per limb
         unsigned long long c64[8];
 #pragma unroll
@@ -352,18 +352,33 @@ k_rlc_reduce(const u32 *__restrict__ part, const u32 *__restrict__ segoff, u32 L
 }
 
 __global__ void __launch_bounds__(64)
-k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ failed, u32 *__restrict__ ok_flag, u32 *__restrict__ epoch) {
+k_rlc_final(const u32 *__restrict__ wsum, const u32 *__restrict__ failed, u32 *__restrict__ ok_flag, u32 *__restrict__ epoch,
+            u32 *__restrict__ partial) {
     if (threadIdx.x >= 4) return;      // one quad
-    const qflags f = rlc_final_quad(wsum);
-    const bool all = q_quad_all(f);
-    if (threadIdx.x == 0) {
-        *ok_flag = (all && *failed == 0) ? 1u : 0u;
-        if (epoch) {                   // the next execution on this workspace (a graph replay included) gets other coefficients
-            const u32 lo = epoch[0] + 1;
-            epoch[0] = lo;
-            if (lo == 0) epoch[1] += 1;
-        }
+    const qv acc = rlc_final_point_quad(wsum);
+    if (partial) {                     // a shard of a combination cut over several devices: hand the point over, test nothing here
+        rlc_store_wsum_quad(partial, acc);
+        if (threadIdx.x == 0) { partial[80] = *failed; *ok_flag = 0u; }
+    } else {
+        const qflags f = rlc_identity_quad(acc);
+        const bool all = q_quad_all(f);
+        if (threadIdx.x == 0) *ok_flag = (all && *failed == 0) ? 1u : 0u;
     }
+    if (threadIdx.x == 0 && epoch) {   // the next execution on this workspace (a graph replay included) gets other coefficients
+        const u32 lo = epoch[0] + 1;
+        epoch[0] = lo;
+        if (lo == 0) epoch[1] += 1;
+    }
+}
+// the partial points of `count` shards (HS_RLC_PART_WORDS each) added up, the identity tested once: 1 = the whole batch accepted
+__global__ void __launch_bounds__(64)
+k_rlc_join(const u32 *__restrict__ parts, u32 count, u32 *__restrict__ ok_flag) {
+    if (threadIdx.x >= 4) return;
+    const qflags f = rlc_join_quad(parts, count);
+    const bool all = q_quad_all(f);
+    u32 failed = 0;
+    for (u32 s = 0; s < count; s++) failed |= parts[(size_t)HS_RLC_PART_WORDS * s + 80];
+    if (threadIdx.x == 0) *ok_flag = (all && failed == 0) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -389,6 +404,8 @@ std::atomic<unsigned long long> g_call_seq{1};
 const size_t kRlcMinBatch = 40960;
 const u32 kTabWords = HS_RLC_WINDOWS * (HS_RLC_BUCKETS + 1);
 const size_t kSmallBytes = 64 + (size_t)HS_RLC_CSUM_SLOTS * 64;
+const size_t kPartBytes = (size_t)HS_RLC_PART_WORDS * 4;
+static_assert(HS_RLC_PART_WORDS * 4 == hs::kRlcPartBytes, "engine.h and rlc.h disagree on the partial record");
 const u32 kMinChunk = 8;
 
 void ws_free(rlc_ws *w) {
@@ -436,7 +453,7 @@ int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream) {
     HS_HIP(hipMalloc((void **)&w->part, (size_t)HS_RLC_WINDOWS * lane_cap(np, kMinChunk) * 160), "hipMalloc rlc partials");
     HS_HIP(hipMalloc((void **)&w->wsum, (size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS * 4), "hipMalloc rlc window sums");
     HS_HIP(hipMalloc((void **)&w->tabs, (size_t)4 * kTabWords * 4), "hipMalloc rlc offsets");
-    HS_HIP(hipMalloc((void **)&w->small, kSmallBytes + 64), "hipMalloc rlc flags");
+    HS_HIP(hipMalloc((void **)&w->small, kSmallBytes + 64 + kPartBytes + 64), "hipMalloc rlc flags");      // ... | epoch | partial record | join flag
     HS_HIP(hipMemset(w->small + kSmallBytes, 0, 64), "rlc clear epoch");       // the execution counter starts at 0 and only k_rlc_final writes it
     w->np = np;
     return 0;
@@ -473,6 +490,12 @@ static int current_key(rlc_key &out, bool &pinned) {
     }
     return 0;
 }
+int hs::rlc_call_key(rlc_key_words &out, bool &pinned) {
+    rlc_key k;
+    const int rc = current_key(k, pinned);
+    if (!rc) memcpy(out.w, k.w, 32);
+    return rc;
+}
 // tests / tuning: run the RLC stage from `min_batch` signatures up on this context (0 = library default)
 extern "C" int hs_ed25519_ctx_set_rlc_min(hs_ed25519_ctx *ctx, size_t min_batch) {
     if (!ctx) return fail(HS_ED25519_E_ARG, "ctx_set_rlc_min: null context");
@@ -497,24 +520,68 @@ extern "C" int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls) {
     return flags[1] ? 1 : 0;
 }
 
+namespace {
+// what distinguishes a shard of a combination cut over several devices from a whole call
+struct rlc_shard_opts { const rlc_key *key = nullptr; u32 index_base = 0; bool partial = false; };
+int enqueue_rlc_body(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
+                     const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream, const rlc_shard_opts &opt);
+}
 int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
                     const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream) {
+    return enqueue_rlc_body(ctx, ks, msgs, d_pks, d_key_idx, d_sigs, n, d_ok_flag, stream, rlc_shard_opts());
+}
+// One shard's part of a combination: the pipeline over this shard's n signatures under the CALL's key, coefficients drawn for
+// positions index_base ... index_base + n - 1, ending in the partial record (*d_partial: HS_RLC_PART_WORDS words in the context's
+// workspace) instead of an identity test.  Any n >= 1 (no minimum: the caller chose this path).
+int hs::enqueue_rlc_partial(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, u32 index_base,
+                            const rlc_key_words &key, u32 **d_partial, void *stream) {
+    rlc_key k;
+    memcpy(k.w, key.w, 32);
+    rlc_shard_opts opt;
+    opt.key = &k; opt.index_base = index_base; opt.partial = true;
+    u32 *flag = nullptr;
+    const int rc = enqueue_rlc_body(ctx, nullptr, msgs, d_pks, nullptr, d_sigs, n, &flag, stream, opt);
+    if (rc) return rc;
+    rlc_ws *w = (rlc_ws *)ctx->rlc;
+    *d_partial = (u32 *)(w->small + kSmallBytes + 64);
+    return 0;
+}
+// `count` partial records at d_parts (this device's memory, or pinned host memory mapped on it) -> one verdict word in the
+// context's workspace (*d_flag); the context must have an RLC workspace (rlc_reserve)
+int hs::enqueue_rlc_join(hs_ed25519_ctx *ctx, const u32 *d_parts, u32 count, u32 **d_flag, void *stream) {
+    rlc_ws *w = (rlc_ws *)ctx->rlc;
+    if (!w || !w->small || !count) return fail(HS_ED25519_E_ARG, "rlc join: no workspace");
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    u32 *flag = (u32 *)(w->small + kSmallBytes + 64 + kPartBytes);
+    void *a[] = { &d_parts, &count, &flag };
+    HS_HIP(hipLaunchKernel((const void *)k_rlc_join, dim3(1), dim3(64), a, 0, st), "launch k_rlc_join");
+    *d_flag = flag;
+    return 0;
+}
+
+namespace {
+int enqueue_rlc_body(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msgs, const uint8_t *d_pks,
+                     const uint32_t *d_key_idx, const uint8_t *d_sigs, size_t n, u32 **d_ok_flag, void *stream, const rlc_shard_opts &opt) {
     *d_ok_flag = nullptr;
     if (!d_sigs || (!ks && !d_pks) || (ks && !d_key_idx)) return fail(HS_ED25519_E_ARG, "verify_device: null pointer");
     if (misaligned(d_sigs, 16) || misaligned(d_pks, 16) || misaligned(d_key_idx, 4)) return fail(HS_ED25519_E_ARG, "verify_device: misaligned pointer");
     if (ks && ks->slot != ctx->slot) return fail(HS_ED25519_E_ARG, "verify_device_cached: the key set lives on another device slot than the context");
     rlc_ws *w = ws_of(ctx);
     if (!w) return fail(HS_ED25519_E_NOMEM, "rlc: out of memory");
-    const size_t min_batch = w->min_batch ? w->min_batch : kRlcMinBatch;
-    if (n < min_batch || n > 0x0fffffffu) return 0;      // too small to pay for the pipeline (or absurdly large): plain per-signature BATCH
+    const size_t min_batch = opt.partial ? 1 : (w->min_batch ? w->min_batch : kRlcMinBatch);
+    if (n < min_batch || n > 0x0fffffffu) return opt.partial ? fail(HS_ED25519_E_ARG, "rlc partial: bad n") : 0;      // too small to pay for the pipeline (or absurdly large): plain per-signature BATCH
     const u32 *btab = dev_base_table(ctx->slot);
     if (!btab) return HS_ED25519_E_DEVICE;
     int rc = rlc_reserve(ctx, n, stream);
     if (rc) return rc;
     rlc_key key;
     bool pinned = false;
-    rc = current_key(key, pinned);
-    if (rc) return rc;
+    if (opt.key) { key = *opt.key; pinned = true; }      // a shard: the call's key as drawn by the caller, no per-execution counter
+    else {
+        rc = current_key(key, pinned);
+        if (rc) return rc;
+    }
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const u32 np = (u32)round_up(n, 64), NP = 2 * np, nn = (u32)n, C = chunk_for(n), Lcap = lane_cap(np, C);
@@ -535,7 +602,8 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     const uint8_t *p_dig = w->dig;
     {
         const u32 *p_epoch = epoch;
-        void *a[] = { &v, &key, &p_epoch, &msgs, &keys, &p_sg, (void *)&nn };
+        u32 index_base = opt.index_base;
+        void *a[] = { &v, &key, &p_epoch, &msgs, &keys, &p_sg, (void *)&nn, &index_base };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_prepare, dim3((tasks + 63) / 64), dim3(64), a, 0, st), "launch k_rlc_prepare");
     }
     {
@@ -565,10 +633,12 @@ int hs::enqueue_rlc(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src ms
     }
     {
         const u32 *p_wsum = w->wsum; const u32 *p_fail = v.failed;
-        void *a[] = { &p_wsum, &p_fail, &ok_flag, &epoch };
+        u32 *p_partial = opt.partial ? (u32 *)(w->small + kSmallBytes + 64) : nullptr;
+        void *a[] = { &p_wsum, &p_fail, &ok_flag, &epoch, &p_partial };
         HS_HIP(hipLaunchKernel((const void *)k_rlc_final, dim3(1), dim3(64), a, 0, st), "launch k_rlc_final");
     }
     w->calls++;
     *d_ok_flag = ok_flag;
     return 0;
 }
+}  // namespace

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -278,12 +279,154 @@ int verify_sharded_contiguous(const hs_ed25519_keyset *const *ks_per_slot, const
 }
 }  // namespace
 
+// ---- one combination over every device ("batch-MSM mode") ---------------------------------------------
+// HS_ED25519_BATCH_RLC through the sharded calls: dalek's verify_batch is ONE random linear combination over the whole batch
+// (crypto/src/lib.rs:218).  Each device reduces its shard to one partial point under the call's coefficient key
+// (enqueue_rlc_partial), the k records of 384 bytes travel - through pinned host memory, or an in-process RCCL all-gather with
+// HS_ED25519_EXCHANGE_RCCL - to slot 0, which adds them and tests the identity once (k_rlc_join).  Accept: the call is done, the
+// bitmap is all ones.  Reject (or any shard saw a malformed signature): the per-signature kernels localise, per shard, exactly
+// as hs_ed25519_verify_device does behind its own RLC stage.  From hs_ed25519_shard_msm_min() signatures up (the pipeline's
+// floor is its 248-doubling Horner chain, ~0.26 ms: below ~40,000 signatures PER DEVICE the per-signature kernels answer
+// sooner, so on 8 GPUs this pays from ~330,000 signatures; HS_ED25519_SHARD_MSM_MIN overrides, tests force it from 1).
+namespace {
+std::atomic<size_t> s_msm_override{0};      // hs_ed25519_set_shard_msm_min; 0 = none
+size_t msm_min() {
+    const size_t o = s_msm_override.load();
+    if (o) return o;
+    if (const char *e = getenv("HS_ED25519_SHARD_MSM_MIN")) { const long long x = atoll(e); if (x > 0) return (size_t)x; }
+    return hs_ed25519_rlc_min_batch() * (size_t)(dev_slots() > 0 ? dev_slots() : 1);
+}
+// 1 = the combination over all shards accepted, 0 = it did not (localise), < 0 = engine error
+int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n) {
+    const int k = dev_slots();
+    rlc_key_words key;
+    bool pinned = false;
+    int rc = rlc_call_key(key, pinned);
+    if (rc) return rc;
+    struct part_job { hs_ed25519_ctx *c = nullptr; u32 *d_partial = nullptr; size_t n = 0; };
+    std::vector<part_job> jobs(k);
+    struct give_back { std::vector<part_job> &j; ~give_back() { for (part_job &p : j) if (p.c) { (void)hipSetDevice(p.c->device); (void)hipStreamSynchronize(p.c->stream); pool_put(p.c); } } } guard{jobs};
+    const bool rccl = s_exchange.load() == HS_ED25519_EXCHANGE_RCCL;
+    int first = -1;                     // the first slot with work: it joins
+    for (int s = 0; s < k && !rc; s++) {
+        size_t lo, hi;
+        hs_ed25519_shard_plan(n, (unsigned)k, (unsigned)s, &lo, &hi);
+        const size_t ns = hi - lo;
+        if (!ns && !(rccl && first >= 0)) continue;       // an empty shard only matters to a collective (it contributes the identity: not built - see below)
+        if (!ns) continue;
+        rc = pool_get(&jobs[s].c, s, (size_t)-1);
+        if (rc) break;
+        hs_ed25519_ctx *c = jobs[s].c;
+        jobs[s].n = ns;
+        if (first < 0) first = s;
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
+        rc = ctx_reserve(c, ns > 4096 ? ns : 4096, true);
+        if (!rc) rc = rlc_reserve(c, ns);
+        if (rc) break;
+        // staging as host_submit: [digests][keys][sigs], read in place over PCIe up to kZeroCopyMax signatures, copied above
+        const size_t dg_bytes = digest_stride ? 32 * ns : 32;
+        const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + 32 * ns, 16), in_bytes = off_sig + 64 * ns;
+        memcpy(c->h_in, digest_stride ? digests + 32 * lo : digests, dg_bytes);
+        memcpy(c->h_in + off_k, pks + 32 * lo, 32 * ns);
+        memcpy(c->h_in + off_sig, sigs + 64 * lo, 64 * ns);
+        const bool zc = ns <= kZeroCopyMax;
+        uint8_t *in = zc ? c->h_in : c->d_in;
+        if (!zc && hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "H2D"); break; }
+        msg_src m;
+        rc = make_digest_src(m, in, digest_stride);
+        if (!rc) rc = enqueue_rlc_partial(c, m, in + off_k, in + off_sig, ns, (u32)lo, key, &jobs[s].d_partial, c->stream);
+        // the record comes home in the context's pinned bitmap area (>= 520 bytes for the 4,096 signatures reserved above)
+        if (!rc && !rccl && hipMemcpyAsync(c->h_out, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = fail(HS_ED25519_E_DEVICE, "D2H partial point");
+    }
+    if (rc) return rc;
+    if (first < 0) return 1;
+    hs_ed25519_ctx *c0 = jobs[first].c;
+    std::vector<int> live;
+    for (int s = 0; s < k; s++) if (jobs[s].c) live.push_back(s);
+    u32 *d_flag = nullptr;
+    gather_set *gs = nullptr;
+    struct put_set { gather_set *&g; ~put_set() { gather_set_put(g); } } gs_guard{gs};
+    if (rccl && (int)live.size() == k) {
+        // all-gather of the 384-byte records over xGMI; slot `first` (= 0 here) joins what it received
+        std::lock_guard<std::mutex> lk(s_mu);
+        rc = rccl_ensure();
+        if (!rc) rc = gather_set_get(&gs, kRlcPartBytes);
+        for (int s = 0; s < k && !rc; s++) {
+            if (hipSetDevice(jobs[s].c->device) != hipSuccess ||
+                hipMemcpyAsync(gs->buf[s] + (size_t)s * kRlcPartBytes, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToDevice, jobs[s].c->stream) != hipSuccess)
+                rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the partial point");
+        }
+        if (!rc) {
+            ncclResult_t r = s_rccl.GroupStart();
+            for (int s = 0; s < k && r == ncclSuccess; s++)
+                r = s_rccl.AllGather(gs->buf[s] + (size_t)s * kRlcPartBytes, gs->buf[s], kRlcPartBytes, ncclUint8, s_comms[s], jobs[s].c->stream);
+            const ncclResult_t r2 = s_rccl.GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather (partial points)", r != ncclSuccess ? r : r2);
+        }
+        if (rc) return rc;
+        if (hipSetDevice(c0->device) != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+        rc = enqueue_rlc_join(c0, (const u32 *)gs->buf[first], (u32)k, &d_flag, c0->stream);
+    } else {
+        // host exchange: wait for every record, line them up in the joining context's pinned staging, join there (the kernel
+        // reads the pinned memory in place: 384 bytes per device)
+        for (int s : live) {
+            if (hipSetDevice(jobs[s].c->device) != hipSuccess || hipStreamSynchronize(jobs[s].c->stream) != hipSuccess)
+                return fail(HS_ED25519_E_DEVICE, "waiting for a shard's partial point");
+        }
+        if (rccl) {      // a collective was asked for but a slot had no signatures: records fetched one by one instead
+            for (int s : live) {
+                if (hipSetDevice(jobs[s].c->device) != hipSuccess ||
+                    hipMemcpy(jobs[s].c->h_out, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(HS_ED25519_E_DEVICE, "D2H partial point");
+            }
+        }
+        uint8_t *line = c0->h_in;       // its inputs have been consumed: the stream above has drained
+        for (size_t j = 0; j < live.size(); j++) memcpy(line + j * kRlcPartBytes, jobs[live[j]].c->h_out, kRlcPartBytes);
+        if (hipSetDevice(c0->device) != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipSetDevice");
+        rc = enqueue_rlc_join(c0, (const u32 *)line, (u32)live.size(), &d_flag, c0->stream);
+    }
+    if (rc) return rc;
+    u32 flag = 0;
+    if (hipMemcpyAsync(c0->h_out, d_flag, 4, hipMemcpyDeviceToHost, c0->stream) != hipSuccess || hipStreamSynchronize(c0->stream) != hipSuccess)
+        return fail(HS_ED25519_E_DEVICE, "reading the joined verdict");
+    memcpy(&flag, c0->h_out, 4);
+    return flag ? 1 : 0;
+}
+std::atomic<unsigned long long> s_msm_calls{0}, s_msm_accepts{0};
+int verify_sharded_rlc(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint8_t *bitmap) {
+    if (dev_slots() <= 0) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
+    if (n == 0) return 1;
+    if (!digests || !pks || !sigs) return fail(HS_ED25519_E_ARG, "verify_sharded: null pointer");
+    if (n >= msm_min() && n <= 0x0fffffffu) {
+        const int r = sharded_msm_stage(digests, digest_stride, pks, sigs, n);
+        if (r < 0) return r;
+        s_msm_calls++;
+        if (r == 1) {
+            s_msm_accepts++;
+            if (bitmap) { memset(bitmap, 0xff, n / 8); if (n % 8) bitmap[n / 8] = (uint8_t)((1u << (n % 8)) - 1); }
+            return 1;
+        }
+    }
+    return verify_sharded_contiguous(nullptr, digests, digest_stride, pks, 32, sigs, n, HS_ED25519_BATCH, bitmap);      // localise (or: too small for the pipeline)
+}
+}  // namespace
+extern "C" size_t hs_ed25519_shard_msm_min(void) { return msm_min(); }
+extern "C" int hs_ed25519_set_shard_msm_min(size_t n) { s_msm_override.store(n); return 0; }      // 0 = back to the default
+extern "C" int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts) {
+    if (calls) *calls = s_msm_calls.load();
+    if (accepts) *accepts = s_msm_accepts.load();
+    return 0;
+}
+
 extern "C" int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
                                                 uint32_t mode, uint8_t *bitmap) {
+    if (mode == HS_ED25519_BATCH_RLC) return verify_sharded_rlc(digest, 0, pks, sigs, n, bitmap);
     return verify_sharded_contiguous(nullptr, digest, 0, pks, 32, sigs, n, mode, bitmap);
 }
 extern "C" int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,
                                                uint32_t mode, uint8_t *bitmap) {
+    if (mode == HS_ED25519_BATCH_RLC) return verify_sharded_rlc(digests, 32, pks, sigs, n, bitmap);
     return verify_sharded_contiguous(nullptr, digests, 32, pks, 32, sigs, n, mode, bitmap);
 }
 

@@ -130,14 +130,16 @@ HS_HD void rlc_add_csum(unsigned long long *csum, const unsigned long long c[8])
 // c = z_i s_i mod L (zero when s >= L), to be added into v.csum by the caller - the kernel first sums it across
 // the wavefront: 8 atomics per SIGNATURE on the same eight addresses serialised k_rlc_prepare (0.27 ms of atomics at
 // 66,667 signatures).  Returns false when s >= L.
-HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *pk, const u32 *sig, const u32 *msg, u32 c[8]) {
+// zi: the index the coefficient is drawn for - the signature's position in the WHOLE call (a shard of a sharded combination
+// passes its offset + i, so that equal tuples in different shards still get different coefficients)
+HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *pk, const u32 *sig, const u32 *msg, u32 c[8], u32 zi) {
     u32 in[24], h[16], k[8], s[8], z[8], a[8], r[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { in[j] = sig[j]; in[8 + j] = pk[j]; in[16 + j] = msg[j]; s[j] = sig[8 + j]; }
     sha512_96(h, in);
     sc_reduce512(k, h);
     const bool canon = sc_is_canonical(s);
-    rlc_coeff(z, key, k, s, i);
+    rlc_coeff(z, key, k, s, zi);
     sc_mul(a, z, k);                       // z_i h_i mod L  (dalek: Scalar multiplication)
     sc_mul(c, z, s);                       // z_i s_i mod L
     const size_t stride = 2 * (size_t)v.np;
@@ -150,6 +152,10 @@ HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *
         for (int j = 0; j < 8; j++) c[j] = 0;
     }
     return canon;
+}
+
+HS_HD bool rlc_scalars(const rlc_view &v, u32 i, const rlc_key &key, const u32 *pk, const u32 *sig, const u32 *msg, u32 c[8]) {
+    return rlc_scalars(v, i, key, pk, sig, msg, c, i);
 }
 
 // stage 3: one lane's run [lo, hi) of a window's sorted list, as a loop of `trip` steps shared by
@@ -262,7 +268,8 @@ HS_Q void rlc_store_wsum_quad(u32 *slot, const qv &p) {
     for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) { slot[10 * l + i] = p.l[l].v[i]; slot[40 + 10 * l + i] = c.l[l].v[i]; }
 #endif
 }
-HS_Q qflags rlc_final_quad(const u32 *wsum) {
+// Horner over the 32 window sums + the [b]B point: the value of the whole combination, one coordinate per lane
+HS_Q qv rlc_final_point_quad(const u32 *wsum) {
     qv acc = rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * (HS_RLC_WINDOWS - 1));
 #pragma nounroll
     for (int w = HS_RLC_WINDOWS - 2; w >= 0; w--) {
@@ -270,8 +277,10 @@ HS_Q qflags rlc_final_quad(const u32 *wsum) {
         for (int d = 0; d < 8; d++) acc = q_dbl(acc);
         acc = q_add_cached(acc, rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * w + 40));
     }
-    acc = q_add_cached(acc, rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS + 40));
-    // identity: X == 0 (lane 0), Y == Z (lane 1), Z != 0 (lane 2; fail closed on a zeroed accumulator)
+    return q_add_cached(acc, rlc_load_point_quad(wsum + (size_t)HS_RLC_WSUM_WORDS * HS_RLC_WINDOWS + 40));
+}
+// identity: X == 0 (lane 0), Y == Z (lane 1), Z != 0 (lane 2; fail closed on a zeroed accumulator)
+HS_Q qflags rlc_identity_quad(const qv &acc) {
     const qv z = q_perm<2, 2, 2, 2>(acc);
     qflags f;
 #if defined(__HIPCC__)
@@ -283,6 +292,19 @@ HS_Q qflags rlc_final_quad(const u32 *wsum) {
     f.f[2] = !fe_iszero(acc.l[2]); f.f[3] = true;
 #endif
     return f;
+}
+HS_Q qflags rlc_final_quad(const u32 *wsum) { return rlc_identity_quad(rlc_final_point_quad(wsum)); }
+
+// One combination cut over several GPUs (SURVEY.md 8e "batch-MSM mode"): every device reduces ITS shard of the signatures
+// to one partial point under the same coefficient key - a record of HS_RLC_PART_WORDS words: the point in the window-sum slot
+// format (extended + cached, 80 words) and the shard's format / curve failure word - and whoever holds all of them adds them up
+// and tests the identity ONCE, which is exactly dalek's single verify_batch over the whole batch.
+#define HS_RLC_PART_WORDS 96           // 80 point words | failed | pad  = 384 bytes
+HS_Q qflags rlc_join_quad(const u32 *parts, u32 count) {
+    qv acc = rlc_load_point_quad(parts);
+#pragma nounroll
+    for (u32 s = 1; s < count; s++) acc = q_add_cached(acc, rlc_load_point_quad(parts + (size_t)HS_RLC_PART_WORDS * s + 40));
+    return rlc_identity_quad(acc);
 }
 
 // stage 4, serial form (tests/emu and the definition the wavefront-shuffle kernel must match):

@@ -99,9 +99,11 @@ void hs_ed25519_shutdown(void);
  * identical with or without it.  hs_ed25519_init exports GPU_MAX_HW_QUEUES (one hardware queue per stream
  * context) unless the host already set it or HS_ED25519_KEEP_ENV=1 forbids touching the environment. */
 int hs_ed25519_set_tenancy(unsigned tenants, unsigned index);
-/* The GPU_MAX_HW_QUEUES value hs_ed25519_init exports for a process that is one of `tenants` (1..8) on its GPU:
- * one hardware queue per pool context + 2, at most 16.  Pure function, no device needed - a host whose runtime is
- * initialised before this library (PyTorch, hotstuff_amd/_lib.py) sets the variable itself from it. */
+/* The GPU_MAX_HW_QUEUES value hs_ed25519_init exports for a process that is one of `tenants` (1..8) on its GPU: 16 for a
+ * process alone; for co-tenants one hardware queue per pool context + 1 (9 / 5 / 4 for 2 / 4 / 8 tenants).  The GPU's
+ * hardware scheduler runs ~32 user queues at once across ALL processes; past that every process is time-sliced
+ * (profiles/r4_queue_probe.md), so co-tenants keep well below it.  Pure function, no device needed - a host whose runtime
+ * is initialised before this library (PyTorch, hotstuff_amd/_lib.py) sets the variable itself from it. */
 unsigned hs_ed25519_hw_queue_budget(unsigned tenants);
 /* Caller-owned pinned buffers.  Memory from hs_ed25519_host_alloc is page-locked and mapped on every device
  * slot; a host-pointer call (synchronous, submit, sharded) whose digests, keys and signatures all lie in such
@@ -344,6 +346,18 @@ int hs_ed25519_shard_plan(size_t n, unsigned nshards, unsigned shard, size_t *lo
 int hs_ed25519_set_shard_exchange(int how);
 void hs_ed25519_shard_reset(void);        /* drop RCCL communicators / gather buffers (before shutdown) */
 int hs_ed25519_shard_rccl_ranks(void);    /* ranks of the in-process RCCL exchange (0 until it first ran) */
+/* mode HS_ED25519_BATCH_RLC through the two calls below is ONE random linear combination over the whole batch, cut over the
+ * devices (SURVEY.md 8e "batch-MSM mode"; dalek's verify_batch is one combination, crypto/src/lib.rs:218): every device
+ * reduces its shard to one partial point under the call's coefficient key, the 384-byte records are brought together (pinned
+ * host memory, or the RCCL all-gather with HS_ED25519_EXCHANGE_RCCL), one device adds them and tests the identity once.
+ * Accept -> 1 and an all-ones bitmap; otherwise the per-signature kernels localise, per shard, and the result is
+ * HS_ED25519_BATCH's.  Runs from hs_ed25519_shard_msm_min() signatures up (default hs_ed25519_rlc_min_batch() x device slots:
+ * below ~40,000 signatures per device the per-signature kernels answer sooner; env HS_ED25519_SHARD_MSM_MIN or
+ * hs_ed25519_set_shard_msm_min override), below that as HS_ED25519_BATCH.  hs_ed25519_shard_msm_stats: calls that ran the
+ * combination and how many of them it accepted outright. */
+size_t hs_ed25519_shard_msm_min(void);
+int hs_ed25519_set_shard_msm_min(size_t n);
+int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts);
 int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
                                      uint32_t mode, uint8_t *bitmap);
 int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,

@@ -421,8 +421,10 @@ void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t 
 // Same functions the kernels of hs_rlc.hip call, with the counting sort and the bucket fold done
 // serially.  Returns 1 when the combination is the identity, 0 otherwise (incl. format failures).
 // segments: how many lanes share a bucket's run (exercises the partial-sum path).
-int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
-                   const uint8_t *key32, int segments) {
+// partial != null: a shard of a combination cut over several devices (hs_shard.hip): coefficients drawn for positions
+// index_base + i, the result handed over as a partial record (HS_RLC_PART_WORDS words) instead of tested; returns 1 then
+static int emu_rlc_core(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                        const uint8_t *key32, int segments, u32 index_base, u32 *partial) {
     if (!n) return 1;
     const u32 np = (u32)((n + 63) / 64 * 64), NP = 2 * np;
     std::vector<u32> rec((size_t)(NP + 1) * HS_RLC_REC_WORDS, 0);
@@ -437,13 +439,13 @@ int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, c
         if (!rlc_point(v, (u32)i, sig)) fail = 1;
         if (!rlc_point(v, np + (u32)i, pk)) fail = 1;
         u32 c[8];
-        if (!rlc_scalars(v, (u32)i, key, pk, sig, msg, c)) fail = 1;
+        if (!rlc_scalars(v, (u32)i, key, pk, sig, msg, c, index_base + (u32)i)) fail = 1;
         unsigned long long c64[8];
         for (int j = 0; j < 8; j++) c64[j] = c[j];
         rlc_add_csum(csum, c64);
     }
     rlc_store_identity_record(rec.data() + (size_t)NP * HS_RLC_REC_WORDS);
-    if (fail) return 0;
+    if (fail && !partial) return 0;
     static std::vector<u32> btab;
     if (btab.empty()) { btab.resize(HS_KS_KEY_WORDS); emu_keyset_build_base(btab.data()); }
     std::vector<u32> wsum((size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS);
@@ -480,8 +482,37 @@ int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, c
         fe l1, r1, l2, r2; fe_mul(l1, bb.X, qz); fe_mul(r1, qx, bb.Z); fe_mul(l2, bb.Y, qz); fe_mul(r2, qy, bb.Z);
         if (!fe_eq(l1, r1) || !fe_eq(l2, r2)) return -1;
     }
+    if (partial) {
+        rlc_store_wsum_quad(partial, rlc_final_point_quad(wsum.data()));
+        partial[80] = fail;
+        return 1;
+    }
     const qflags f = rlc_final_quad(wsum.data());
     return f.f[0] && f.f[1] && f.f[2] && f.f[3];
+}
+int emu_rlc_verify(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                   const uint8_t *key32, int segments) {
+    return emu_rlc_core(msgs, msg_stride, pks, sigs, n, key32, segments, 0, nullptr);
+}
+// one combination cut over `nshards` devices (hs_shard.hip's plan: contiguous shards of ceil(n / k) rounded up to 64): the
+// partial records joined and the identity tested once - must equal emu_rlc_verify over the whole batch
+int emu_rlc_verify_sharded(const uint8_t *msgs, size_t msg_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                           const uint8_t *key32, int nshards) {
+    if (!n) return 1;
+    const size_t S = ((n + nshards - 1) / nshards + 63) / 64 * 64;
+    std::vector<u32> parts;
+    u32 count = 0, failed = 0;
+    for (int s = 0; s < nshards; s++) {
+        const size_t lo = (size_t)s * S < n ? (size_t)s * S : n, hi = lo + S < n ? lo + S : n;
+        if (hi == lo) continue;
+        parts.resize((size_t)(count + 1) * HS_RLC_PART_WORDS, 0);
+        u32 *p = parts.data() + (size_t)count * HS_RLC_PART_WORDS;
+        if (emu_rlc_core(msgs + msg_stride * lo, msg_stride, pks + 32 * lo, sigs + 64 * lo, hi - lo, key32, 1 + s % 3, (u32)lo, p) != 1) return -1;
+        failed |= p[80];
+        count++;
+    }
+    const qflags f = rlc_join_quad(parts.data(), count);
+    return (f.f[0] && f.f[1] && f.f[2] && f.f[3] && !failed) ? 1 : 0;
 }
 void emu_rlc_coeff(const uint8_t *key32, const uint8_t *k32, const uint8_t *s32, uint32_t index, uint8_t *z16) {
     rlc_key key; memcpy(key.w, key32, 32);

@@ -129,3 +129,78 @@ def test_host_calls_by_key_bytes_go_round_the_device_slots(oracle, three_slots):
     for dg, pk, sg, n, shared, want in cases:            # the synchronous calls rotate as well; verdicts unchanged
         ok, bm = _lib.verify_packed(dg, pk, sg, n, _lib.STRICT, shared, want_bitmap=True)
         assert bits(bm, n) == want and ok == all(want)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 200, 1000, 6667])
+def test_one_combination_over_three_slots_equals_dalek_verify_batch(oracle, three_slots, n):
+    """SURVEY.md 8e "batch-MSM mode" (VERDICT r3 missing #2): HS_ED25519_BATCH_RLC through the sharded call = ONE random
+    linear combination over the whole batch - each slot reduces its shard to a partial point, the records meet on one slot,
+    the identity is tested once.  Against the oracle's own restatement of dalek's verify_batch: a valid batch must be accepted
+    BY THE COMBINATION (the stats say so, not the fallback), a batch with bad signatures rejected by it and then localised
+    bit-exactly by the per-signature kernels.  Ragged and empty shards included (n = 200 -> 128 + 72 + 0; n = 1, 3)."""
+    from conftest import oracle_verify_batch
+    lib = _lib.lib()
+    lib.hs_ed25519_set_shard_msm_min(1)
+    try:
+        for shared in (True, False):
+            st = 0 if shared else 32
+            dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+            c0, a0 = _lib.shard_msm_stats()
+            ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, shared, want_bitmap=True)
+            c1, a1 = _lib.shard_msm_stats()
+            assert ok and all(bits(bm, n)) and (c1 - c0, a1 - a0) == (1, 1)
+            assert oracle_verify_batch(oracle, dg, st, pk, sg, n) == 1
+            # one bit of one s: every format check stays green, the equation breaks
+            v = n // 2
+            s2 = bytearray(sg); s2[64 * v + 35] ^= 0x10; s2 = bytes(s2)
+            expect = oracle_verify_many(oracle, dg, st, pk, s2, n, 0)
+            ok, bm = _lib.verify_packed_sharded(dg, pk, s2, n, _lib.BATCH_RLC, shared, want_bitmap=True)
+            c2, a2 = _lib.shard_msm_stats()
+            assert not ok and bits(bm, n) == expect and not expect[v] and (c2 - c1, a2 - a1) == (1, 0)
+            assert oracle_verify_batch(oracle, dg, st, pk, s2, n) == 0
+            if n >= 64:          # the SURVEY 8d mix: off-curve points, s >= L, wrong digests - a shard's `failed` word must reach the join
+                dg3, pk3, sg3, bad = synth.corrupt(dg, pk, sg, n, shared, rate_byte=20)
+                expect = oracle_verify_many(oracle, dg3, st, pk3, sg3, n, 0)
+                ok, bm = _lib.verify_packed_sharded(dg3, pk3, sg3, n, _lib.BATCH_RLC, shared, want_bitmap=True)
+                assert ok == all(expect) and bits(bm, n) == expect
+                assert oracle_verify_batch(oracle, dg3, st, pk3, sg3, n) == int(all(expect))
+        # duplicates across shards: the same tuple at two positions in different shards gets different coefficients (its index
+        # is its position in the WHOLE call), so a pair of signatures that cancel each other cannot be built from one tuple
+        if n == 200:
+            dg, pk, sg = synth.make_batch(100, shared=True, cache_dir=CACHE)
+            ok, bm = _lib.verify_packed_sharded(dg, pk + pk, sg + sg, 200, _lib.BATCH_RLC, True, want_bitmap=True)
+            assert ok and all(bits(bm, 200))
+    finally:
+        lib.hs_ed25519_set_shard_msm_min(0)
+
+
+def test_small_sharded_rlc_calls_skip_the_combination(three_slots):
+    """Below hs_ed25519_shard_msm_min() (the pipeline's minimum per device x the slots) a sharded BATCH_RLC call is plain BATCH."""
+    assert _lib.lib().hs_ed25519_shard_msm_min() == 3 * _lib.lib().hs_ed25519_rlc_min_batch()
+    dg, pk, sg = synth.make_batch(500, shared=True, cache_dir=CACHE)
+    c0, _ = _lib.shard_msm_stats()
+    ok, bm = _lib.verify_packed_sharded(dg, pk, sg, 500, _lib.BATCH_RLC, True, want_bitmap=True)
+    assert ok and all(bits(bm, 500)) and _lib.shard_msm_stats()[0] == c0
+
+
+def test_one_combination_through_the_rccl_exchange_one_slot(oracle):
+    """The same with the partial records travelling through the in-process RCCL all-gather - one rank here (one GPU)."""
+    _lib.shutdown()
+    _lib.init(0, 8192)
+    lib = _lib.lib()
+    old = lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_RCCL)
+    lib.hs_ed25519_set_shard_msm_min(1)
+    try:
+        n = 700
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        c0, a0 = _lib.shard_msm_stats()
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)
+        assert ok and all(bits(bm, n)) and _lib.shard_msm_stats() == (c0 + 1, a0 + 1)
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=20)
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect
+    finally:
+        lib.hs_ed25519_set_shard_msm_min(0)
+        lib.hs_ed25519_set_shard_exchange(old)
+        lib.hs_ed25519_shard_reset()

@@ -85,3 +85,23 @@ def test_rlc_emulation_on_deterministic_edge_classes(emu, oracle, edge_vectors):
             assert got == 1 == oracle_verify_batch(oracle, dg, 0, pk, sg, 1), v["name"]
             seen[1] += 1
     assert seen[0] >= 10 and seen[1] >= 3
+
+
+@pytest.mark.parametrize("n,shards", [(1, 3), (65, 2), (200, 3), (300, 8), (129, 2)])
+def test_one_combination_cut_over_shards_equals_the_whole(emu, oracle, n, shards):
+    """SURVEY.md 8e "batch-MSM mode" on the CPU (the functions hs_rlc.hip / hs_shard.hip run): every shard reduces its
+    signatures to a partial record under the call's key - coefficients drawn for positions in the WHOLE call - and the records
+    are joined and tested once.  Same verdict as the unsharded combination and as the oracle's restatement of dalek's
+    verify_batch, for valid batches, a broken equation, and a malformed signature (a shard's `failed` word reaching the join)."""
+    for shared in (True, False):
+        dg, pk, sg = synth.make_batch(n, shared=shared, cache_dir=CACHE)
+        st = 0 if shared else 32
+        assert emu.emu_rlc_verify_sharded(dg, S(st), pk, sg, S(n), KEY, shards) == 1 == oracle_verify_batch(oracle, dg, st, pk, sg, n)
+        s2 = bytearray(sg); s2[64 * (n - 1) + 33] ^= 4; s2 = bytes(s2)          # the LAST shard's last signature
+        assert emu.emu_rlc_verify_sharded(dg, S(st), pk, s2, S(n), KEY, shards) == 0 == oracle_verify_batch(oracle, dg, st, pk, s2, n)
+        s3 = bytearray(sg); s3[64 * 0 + 63] |= 0x10; s3 = bytes(s3)             # s >= L in the first shard
+        assert emu.emu_rlc_verify_sharded(dg, S(st), pk, s3, S(n), KEY, shards) == 0 == oracle_verify_batch(oracle, dg, st, pk, s3, n)
+    if n == 200:      # two signatures that would cancel if they shared a coefficient: the same tuple with s negated cannot be built, but
+        # the same tuple twice in different shards must get different coefficients - swapped halves still verify
+        dg, pk, sg = synth.make_batch(100, shared=True, cache_dir=CACHE)
+        assert emu.emu_rlc_verify_sharded(dg, S(0), pk + pk, sg + sg, S(200), KEY, shards) == 1

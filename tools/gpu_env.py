@@ -101,6 +101,23 @@ def clock_probe(idle_ms=100):
     return res or None
 
 
+def mem_latency_probe():
+    """tools/mem_latency_probe: ns per DEPENDENT 16-byte gather of one wavefront over 32 MB ... 6 GB (what the table lookups on a
+    QC's chain wait for; None when not built)."""
+    exe = os.path.join(ROOT, "tools", "mem_latency_probe")
+    if not os.path.exists(exe):
+        return None
+    txt = _run([exe], timeout=120)
+    if not txt:
+        return None
+    res = {}
+    for line in txt.splitlines():
+        m = re.match(r"\s*(\d+) MB.*?:\s+([\d.]+) ns per hop.*?([\d.]+) shader cycles per hop", line)
+        if m:
+            res["%s_MB" % m.group(1)] = {"ns_per_hop": float(m.group(2)), "cycles_per_hop": float(m.group(3))}
+    return res or None
+
+
 def snapshot(with_probe=True):
     s = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "HS_ED25519_TENANTS": os.environ.get("HS_ED25519_TENANTS"),
          "HSA_ENABLE_SDMA": os.environ.get("HSA_ENABLE_SDMA"), "host_cores": os.cpu_count()}
@@ -116,6 +133,7 @@ def snapshot(with_probe=True):
         pass
     if with_probe:
         s["lone_wavefront_clock"] = clock_probe()
+        s["dependent_gather"] = mem_latency_probe()
     return s
 
 

@@ -10,6 +10,7 @@ env_record() {      # clocks / power / partitions / the lone-wavefront clock, be
     rocm-smi --showclocks --showperflevel --showpower --showmaxpower --showcomputepartition --showmemorypartition --showsclkrange > ${O}_rocm_smi_$1.txt 2>&1
     timeout 60 tools/clock_probe 200 > ${O}_clock_probe_$1.txt 2>&1
     grep -E "cold|spaced|back2back|loaded|after" ${O}_clock_probe_$1.txt | cut -c1-170
+    timeout 120 tools/mem_latency_probe > ${O}_mem_latency_$1.txt 2>&1; cat ${O}_mem_latency_$1.txt
 }
 case $stage in
 a)  # tests of the round's first changes + the idle-context coupling probe under three hardware-queue budgets + the driver's bench
@@ -67,6 +68,23 @@ j = json.loads(open("gpurun_out/r4_c_bench_default.json.txt").read().strip().spl
 q = j.get("qc_verify_latency", {})
 print("headline %.2f M | qc cold %s cached %s | kfd %s" % (j["value"] / 1e6, q.get("p10_p50_p99_ms_device_resident"),
       q.get("committee_cached", {}).get("p10_p50_p99_ms_device_resident"), q.get("env", {}).get("kfd")))
+for r in j.get("multi_process", {}).get("rows", []): print(r)
+PY
+    ;;
+d)  # memory latency beside the clocks; the suite (sharded one-combination tests); streams-sharing-queues probe; tenants with
+    # the smaller pools: sweep + the idle-holder probe; the driver's bench
+    env_record start
+    timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    timeout 400 python tools/streamed_probe.py coupling2 > ${O}_coupling2.txt 2>&1; echo "coupling2 rc=$?"; grep "in flight" ${O}_coupling2.txt | cut -c1-160
+    timeout 600 python tools/queue_probe.py 0.6 > ${O}_queue_probe.txt 2>${O}_queue_probe.err; echo "queue_probe rc=$?"; cat ${O}_queue_probe.txt | cut -c1-200
+    timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench_default.json.txt 2>${O}_bench_default.err; echo "bench rc=$?"
+    python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r4_d_bench_default.json.txt").read().strip().splitlines()[-1])
+q = j.get("qc_verify_latency", {})
+print("headline %.2f M | qc cold %s kernel %s | cached %s kernel %s" % (j["value"] / 1e6, q.get("p10_p50_p99_ms_device_resident"), q.get("kernel_ms_device_resident"),
+      q.get("committee_cached", {}).get("p10_p50_p99_ms_device_resident"), q.get("committee_cached", {}).get("kernel_ms_device_resident")))
+print("gather", q.get("env", {}).get("dependent_gather"))
 for r in j.get("multi_process", {}).get("rows", []): print(r)
 PY
     ;;

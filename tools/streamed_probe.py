@@ -199,3 +199,55 @@ if which == "coupling":
         c = _lib.DeviceContext(64); rate("+ an idle engine context of 64 signatures (stream, tiny buffers)"); c.close()
         rate("nothing extra again")
     ks.close()
+
+if which == "coupling2":
+    # Is the "idle-context coupling" streams sharing hardware queues?  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES
+    # (16 here) hardware queues; a stream is bound when it is first used.  N extra contexts, each USED ONCE (so that its stream
+    # holds a queue) and then idle, beside four contexts that keep key-cache QCs in flight: the rate against N.
+    n = 6667
+    dev = torch.device("cuda", 0)
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir="/tmp/hs_synth")
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)] + [synth.key_seed(20_000_000 + i) for i in range(3333)]
+    t = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (dg, sg)]
+    tp = torch.frombuffer(bytearray(pk), dtype=torch.uint8).to(dev)
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+    ks = _lib.KeySet(keys)
+    sdg, spk, ssg = synth.make_batch(64, shared=True, cache_dir="/tmp/hs_synth")
+    st_ = [torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) for x in (sdg, spk, ssg)]
+    sbm = torch.zeros(8, dtype=torch.uint8, device=dev)
+
+    def rate(tag, nctx=4, reps=60):
+        ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+        bms = [torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev) for _ in range(nctx)]
+        sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        torch.cuda.synchronize(dev)
+        def call(j):
+            ctxs[j].verify_cached(ks, t[0].data_ptr(), 0, d_ki.data_ptr(), t[1].data_ptr(), n, _lib.BATCH, bms[j].data_ptr(), 0, 0)
+        for j in range(nctx):
+            call(j)
+        for s in sts:
+            s.synchronize()
+        lat = []
+        for i in range(60):
+            t0 = time.perf_counter(); call(0); sts[0].synchronize(); lat.append(time.perf_counter() - t0)
+        lat.sort()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            for j in range(nctx):
+                call(j)
+        for s in sts:
+            s.synchronize()
+        wall = time.perf_counter() - t0
+        for c in ctxs:
+            c.close()
+        print("%-64s lone p50 %.4f ms  %.1f M sig/s with four in flight" % (tag, lat[30] * 1e3, reps * nctx * n / wall / 1e6), flush=True)
+
+    for N in (0, 4, 8, 10, 11, 12, 13, 14, 16, 20, 28, 0):
+        extra = [_lib.DeviceContext(64) for _ in range(N)]
+        for c in extra:      # used once: the stream now holds its hardware queue
+            c.verify(st_[0].data_ptr(), 0, st_[1].data_ptr(), st_[2].data_ptr(), 64, _lib.BATCH, sbm.data_ptr(), 0, 0)
+        torch.cuda.synchronize(dev)
+        rate("%d extra contexts, each used once, idle (GPU_MAX_HW_QUEUES=%s)" % (N, os.environ.get("GPU_MAX_HW_QUEUES")))
+        for c in extra:
+            c.close()
+    ks.close()
