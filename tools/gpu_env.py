@@ -83,6 +83,59 @@ def kfd_params():
     return out
 
 
+def identity():
+    """WHICH box and which GPU of it: unique id, PCI location, VBIOS, firmware and driver versions, the KFD topology node's
+    properties, the NUMA node the card hangs off - whatever could tell the two 'classes of box' apart when clocks do not."""
+    out = {"uname": _run(["uname", "-r"]), "hostname": _run(["hostname"])}
+    for k in ("uname", "hostname"):
+        out[k] = out[k].strip() if out[k] else None
+    try:
+        out["amdgpu_version"] = open("/sys/module/amdgpu/version").read().strip()
+    except OSError:
+        out["amdgpu_version"] = None
+    txt = _run(["rocm-smi", "-d", "0", "--showuniqueid", "--showvbios", "--showbus", "--showserial", "--showfwinfo", "--showdriverversion", "--json"])
+    try:
+        j = json.loads(txt) if txt else {}
+        card = j.get("card0") or {}
+        out["unique_id"] = card.get("Unique ID"); out["vbios"] = card.get("VBIOS version"); out["pci_bus"] = card.get("PCI Bus")
+        out["serial"] = card.get("Serial Number")
+        out["driver"] = (j.get("system") or {}).get("Driver version")
+        out["firmware"] = {k.replace(" firmware version", ""): v for k, v in card.items() if "firmware version" in k}
+    except ValueError:
+        out["rocm_smi_raw"] = (txt or "")[:1500]
+    # the KFD topology node of the (first) GPU
+    try:
+        import glob
+        for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*")):
+            props = dict(l.split(None, 1) for l in open(node + "/properties").read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            keep = ("simd_count", "array_count", "num_xcc", "cu_per_simd_array", "max_waves_per_simd", "lds_size_in_kb", "fw_version", "sdma_fw_version",
+                    "unique_id", "location_id", "domain", "hive_id", "max_engine_clk_fcompute", "num_sdma_engines", "num_sdma_xgmi_engines", "num_cp_queues",
+                    "num_sdma_queues_per_engine", "debug_prop", "capability", "gfx_target_version")
+            out["kfd_node"] = {k: props.get(k) for k in keep if k in props}
+            banks = []
+            for b in sorted(glob.glob(node + "/mem_banks/*/properties")):
+                bp = dict(l.split(None, 1) for l in open(b).read().splitlines() if " " in l)
+                banks.append({k: bp.get(k) for k in ("heap_type", "size_in_bytes", "width", "mem_clk_max")})
+            out["kfd_mem_banks"] = banks
+            out["kfd_caches"] = len(glob.glob(node + "/caches/*"))
+            break
+    except (OSError, ValueError):
+        pass
+    try:
+        if out.get("pci_bus"):
+            out["numa_node"] = open("/sys/bus/pci/devices/%s/numa_node" % out["pci_bus"].lower()).read().strip()
+            out["pcie_link"] = open("/sys/bus/pci/devices/%s/current_link_speed" % out["pci_bus"].lower()).read().strip()
+    except OSError:
+        pass
+    try:
+        out["thp"] = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip()
+    except OSError:
+        pass
+    return out
+
+
 def clock_probe(idle_ms=100):
     """tools/clock_probe: effective MHz of a lone wavefront cold / spaced / back-to-back / under load (None when not built)."""
     exe = os.path.join(ROOT, "tools", "clock_probe")
@@ -110,11 +163,14 @@ def mem_latency_probe():
     txt = _run([exe], timeout=120)
     if not txt:
         return None
-    res = {}
+    res, cur = {}, None
     for line in txt.splitlines():
         m = re.match(r"\s*(\d+) MB.*?:\s+([\d.]+) ns per hop.*?([\d.]+) shader cycles per hop", line)
         if m:
-            res["%s_MB" % m.group(1)] = {"ns_per_hop": float(m.group(2)), "cycles_per_hop": float(m.group(3))}
+            cur = res["%s_MB" % m.group(1)] = {"ns_per_hop": float(m.group(2)), "cycles_per_hop": float(m.group(3))}
+        m = re.match(r"\s*independent gathers,\s*(\d+) wavefronts:\s+([\d.]+) lines per us", line)
+        if m and cur is not None:
+            cur["lines_per_us_%s_wavefronts" % m.group(1)] = float(m.group(2))
     return res or None
 
 
@@ -123,6 +179,7 @@ def snapshot(with_probe=True):
          "HSA_ENABLE_SDMA": os.environ.get("HSA_ENABLE_SDMA"), "host_cores": os.cpu_count()}
     s["rocm_smi"] = rocm_smi()
     s["kfd"] = kfd_params()
+    s["identity"] = identity()
     try:
         import torch
         if torch.cuda.is_available():

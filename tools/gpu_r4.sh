@@ -88,4 +88,12 @@ print("gather", q.get("env", {}).get("dependent_gather"))
 for r in j.get("multi_process", {}).get("rows", []): print(r)
 PY
     ;;
+e)  # box identity + gather throughput beside the clocks; key-table footprint probe; 3 against 4 wavefronts per SIMD for the
+    # key-cache kernel; tenants with the pools divided like the single process's; the suite
+    env_record start
+    timeout 300 python tools/cached_footprint_probe.py > ${O}_cached_footprint.md 2>${O}_cached_footprint.err; echo "footprint rc=$?"; cat ${O}_cached_footprint.md
+    timeout 500 python tools/cached_waves_ab.py > ${O}_cached_waves_ab.md 2>${O}_cached_waves_ab.err; echo "cached_waves_ab rc=$?"; cat ${O}_cached_waves_ab.md | cut -c1-220
+    timeout 600 python tools/mp_sweep.py 0.6 > ${O}_mp_sweep.txt 2>${O}_mp_sweep.err; echo "mp_sweep rc=$?"; cat ${O}_mp_sweep.txt | cut -c1-230
+    timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    ;;
 esac

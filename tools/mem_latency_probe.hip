@@ -41,6 +41,25 @@ __global__ void __launch_bounds__(64) k_chase(const uint32_t *__restrict__ buf, 
     if (x == ~0ull) out[2] = x;
 }
 
+// The throughput side: `G` wavefronts, every lane fetching INDEPENDENT random 128-byte lines (eight 16-byte loads in flight
+// per lane and step, as a key-table entry is read) - what the key-cache kernel's 6,667 x 48 lookups look like to the memory
+// system when the chip is full.  Lines per microsecond over the same footprints.
+__global__ void __launch_bounds__(64) k_gather(const uint32_t *__restrict__ buf, uint64_t lines, uint32_t steps, uint32_t *sink) {
+    uint64_t x = ((uint64_t)(blockIdx.x * 64 + threadIdx.x) * 0x9e3779b97f4a7c15ull) >> 7;
+    uint32_t acc = 0;
+    for (uint32_t s = 0; s < steps; s++) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            v[j] = *reinterpret_cast<const uint4 *>(buf + ((x >> 20) & (lines - 1)) * 32 + 4 * (j & 7));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += v[j].x ^ v[j].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main() {
     CK(hipSetDevice(0));
     int wall_khz = 0;
@@ -49,7 +68,7 @@ int main() {
     CK(hipMalloc(&d_out, 64));
     const uint32_t hops = 2000;
     printf("one wavefront, 64 lanes each on its own walk, %u dependent 16-byte loads per lane (one per 128-byte line)\n", hops);
-    const size_t sizes_mb[] = {32, 256, 2048, 6144};
+    const size_t sizes_mb[] = {2, 32, 256, 2048, 6144, 12288};
     for (size_t mb : sizes_mb) {
         uint64_t lines = (mb << 20) / 128;
         uint64_t p2 = 1; while (p2 * 2 <= lines) p2 *= 2;        // the walk needs a power of two; allocate what is asked, walk the power of two inside
@@ -68,6 +87,23 @@ int main() {
         std::sort(ns.begin(), ns.end()); std::sort(cyc.begin(), cyc.end());
         printf("%6zu MB (walk over %5.0f MB): %7.1f ns per hop (min %.1f max %.1f), %7.1f shader cycles per hop\n", mb, (double)p2 * 128 / (1 << 20),
                ns[3], ns[0], ns[6], cyc[3]);
+        // independent gathers: one wavefront per SIMD (1,024) and four (4,096), 64 x 8 lines per lane
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (unsigned G : {1024u, 4096u}) {
+            const uint32_t steps = 64;
+            std::vector<double> us;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(k_gather, dim3(G), dim3(64), 0, 0, buf, p2, steps, (uint32_t *)d_out);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); us.push_back(ms * 1e3);
+            }
+            std::sort(us.begin(), us.end());
+            const double nlines = (double)G * 64 * steps * 8;
+            printf("          independent gathers, %4u wavefronts: %8.1f lines per us (%6.1f GB/s of 128-byte lines), %.1f us per launch\n", G, nlines / us[2],
+                   nlines * 128 / us[2] / 1e3, us[2]);
+        }
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
         fflush(stdout);
         CK(hipFree(buf));
     }

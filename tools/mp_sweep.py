@@ -26,17 +26,15 @@ def row(k, shape, env, tenancy=True):
 
 row(1, (4, 8, 4), {}, False)
 row(1, (4, 32, 16), {}, False)
-row(1, (16, 16, 16), {}, False)
-for shape in ((4, 8, 4), (4, 16, 8), (2, 32, 16), (4, 32, 16), (4, 64, 16)):
-    row(4, shape, {})
-# the split of the tenant's share: one 64-CU slice with four contexts on it, or two 32-CU slices (the default) - and the
-# wide pool unconfined as in round 3
-for env in ({"HS_ED25519_POOL_PARTITIONS": "1"}, {"HS_ED25519_POOL_PARTITIONS": "1", "HS_ED25519_POOL_NARROW": "2"},
-            {"HS_ED25519_POOL_PARTITIONS": "1", "HS_ED25519_POOL_NARROW": "3"}, {"HS_ED25519_POOL_NARROW": "6", "HS_ED25519_POOL_PARTITIONS": "2"}):
-    for shape in ((4, 32, 16), (2, 32, 16)):
+# the default tenant pools (4 narrow contexts on two 32-CU slices) at bursts of four and sixteen, then other splits of the
+# tenant's 64 CUs at BOTH burst sizes (round 4's second shape, 3 contexts on one 64-CU slice, was chosen on bursts of sixteen
+# alone and lost a quarter at bursts of four)
+SPLITS = ({}, {"HS_ED25519_POOL_NARROW": "4", "HS_ED25519_POOL_PARTITIONS": "1"}, {"HS_ED25519_POOL_NARROW": "3", "HS_ED25519_POOL_PARTITIONS": "1"},
+          {"HS_ED25519_POOL_NARROW": "6", "HS_ED25519_POOL_PARTITIONS": "2"})
+for env in SPLITS:
+    for shape in ((4, 8, 4), (4, 32, 16), (1, 8, 4), (1, 32, 16)):
         row(4, shape, env)
-# hardware-queue budget per tenant
-for q in ("4", "5", "8", "16"):
-    row(4, (4, 32, 16), {"GPU_MAX_HW_QUEUES": q})
+row(4, (4, 8, 4), {}, False)
 row(4, (4, 32, 16), {}, False)
+row(2, (4, 8, 4), {})
 row(2, (4, 32, 16), {})
