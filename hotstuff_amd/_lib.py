@@ -21,8 +21,8 @@ def hw_queue_budget(tenants):
     t = max(1, min(8, int(tenants)))
     if t == 1:
         return 16
-    parts = max(1, 4 // t)
-    return (3 * parts if t <= 4 else 2) + parts + 1
+    parts = max(1, 8 // t)
+    return 2 * parts + max(1, 4 // t) + 1
 
 
 if os.environ.get("HS_ED25519_KEEP_ENV") != "1":

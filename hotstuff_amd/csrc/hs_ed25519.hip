@@ -637,7 +637,10 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
         }
     }
 }
-__global__ void __launch_bounds__(192)
+#ifndef HS_CACHED2R_WAVES
+#define HS_CACHED2R_WAVES 3             // wavefronts per SIMD the kernel is compiled for: 3 = 165 VGPRs, no scratch (4 = at most 128: A/B below)
+#endif
+__global__ void __launch_bounds__(192, HS_CACHED2R_WAVES)
 k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
                        const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                        u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
@@ -931,16 +934,19 @@ static int build_base_tables(dev_state &d) {
     return rc;
 }
 // Pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for.  The budget that matters is
-// the GPU's, not the process's: the driver's hardware scheduler runs ~32 user queues at once ACROSS ALL PROCESSES, and one
-// queue more oversubscribes its runlist - every process is then time-sliced (four tenants: 75 M verifies/s with 28 queues
-// between them, 66 M and a 1.6x spread with ONE more queue held by an idle fifth process, 0.1 - 33 M and up to 160x with 8 - 32
-// more: tools/queue_probe.py, profiles/r4_queue_probe.md).  So co-tenants take few queues and leave headroom for whatever
-// else opens the GPU (a monitoring agent, a bench harness): per tenant 3 narrow contexts on each of its 64-CU partitions
-// (the shape the sweep measured best: 77.9 M against 76.9 M for four contexts on two 32-CU halves, profiles/r4_b_mp_sweep.txt),
-// one wide context per partition, one queue for the process's own default stream - 20 queues for four tenants, 18 for two.
-static unsigned tenant_partitions(unsigned tenants) { return tenants <= 1 ? 8u : (4 / tenants < 1 ? 1u : 4 / tenants); }
-static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : (tenants <= 4 ? 3 * (int)tenant_partitions(tenants) : 2); }
-static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : (int)tenant_partitions(tenants); }
+// the GPU's, not the process's: the driver's hardware scheduler runs ~28 user queues at once ACROSS ALL PROCESSES, and one
+// queue more oversubscribes its runlist - every process is then time-sliced (four tenants with seven queues each: 75 M
+// verifies/s alone, 66 M and a 1.6x spread with ONE more queue held by an idle fifth process, 0.1 - 33 M and up to 160x with
+// 8 - 32 more: tools/queue_probe.py, profiles/r4_c_queue_probe_pools_of_7.md).  So co-tenants take few queues and leave
+// headroom for whatever else opens the GPU (a monitoring agent, a bench harness).  A tenant's pools are the single process's
+// (16 narrow contexts on eight 32-CU slices, 4 wide) divided by the tenants: for four, 4 narrow contexts on two 32-CU slices
+// - two launches per slice is what keeps two wavefronts on every SIMD for bursts of four AND of sixteen (3 contexts on one
+// 64-CU slice measured 77.9 M at bursts of sixteen but 54.6 M at bursts of four, where three half-filling launches leave the
+// SIMDs at 1.5 wavefronts: profiles/r4_b_mp_sweep.txt, r4_d) - one wide context, one queue for the process's own default
+// stream: 6 queues per tenant, 24 for four, 22 for two.
+static unsigned tenant_partitions(unsigned tenants) { return tenants <= 1 ? 8u : (8 / tenants < 1 ? 1u : 8 / tenants); }
+static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : 2 * (int)tenant_partitions(tenants); }
+static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : (4 / tenants < 1 ? 1 : 4 / (int)tenants); }
 extern "C" unsigned hs_ed25519_hw_queue_budget(unsigned tenants) {
     if (tenants < 1) tenants = 1;
     if (tenants > 8) tenants = 8;

@@ -100,9 +100,9 @@ void hs_ed25519_shutdown(void);
  * context) unless the host already set it or HS_ED25519_KEEP_ENV=1 forbids touching the environment. */
 int hs_ed25519_set_tenancy(unsigned tenants, unsigned index);
 /* The GPU_MAX_HW_QUEUES value hs_ed25519_init exports for a process that is one of `tenants` (1..8) on its GPU: 16 for a
- * process alone; for co-tenants one hardware queue per pool context + 1 (9 / 5 / 4 for 2 / 4 / 8 tenants).  The GPU's
- * hardware scheduler runs ~32 user queues at once across ALL processes; past that every process is time-sliced
- * (profiles/r4_queue_probe.md), so co-tenants keep well below it.  Pure function, no device needed - a host whose runtime
+ * process alone; for co-tenants one hardware queue per pool context + 1 (11 / 6 / 4 for 2 / 4 / 8 tenants).  The GPU's
+ * hardware scheduler runs ~28 user queues at once across ALL processes; past that every process is time-sliced
+ * (profiles/r4_c_queue_probe_pools_of_7.md), so co-tenants keep well below it.  Pure function, no device needed - a host whose runtime
  * is initialised before this library (PyTorch, hotstuff_amd/_lib.py) sets the variable itself from it. */
 unsigned hs_ed25519_hw_queue_budget(unsigned tenants);
 /* Caller-owned pinned buffers.  Memory from hs_ed25519_host_alloc is page-locked and mapped on every device

@@ -197,5 +197,5 @@ def test_wrapper_and_library_agree_on_the_hardware_queue_budget():
     lib = _lib.lib()
     for t in range(1, 9):
         assert _lib.hw_queue_budget(t) == lib.hs_ed25519_hw_queue_budget(t), t
-    assert [_lib.hw_queue_budget(t) for t in (1, 2, 4, 8)] == [16, 9, 5, 4]      # 18 / 20 / 32 queues in all: within the GPU's ~32
+    assert [_lib.hw_queue_budget(t) for t in (1, 2, 4, 8)] == [16, 11, 6, 4]      # 22 / 24 / 32 queues in all
     assert lib.hs_ed25519_hw_queue_budget(0) == 16 and lib.hs_ed25519_hw_queue_budget(99) == 4      # clamped
