@@ -565,6 +565,17 @@ k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, m
 }
 
 #endif  // HS_AB_VARIANTS
+#ifdef HS_CACHED_TRACE
+// Probe builds only (build/variant/libhs_trace.so, tools/cached_trace.py): every wavefront of k_verify_cached_lane2r writes the
+// constant-rate clock at its phase boundaries - which phase of a key-cache QC stretches when the grid grows, or between two boxes?
+__device__ unsigned long long *g_cached_trace = nullptr;
+extern "C" int hs_debug_set_cached_trace(unsigned long long *d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cached_trace), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+}
+#define HS_TRACE(slot) do { if (g_cached_trace && lane == 0) g_cached_trace[((size_t)block * 3 + wave) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define HS_TRACE(slot) do { } while (0)
+#endif
 // Two lanes per signature with the square root off the chains: a workgroup of THREE wavefronts
 // covers 64 signatures.  Wavefronts 0 and 1 run the paired addition chains (32 signatures each);
 // wavefront 2 meanwhile decompresses the 64 R's one lane each and hands (x_R, y_R, flags) over
@@ -584,6 +595,7 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
     const bool strict = (mode & HS_MODE_STRICT) != 0;
     ge_p3 acc;
     bool ok = false, active = false;
+    HS_TRACE(0);
     if (wave == 2) {
         const u32 i = block * 64 + lane;
         const u32 j = i < n ? i : n - 1;
@@ -596,6 +608,7 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
 #pragma unroll
         for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
         s_r[20][lane] = fl;
+        HS_TRACE(2);
     } else {
         const u32 i = block * 64 + wave * 32 + (lane >> 1);
         active = i < n;
@@ -610,9 +623,12 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
         const u32 fl = ks.flag[ki];
         ok = ok && known && (fl & HS_F_ONCURVE);
         if (strict) ok = ok && !(fl & HS_F_SMALL);
+        HS_TRACE(1);
         cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw);
+        HS_TRACE(2);
     }
     __syncthreads();
+    HS_TRACE(3);
     if (wave == 2) return;
     const u32 slot = wave * 32 + (lane >> 1);
     fe rx, ry;
@@ -636,6 +652,7 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 block, c
             if (bad) atomicAdd(nreject, bad);
         }
     }
+    HS_TRACE(4);
 }
 #ifndef HS_CACHED2R_WAVES
 #define HS_CACHED2R_WAVES 3             // wavefronts per SIMD the kernel is compiled for: 3 = 165 VGPRs, no scratch (4 = at most 128: A/B below)

@@ -40,6 +40,33 @@ __global__ void __launch_bounds__(64) k_chain(uint64_t *out, uint32_t seed) {
     const uint64_t w1 = wall_clock64();
     if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; out[2] = c; }
 }
+// The ISSUE side of a lone wavefront: eight INDEPENDENT multiply-add accumulators (and eight independent 32-bit adds), so that
+// nothing but the SIMD's willingness to issue from one wavefront bounds the rate - the dependent chain above measures latency,
+// which two boxes can share while their issue cadence differs.  Launched as one wavefront on the whole chip, and as a workgroup
+// of eight wavefronts (two per SIMD of one CU): cycles per instruction of ONE wavefront in each case.
+__global__ void __launch_bounds__(512) k_indep(uint64_t *out, uint32_t seed, int what) {
+    uint64_t c[8];
+    uint32_t d[8];
+    const uint32_t a = seed * 2654435761u + threadIdx.x, m = seed | 1;
+    for (int i = 0; i < 8; i++) { c[i] = a + i; d[i] = a ^ i; }
+    __syncthreads();
+    const uint64_t t0 = clock64();
+    if (what == 0) {
+        for (int it = 0; it < CHAIN_ITERS; it++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(m) : "vcc");
+        }
+    } else {
+        for (int it = 0; it < CHAIN_ITERS; it++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_add_u32 %0, %1, %0" : "+v"(d[i]) : "v"(m));
+        }
+    }
+    const uint64_t t1 = clock64();
+    uint64_t x = 0;
+    for (int i = 0; i < 8; i++) x += c[i] + d[i];
+    if ((threadIdx.x & 63) == 0) { out[8 + (threadIdx.x >> 6)] = t1 - t0; if (x == 0x1234567ull) out[7] = x; }
+}
 // the load: every SIMD busy with two wavefronts of the same instruction for a few milliseconds
 __global__ void __launch_bounds__(256) k_load(uint64_t *out, uint32_t seed, int iters) {
     uint64_t c[4];
@@ -89,7 +116,7 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
     uint64_t *d_out, h_out[4];
-    CK(hipMalloc(&d_out, 64));
+    CK(hipMalloc(&d_out, 256));
     run_chain(st, d_out, h_out, wall_khz);       // module load, first launch
     std::vector<sample> v;
     for (int i = 0; i < 8; i++) { std::this_thread::sleep_for(std::chrono::milliseconds(idle_ms)); v.push_back(run_chain(st, d_out, h_out, wall_khz)); }
@@ -110,5 +137,23 @@ int main(int argc, char **argv) {
     report("after-load", v); v.clear();
     for (int i = 0; i < 4; i++) { std::this_thread::sleep_for(std::chrono::milliseconds(idle_ms)); v.push_back(run_chain(st, d_out, h_out, wall_khz)); }
     report("cold-again", v);
+    // issue cadence of one wavefront: alone on the chip / one of two on its SIMD
+    for (int what = 0; what < 2; what++) {
+        for (int waves : {1, 8}) {
+            std::vector<double> cpi;
+            for (int rep = 0; rep < 9; rep++) {
+                hipLaunchKernelGGL(k_indep, dim3(1), dim3(64 * waves), 0, st, d_out, 7u, what);
+                CK(hipStreamSynchronize(st));
+                uint64_t h[16];
+                CK(hipMemcpy(h, d_out, 128, hipMemcpyDeviceToHost));
+                double worst = 0;
+                for (int w = 0; w < waves; w++) worst = std::max(worst, (double)h[8 + w] / (8.0 * CHAIN_ITERS));
+                cpi.push_back(worst);
+            }
+            std::sort(cpi.begin(), cpi.end());
+            printf("issue      %-14s independent x8, %d wavefront%s in one workgroup (%s): %.2f cycles per instruction of one wavefront (min %.2f max %.2f)\n",
+                   what == 0 ? "v_mad_u64_u32" : "v_add_u32", waves, waves > 1 ? "s" : "", waves > 1 ? "two per SIMD" : "alone on the chip", cpi[4], cpi[0], cpi[8]);
+        }
+    }
     return 0;
 }

@@ -151,6 +151,9 @@ def clock_probe(idle_ms=100):
             res[m.group(1)] = {"chain_us": float(m.group(2)), "mhz": float(m.group(3)), "cycles_per_instruction": float(m.group(4))}
         elif line.startswith("device 0"):
             res["device"] = line.strip()
+        m = re.match(r"issue\s+(\S+)\s+independent x8, (\d+) wavefront.*?:\s+([\d.]+) cycles per instruction", line)
+        if m:
+            res.setdefault("issue_cycles_per_instruction", {})["%s_%s_wavefronts" % (m.group(1), m.group(2))] = float(m.group(3))
     return res or None
 
 

@@ -9,8 +9,27 @@ env_record() {      # clocks / power / partitions / the lone-wavefront clock, be
     python tools/gpu_env.py > ${O}_env_$1.json 2>${O}_env_$1.err
     rocm-smi --showclocks --showperflevel --showpower --showmaxpower --showcomputepartition --showmemorypartition --showsclkrange > ${O}_rocm_smi_$1.txt 2>&1
     timeout 60 tools/clock_probe 200 > ${O}_clock_probe_$1.txt 2>&1
-    grep -E "cold|spaced|back2back|loaded|after" ${O}_clock_probe_$1.txt | cut -c1-170
-    timeout 120 tools/mem_latency_probe > ${O}_mem_latency_$1.txt 2>&1; cat ${O}_mem_latency_$1.txt
+    grep -E "cold|spaced|back2back|loaded|after|issue" ${O}_clock_probe_$1.txt | cut -c1-170
+    timeout 120 tools/mem_latency_probe > ${O}_mem_latency_$1.txt 2>&1; grep -v independent ${O}_mem_latency_$1.txt
+    timeout 60 tools/placement_probe > ${O}_placement_$1.txt 2>&1; head -3 ${O}_placement_$1.txt | cut -c1-330
+    timeout 60 tools/ifetch_probe > ${O}_ifetch_$1.txt 2>&1; cat ${O}_ifetch_$1.txt | cut -c1-200
+    timeout 200 python tools/cached_trace.py > ${O}_cached_trace_$1.md 2>&1; cat ${O}_cached_trace_$1.md | cut -c1-300
+    timeout 120 python tools/qc_marker.py > ${O}_qc_marker_$1.json 2>${O}_qc_marker_$1.err; echo "class marker: $(cat ${O}_qc_marker_$1.json)"
+}
+pmc_record() {      # SQ / instruction-cache counters of the two QC kernels (lone calls of 6,667 signatures), two passes
+    for pass in sq:"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_IFETCH SQ_WAVES GRBM_GUI_ACTIVE" \
+                sqc:"SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_STALL SQC_ICACHE_BUSY_CYCLES SQC_DCACHE_MISSES"; do
+        name=${pass%%:*}; ctrs=${pass#*:}
+        rm -rf /tmp/pmc_$name
+        timeout 200 rocprofv3 --pmc $ctrs -d /tmp/pmc_$name -o p -- python tools/qc_marker.py > ${O}_pmc_${name}_$1.marker.json 2> ${O}_pmc_${name}_$1.err; echo "pmc $name rc=$?"
+        db=$(find /tmp/pmc_$name -name "*results.db" | head -1)
+        [ -n "$db" ] && python tools/rocpd_pmc.py $db --by-grid k_verify_cached_lane2r k_verify_fused8 > ${O}_pmc_${name}_$1.json && python - ${O}_pmc_${name}_$1.json <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1]))
+for k, v in sorted(j.items()):
+    print(k, {c: round(x["avg_per_dispatch"]) for c, x in sorted(v.items())})
+PY
+    done
 }
 case $stage in
 a)  # tests of the round's first changes + the idle-context coupling probe under three hardware-queue budgets + the driver's bench
@@ -95,5 +114,12 @@ e)  # box identity + gather throughput beside the clocks; key-table footprint pr
     timeout 500 python tools/cached_waves_ab.py > ${O}_cached_waves_ab.md 2>${O}_cached_waves_ab.err; echo "cached_waves_ab rc=$?"; cat ${O}_cached_waves_ab.md | cut -c1-220
     timeout 600 python tools/mp_sweep.py 0.6 > ${O}_mp_sweep.txt 2>${O}_mp_sweep.err; echo "mp_sweep rc=$?"; cat ${O}_mp_sweep.txt | cut -c1-230
     timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    ;;
+env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
+    env_record only
+    ;;
+pmc)  # the QC kernels' SQ / instruction-cache counters beside the class marker (two rocprofv3 passes)
+    env_record only
+    pmc_record only
     ;;
 esac
