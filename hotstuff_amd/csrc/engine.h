@@ -116,8 +116,10 @@ int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msg
                    const u32 *d_skip = nullptr);
 // one host-pointer verification on one device slot, split so that several devices can be in flight from one thread
 struct host_job { hs_ed25519_ctx *c = nullptr; size_t n = 0; bool zc = false; };
+// gather (optional): element p of the call is signature gather[p] of `sigs` (and digest gather[p] of `digests` when they are
+// per tuple) - a routed shard is packed straight into the pinned staging, one copy instead of two; `keys` stay contiguous
 int host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
-                const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait = false);
+                const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait = false, const uint32_t *gather = nullptr);
 int host_finish(host_job &job, uint8_t *bitmap);          // 1 / 0 / <0; returns the context to its pool
 void host_abandon(host_job &job);                          // after a failed submit
 const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap (valid until finish)

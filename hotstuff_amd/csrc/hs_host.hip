@@ -200,7 +200,7 @@ extern "C" void hs_ed25519_host_free(void *p) {
 // exactly once): no copy-engine round trips, -10..20 us per call.  Above, bulk H2D / D2H copies.
 //   keys: n*32 key bytes (ks == NULL) or n uint32 indices into `ks`
 int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,
-                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait) {
+                    const void *keys, const uint8_t *sigs, size_t n, uint32_t mode, bool nowait, const uint32_t *gather) {
     job.c = nullptr; job.n = n;
     int rc = pool_get(&job.c, slot, n, nowait);
     if (rc) return rc;
@@ -212,8 +212,14 @@ int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const 
     // staging layout: [digests][keys: 32n bytes or 4n index bytes][sigs: 64n], each section 16-byte aligned
     const size_t dg_bytes = digest_stride ? 32 * n : 32, key_bytes = ks ? 4 * n : 32 * n;
     const size_t off_k = round_up(dg_bytes, 16), off_sig = round_up(off_k + key_bytes, 16), in_bytes = off_sig + 64 * n;
-    const bool own = caller_pinned(ks, digests, digest_stride, keys, sigs, n);     // caller-owned pinned buffers: no staging copy
-    if (!own) {
+    const bool own = !gather && caller_pinned(ks, digests, digest_stride, keys, sigs, n);     // caller-owned pinned buffers: no staging copy
+    if (gather) {                  // a routed shard (hs_shard.hip, keys by owner): packed here, once
+        if (digest_stride) for (size_t p = 0; p < n; p++) memcpy(c->h_in + 32 * p, digests + (size_t)32 * gather[p], 32);
+        else memcpy(c->h_in, digests, 32);
+        memcpy(c->h_in + off_k, keys, key_bytes);
+        uint8_t *dst = c->h_in + off_sig;
+        for (size_t p = 0; p < n; p++) memcpy(dst + 64 * p, sigs + (size_t)64 * gather[p], 64);
+    } else if (!own) {
         memcpy(c->h_in, digests, dg_bytes);
         memcpy(c->h_in + off_k, keys, key_bytes);
         memcpy(c->h_in + off_sig, sigs, 64 * n);

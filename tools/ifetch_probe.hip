@@ -78,7 +78,8 @@ static void masked(const char *name, const uint32_t mask[8], int wall_khz) {
     CK(hipStreamDestroy(st));
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool quick = argc > 1 && argv[1][0] == 'q';      // the class marker only: no masked placements
     CK(hipSetDevice(0));
     int wall_khz = 0;
     CK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
@@ -104,6 +105,7 @@ int main() {
                    big ? "192 KB" : "24 KB", wgs, worst[3], worst[0], worst[6], med[3]);
         }
     }
+    if (quick) return 0;
     printf("105 workgroups x 3 wavefronts of the 24 KB code on CU-masked streams:\n");
     const uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
     uint32_t m[8];

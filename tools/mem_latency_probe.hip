@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(64) k_gather(const uint32_t *__restrict__ buf,
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool quick = argc > 1 && argv[1][0] == 'q';      // three sizes, no throughput runs (bench.py's env record)
     CK(hipSetDevice(0));
     int wall_khz = 0;
     CK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
@@ -70,6 +71,7 @@ int main() {
     printf("one wavefront, 64 lanes each on its own walk, %u dependent 16-byte loads per lane (one per 128-byte line)\n", hops);
     const size_t sizes_mb[] = {2, 32, 256, 2048, 6144, 12288};
     for (size_t mb : sizes_mb) {
+        if (quick && mb != 2 && mb != 256 && mb != 6144) continue;
         uint64_t lines = (mb << 20) / 128;
         uint64_t p2 = 1; while (p2 * 2 <= lines) p2 *= 2;        // the walk needs a power of two; allocate what is asked, walk the power of two inside
         uint32_t *buf = nullptr;
@@ -90,6 +92,7 @@ int main() {
         // independent gathers: one wavefront per SIMD (1,024) and four (4,096), 64 x 8 lines per lane
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (unsigned G : {1024u, 4096u}) {
+            if (quick) break;
             const uint32_t steps = 64;
             std::vector<double> us;
             for (int rep = 0; rep < 5; rep++) {
