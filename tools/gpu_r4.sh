@@ -115,6 +115,11 @@ e)  # box identity + gather throughput beside the clocks; key-table footprint pr
     timeout 600 python tools/mp_sweep.py 0.6 > ${O}_mp_sweep.txt 2>${O}_mp_sweep.err; echo "mp_sweep rc=$?"; cat ${O}_mp_sweep.txt | cut -c1-230
     timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
     ;;
+f)  # inputs staged through LDS (coalesced, every byte once) against per-lane record loads: the suite, then the same-box A/B
+    timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
+    timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; head -4 ${O}_ifetch.txt | cut -c1-200
+    timeout 1200 python tools/staged_ab.py > ${O}_staged_ab.md 2>${O}_staged_ab.err; echo "staged_ab rc=$?"; cat ${O}_staged_ab.md | cut -c1-700
+    ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only
     ;;
