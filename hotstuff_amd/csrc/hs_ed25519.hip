@@ -93,28 +93,14 @@ k_verify(workspace ws, u32 n, u32 mode, unsigned long long *__restrict__ bitmap,
 #endif
 struct lane_batch { workspace ws; msg_src msgs; const u32 *pks, *sigs; unsigned long long *bitmap; u32 *nreject; u32 n, mode, first_p, first_v; };
 struct lane_batch_list { lane_batch b[HS_MAX_LANE_BATCHES]; u32 count; };
-__global__ void __launch_bounds__(64, 3)
-k_prepare_batches(lane_batch_list L) {
-    u32 k = 0;
-#pragma unroll
-    for (u32 t = 1; t < HS_MAX_LANE_BATCHES; t++) if (t < L.count && blockIdx.x >= L.b[t].first_p) k = t;
-    const lane_batch &B = L.b[k];
-    const u32 t = (blockIdx.x - B.first_p) * 64 + threadIdx.x;
-    if (t >= 2 * B.n) return;
-    const bool is_r = t >= B.n;
-    const u32 i = is_r ? t - B.n : t;
-    u32 msg[8];
-    if (is_r) load_msg(msg, B.msgs, i);
-    prepare_point(B.ws, i, is_r, B.pks + (size_t)8 * i, B.sigs + (size_t)16 * i, msg, B.mode);
-}
-// The same stage with the wavefront's inputs brought in COALESCED and exactly once: a wavefront is 64 A tasks or 64 R tasks
+// Stage 1 over the list, with a wavefront's inputs brought in COALESCED and exactly once: a wavefront is 64 A tasks or 64 R tasks
 // of one batch (blocks [0, ceil(n/64)) of a batch are its A blocks, the next ceil(n/64) its R blocks), reads its 64 keys
 // (2 KB) - and, an R wavefront, its 64 signatures (4 KB) and 64 digests (2 KB) - as consecutive 16-byte pieces, lane l
 // piece l, l + 64, ... (every load instruction covers one contiguous kilobyte), parks them in LDS and picks its own record
-// from there.  k_prepare_batches' per-lane record loads are dwordx4 loads at a lane stride of 32 / 64 bytes: every
-// instruction touches 64 different lines and uses 16 bytes of each, which the L2 forgives for HBM-resident inputs and
-// nothing forgives when the inputs are the pinned staging of a host call read over PCIe (uncached): the group of sixteen
-// host batches then moved 2 - 4 x its bytes across the link (bench.py `end_to_end`).
+// from there.  Per-lane record loads (k_prepare's form) are dwordx4 loads at a lane stride of 32 / 64 bytes: every instruction
+// touches 64 different lines and uses 16 bytes of each.  Same box, alternating (profiles/r4_f_staged_ab.md): HBM-resident
+// rows unchanged (the L2 forgives the strided form), host calls - whose inputs are pinned memory read over PCIe - +1 - 3.5 %,
+// and the kernel lost its 20 bytes of scratch.
 template <int WORDS>      // words per record: 8 (keys, digests) or 16 (signatures)
 __device__ __forceinline__ void stage_records(u32 *lds, const u32 *__restrict__ src, u32 first, u32 count) {
     const uint4 *g = reinterpret_cast<const uint4 *>(src + (size_t)WORDS * first);
@@ -127,7 +113,7 @@ __device__ __forceinline__ void stage_records(u32 *lds, const u32 *__restrict__ 
     }
 }
 __global__ void __launch_bounds__(64, 3)
-k_prepare_batches_staged(lane_batch_list L) {
+k_prepare_batches(lane_batch_list L) {
     __shared__ __attribute__((aligned(16))) u32 s_in[64 * 32];      // [keys 64 x 8][signatures 64 x 16][digests 64 x 8]
     u32 k = 0;
 #pragma unroll
@@ -630,11 +616,10 @@ extern "C" int hs_debug_set_cached_trace(unsigned long long *d_buf) {
 // through LDS; the chains then finish with a projective comparison instead of an inversion that both
 // lanes of a pair would execute.  Per 64 signatures: 2 x 52 K + 36 K instructions instead of 2 x 82 K.
 // `block` = this workgroup's index within its batch (64 signatures per workgroup)
-// HS_CACHED_STAGED (default): the workgroup's 64 signatures (4 KB) and per-tuple digests (2 KB) come in as consecutive
-// 16-byte pieces over all 192 lanes - every load instruction a contiguous 3 KB, every input byte fetched once - and are
-// picked out of LDS; the per-lane record loads (0) fetch the signature twice (chain pair, R wavefront) as 16-byte pieces at
-// a 64-byte stride, which is what bounded host calls through the key cache: their inputs are pinned host memory read over
-// PCIe, uncached (bench.py `end_to_end`, profiles/r4_f_staged_inputs.md).
+// HS_CACHED_STAGED (the batch-list kernel): the workgroup's 64 signatures (4 KB) and per-tuple digests (2 KB) come in as
+// consecutive 16-byte pieces over all 192 lanes - every load instruction a contiguous 3 KB, every input byte fetched once -
+// and are picked out of LDS; the per-lane record loads (false; the lone-call kernel) fetch the signature twice (chain pair, R
+// wavefront) as 16-byte pieces at a 64-byte stride (profiles/r4_f_staged_ab.md).
 #define HS_CACHED_STAGE_WORDS (64 * 24)     // [signatures 64 x 16][digests 64 x 8]
 template <bool HS_CACHED_STAGED>
 __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16,
@@ -734,43 +719,28 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u
 #ifndef HS_CACHED2R_WAVES
 #define HS_CACHED2R_WAVES 3             // wavefronts per SIMD the kernel is compiled for: 3 = 165 VGPRs, no scratch (4 = at most 128: A/B below)
 #endif
+// a lone call (the QC): per-lane record loads - the staged form's extra barrier costs the latency path 1 % (0.1232 against
+// 0.1220 ms at 6,667 signatures, host API 0.233 against 0.229 ms; profiles/r4_f_staged_ab.md)
 __global__ void __launch_bounds__(192, HS_CACHED2R_WAVES)
 k_verify_cached_lane2r(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
                        const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
                        u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
-    __shared__ __attribute__((aligned(16))) u32 s_in[HS_CACHED_STAGE_WORDS];
-    cached_lane2r_block<true>(s_r, s_in, blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, bitmap32, nreject, skip);
-}
-__global__ void __launch_bounds__(192, HS_CACHED2R_WAVES)
-k_verify_cached_lane2r_direct(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
-                              const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                              u32 *__restrict__ bitmap32, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    __shared__ u32 s_r[21][64];
     cached_lane2r_block<false>(s_r, nullptr, blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, bitmap32, nreject, skip);
 }
 // several independent small key-cache batches in one grid (hs_ed25519_verify_device_batches_cached): a 1,024-signature
-// batch is only 16 workgroups of three wavefronts here
+// batch is only 16 workgroups of three wavefronts here.  Inputs staged: host groups of four / eight +4 - 4.5 %.
 struct cached_batch { msg_src msgs; const u32 *key_idx, *sigs; u32 *bitmap32; u32 *nreject; u32 n, mode, first_block, pad; };
 struct cached_batch_list { cached_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
-template <bool STAGED>
-__device__ __forceinline__ void cached_lane2r_batches_body(u32 (*s_r)[64], u32 *s_in, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16, const cached_batch_list &L) {
-    u32 k = 0;
-#pragma unroll
-    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
-    const cached_batch &B = L.b[k];
-    cached_lane2r_block<STAGED>(s_r, s_in, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
-}
 __global__ void __launch_bounds__(192)
 k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cached_batch_list L) {
     __shared__ u32 s_r[21][64];
     __shared__ __attribute__((aligned(16))) u32 s_in[HS_CACHED_STAGE_WORDS];
-    cached_lane2r_batches_body<true>(s_r, s_in, ks, nkeys, b16, L);
-}
-__global__ void __launch_bounds__(192)
-k_verify_cached_lane2r_batches_direct(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cached_batch_list L) {
-    __shared__ u32 s_r[21][64];
-    cached_lane2r_batches_body<false>(s_r, nullptr, ks, nkeys, b16, L);
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const cached_batch &B = L.b[k];
+    cached_lane2r_block<true>(s_r, s_in, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
 }
 
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches and for long batch lists
@@ -862,8 +832,6 @@ static const size_t kLaneMinTotal = 8192;
 // With the half-size form the quad kernels hold TWO per-signature tables in LDS (40,960 B per wavefront: one wavefront per
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{32768};
-static std::atomic<bool> g_cached_staged{true};       // HS_ED25519_CACHED_STAGED=0: the key-cache kernels with per-lane record loads (A/B runs)
-static std::atomic<bool> g_prepare_staged{true};      // HS_ED25519_PREPARE_STAGED=0: k_prepare_batches' per-lane record loads instead of the LDS-staged coalesced ones (A/B runs)
 static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
 static std::atomic<bool> g_oct_split{true};            // HS_ED25519_OCT_SPLIT=0: the one-wavefront eight-lane form (k_verify_fused8) instead of the split one
 static const size_t kQuadMaxBatch = 32768;
@@ -1102,8 +1070,6 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0');
-    if (const char *e = getenv("HS_ED25519_PREPARE_STAGED")) g_prepare_staged.store(e[0] != '0');
-    if (const char *e = getenv("HS_ED25519_CACHED_STAGED")) g_cached_staged.store(e[0] != '0');
     if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
@@ -1360,7 +1326,6 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
     int rc = ctx_reserve(ctx, total, ctx->staging);
     if (rc) return rc;
     size_t done = 0, ws_off = 0;            // ws_off: padded signatures already given a workspace slice
-    const bool staged = g_prepare_staged.load();
     while (done < count) {
         lane_batch_list L;
         L.count = 0;
@@ -1376,7 +1341,7 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
             ws_off += np;
             f.pks = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap = (unsigned long long *)b.d_bitmap;
             f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode; f.first_p = pw; f.first_v = vw;
-            pw += staged ? 2 * (np / 64) : (2 * f.n + 63) / 64; vw += np / 64;
+            pw += 2 * (np / 64); vw += np / 64;          // A blocks, then R blocks
         }
         if (!L.count) continue;
         const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
@@ -1384,8 +1349,7 @@ static int enqueue_lane_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *bat
         hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
         if (ev) ctx->ev_mid[slot] = 1;
         void *a[] = { &L };
-        HS_HIP(launch1(staged ? (const void *)k_prepare_batches_staged : (const void *)k_prepare_batches, dim3(pw), dim3(64), a, st,
-                       ev ? ev[0] : nullptr, ev ? ev[1] : nullptr), "launch k_prepare_batches");
+        HS_HIP(launch1((const void *)k_prepare_batches, dim3(pw), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr), "launch k_prepare_batches");
         HS_HIP(launch1((const void *)k_verify_batches, dim3(vw), dim3(64), a, st, nullptr, ev ? ev[2] : nullptr), "launch k_verify_batches");
     }
     return 0;
@@ -1480,7 +1444,7 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
             HS_HIP(launch1((const void *)k_verify_cached_lane_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                    "launch k_verify_cached_lane_batches");
         else
-        HS_HIP(launch1(g_cached_staged.load() ? (const void *)k_verify_cached_lane2r_batches : (const void *)k_verify_cached_lane2r_batches_direct, dim3(blocks), dim3(192), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
+        HS_HIP(launch1((const void *)k_verify_cached_lane2r_batches, dim3(blocks), dim3(192), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane2r_batches");
     }
     return 0;
@@ -1670,8 +1634,7 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
     if (forced == HS_K_LANE || (forced == HS_K_AUTO && n > kCachedLane1Min))
         HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane");
     else
-        HS_HIP(launch1(g_cached_staged.load() ? (const void *)k_verify_cached_lane2r : (const void *)k_verify_cached_lane2r_direct, dim3(np / 64), dim3(192), a, st, e0, e2),
-               "launch k_verify_cached_lane2r");
+        HS_HIP(launch1((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, st, e0, e2), "launch k_verify_cached_lane2r");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,

@@ -116,9 +116,40 @@ e)  # box identity + gather throughput beside the clocks; key-table footprint pr
     timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
     ;;
 f)  # inputs staged through LDS (coalesced, every byte once) against per-lane record loads: the suite, then the same-box A/B
+    # (the HS_ED25519_PREPARE_STAGED / HS_ED25519_CACHED_STAGED switches exist at commit 8f5d7a8 only; the winners are built in since)
     timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.txt
     timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; head -4 ${O}_ifetch.txt | cut -c1-200
     timeout 1200 python tools/staged_ab.py > ${O}_staged_ab.md 2>${O}_staged_ab.err; echo "staged_ab rc=$?"; cat ${O}_staged_ab.md | cut -c1-700
+    ;;
+g)  # confirmation at the simplified kernels (staged batch lists, direct lone key-cache call): suite, smoke, rocprofv3 kernel stats of
+    # the headline, the driver's bench; then the host path against the narrow pool's shape (8 / 4 / 2 slices) with today's kernels
+    timeout 900 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" ${O}_pytest.txt | tail -3
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+    timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; sed -n 2,3p ${O}_ifetch.txt | cut -c1-120
+    timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprof rc=$?"
+    python tools/rocpd_summary.py $(find /tmp/kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench_default.json.txt 2>${O}_bench_default.err; echo "bench rc=$?"
+    python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r4_g_bench_default.json.txt").read().strip().splitlines()[-1])
+q = j.get("qc_verify_latency", {})
+print("headline %.2f M | kernels %s | qc cold %s kernel %s | cached %s kernel %s | e2e %.1f M" % (j["value"] / 1e6, j["kernels_ms"], q.get("p10_p50_p99_ms_device_resident"), q.get("kernel_ms_device_resident"),
+      q.get("committee_cached", {}).get("p10_p50_p99_ms_device_resident"), q.get("committee_cached", {}).get("kernel_ms_device_resident"), j["end_to_end"]["value"] / 1e6))
+print("cached", j["committee_cached"]["value"] / 1e6, "streamed", json.dumps(j.get("streamed_rounds"))[:300])
+for r in j.get("multi_process", {}).get("rows", []): print(r)
+PY
+    for P in 8 4 2; do
+        HS_ED25519_POOL_PARTITIONS=$P timeout 200 python tools/e2e_async.py 16x16x16 4x32x16 1x256x16 16x8x8 16x4x4 16x2x2 > ${O}_e2e_shape_p$P.txt 2>&1; cat ${O}_e2e_shape_p$P.txt | cut -c1-150
+    done
+    HS_ED25519_POOL_PARTITIONS=4 HS_ED25519_POOL_NARROW=8 timeout 200 python tools/e2e_async.py 16x16x16 1x256x16 16x8x8 > ${O}_e2e_shape_p4n8.txt 2>&1; cat ${O}_e2e_shape_p4n8.txt | cut -c1-150
+    for P in 8 4; do
+        timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu --no-extras --partitions $P 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    try: j = json.loads(l)
+    except Exception: continue
+    print('device-resident, sixteen batches per launch, $P partitions: %.2f M  kernels %s' % (j['value'] / 1e6, j['kernels_ms']))"
+    done
     ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only

@@ -1,7 +1,8 @@
 """Inputs brought in coalesced through LDS (k_prepare_batches_staged, k_verify_cached_lane2r[_batches]) against the per-lane
 record loads they replace (HS_ED25519_PREPARE_STAGED=0 / HS_ED25519_CACHED_STAGED=0 select the old kernels of the same
 library), same box, alternating: host-API rates from pinned staging read over PCIe (tools/e2e_async.py), the key-cache QC
-latency, and the HBM-resident bench rows.
+latency, and the HBM-resident bench rows.  The two switches exist at commit 8f5d7a8 only (profiles/r4_f_staged_ab.md is its
+output); since then the winners are built in: staged batch lists, per-lane loads for the lone key-cache call.
 
     python tools/staged_ab.py [quick]      (driver; every measurement runs in a subprocess of its own)"""
 import json
