@@ -315,6 +315,10 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
     if (rc) return rc;
     struct part_job { hs_ed25519_ctx *c = nullptr; u32 *d_partial = nullptr; size_t n = 0; };
     std::vector<part_job> jobs(k);
+    // destruction order matters: `guard` (declared last, destroyed first) drains every context's stream before the gather set
+    // goes back to the free list - a device may still be receiving its copy of the all-gather when slot 0 has its verdict
+    gather_set *gs = nullptr;
+    struct put_set { gather_set *&g; ~put_set() { gather_set_put(g); } } gs_guard{gs};
     struct give_back { std::vector<part_job> &j; ~give_back() { for (part_job &p : j) if (p.c) { (void)hipSetDevice(p.c->device); (void)hipStreamSynchronize(p.c->stream); pool_put(p.c); } } } guard{jobs};
     const bool rccl = s_exchange.load() == HS_ED25519_EXCHANGE_RCCL;
     int first = -1;                     // the first slot with work: it joins
@@ -322,8 +326,7 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
         size_t lo, hi;
         hs_ed25519_shard_plan(n, (unsigned)k, (unsigned)s, &lo, &hi);
         const size_t ns = hi - lo;
-        if (!ns && !(rccl && first >= 0)) continue;       // an empty shard only matters to a collective (it contributes the identity: not built - see below)
-        if (!ns) continue;
+        if (!ns) continue;       // an empty shard: with the collective asked for, the records are then fetched one by one (below)
         rc = pool_get(&jobs[s].c, s, (size_t)-1);
         if (rc) break;
         hs_ed25519_ctx *c = jobs[s].c;
@@ -355,8 +358,6 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
     std::vector<int> live;
     for (int s = 0; s < k; s++) if (jobs[s].c) live.push_back(s);
     u32 *d_flag = nullptr;
-    gather_set *gs = nullptr;
-    struct put_set { gather_set *&g; ~put_set() { gather_set_put(g); } } gs_guard{gs};
     if (rccl && (int)live.size() == k) {
         // all-gather of the 384-byte records over xGMI; slot `first` (= 0 here) joins what it received
         std::lock_guard<std::mutex> lk(s_mu);
