@@ -199,3 +199,46 @@ def test_wrapper_and_library_agree_on_the_hardware_queue_budget():
         assert _lib.hw_queue_budget(t) == lib.hs_ed25519_hw_queue_budget(t), t
     assert [_lib.hw_queue_budget(t) for t in (1, 2, 4, 8)] == [16, 11, 6, 4]      # 22 / 24 / 32 queues in all
     assert lib.hs_ed25519_hw_queue_budget(0) == 16 and lib.hs_ed25519_hw_queue_budget(99) == 4      # clamped
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """The boundary is what a Rust `extern "C"` block / bindgen / cgo would consume: include/hs_ed25519.h must compile as
+    strict C (not only as C++), and a C program written against it must link with the library and get the documented
+    answers for the calls that need no GPU: the shard plan (pure arithmetic), the small-batch policy, and - where there is
+    no GPU - a negative error code with a message from every verification entry point, never 1."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "hs_ed25519.h")
+    src = tmp_path / "client.c"
+    src.write_text('''
+#include <stdio.h>
+#include <string.h>
+#include "%s"
+int main(void) {
+    size_t lo = 0, hi = 0;
+    if (hs_ed25519_shard_plan(66667, 8, 7, &lo, &hi) != 0) return 10;
+    printf("plan %%zu %%zu\\n", lo, hi);
+    printf("min %%zu\\n", hs_ed25519_min_gpu_batch(0));
+    unsigned char d[32], pk[32], sg[64];
+    memset(d, 0, sizeof d); memset(pk, 0, sizeof pk); memset(sg, 0, sizeof sg);
+    int rc = hs_ed25519_verify_shared(d, pk, sg, 1, HS_ED25519_BATCH, NULL);
+    printf("verify %%d\\n", rc);
+    printf("error %%s\\n", hs_ed25519_last_error());
+    return 0;
+}
+''' % hdr)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wstrict-prototypes", "-fsyntax-only", str(src)], check=True)
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", str(src), "-o", str(exe), "-L" + libdir, "-l:libhs_ed25519.so", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    lo, hi = (int(x) for x in lines["plan"].split())
+    assert (lo, hi) == _lib.shard_plan(66667, 8, 7) and hi == 66667 and lo % 64 == 0
+    assert int(lines["min"]) >= 1
+    if not torch.cuda.is_available():
+        assert int(lines["verify"]) < 0 and lines["error"].strip(), lines       # not initialised / no device: an error, with a message

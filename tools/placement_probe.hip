@@ -62,6 +62,47 @@ static void report(const char *name, const std::vector<rec> &v, int waves_per_wg
            (double)(tstart_max - tmin) / wall_khz * 1e3);
 }
 
+// Two-wavefront workgroups (the split eight-lane cold kernel: wavefront 0 = the MAIN chain, ~270 us; wavefront 1 = the helper,
+// ~50 us): after the helpers have gone, how many SIMDs hold two MAIN wavefronts while a neighbour SIMD of the same CU idles -
+// under the kernel's rule (main = wavefront 0) and under other rules a workgroup could apply from what it can see (its index,
+// its wavefronts' SIMD ids); "best" = a per-CU greedy assignment with full knowledge, the bound.
+static void report_roles(const char *name, const std::vector<rec> &v) {
+    struct wgp { uint32_t cu, simd[2]; };
+    std::map<uint32_t, wgp> wg;
+    for (const rec &r : v) {
+        const uint32_t simd = (r.hw_id >> 4) & 3, cu = (r.hw_id >> 8) & 15, sh = (r.hw_id >> 12) & 1, se = (r.hw_id >> 13) & 7;
+        wgp &w = wg[r.wg]; w.cu = (r.xcc << 12) | (se << 8) | (sh << 4) | cu; w.simd[r.wave & 1] = simd;
+    }
+    const char *rules[] = { "main = wavefront 0 (the kernel)", "wavefront (wg & 1)", "wavefront ((wg >> 8) & 1)", "wavefront ((wg >> 9) & 1)",
+                            "the wavefront on the odd SIMD when (wg >> 8) is odd", "the wavefront on SIMD (wg >> 8) & 3 if it has one, else wavefront 0" };
+    for (int rule = 0; rule < 6; rule++) {
+        std::map<uint32_t, int> mains;
+        for (auto &p : wg) {
+            const uint32_t i = p.first; const wgp &w = p.second;
+            int m = 0;
+            if (rule == 1) m = i & 1; else if (rule == 2) m = (i >> 8) & 1; else if (rule == 3) m = (i >> 9) & 1;
+            else if (rule == 4) { const uint32_t want = (i >> 8) & 1; m = (w.simd[0] & 1) == want ? 0 : ((w.simd[1] & 1) == want ? 1 : 0); }
+            else if (rule == 5) { const uint32_t want = (i >> 8) & 3; m = w.simd[0] == want ? 0 : (w.simd[1] == want ? 1 : 0); }
+            mains[(w.cu << 2) | w.simd[m]]++;
+        }
+        int h[5] = {0};
+        for (auto &q : mains) h[std::min(q.second, 4)]++;
+        printf("    %-72s SIMDs holding 1 / 2 / 3 / 4+ main wavefronts: %d / %d / %d / %d\n", rules[rule], h[1], h[2], h[3], h[4]);
+    }
+    // the bound: per CU, workgroups in index order, each takes whichever of its two SIMDs holds fewer mains so far
+    std::map<uint32_t, int> mains;
+    for (auto &p : wg) { const wgp &w = p.second; const uint32_t a = (w.cu << 2) | w.simd[0], b = (w.cu << 2) | w.simd[1]; mains[mains[a] <= mains[b] ? a : b]++; }
+    int h[5] = {0};
+    for (auto &q : mains) if (q.second) h[std::min(q.second, 4)]++;
+    printf("    %-72s SIMDs holding 1 / 2 / 3 / 4+ main wavefronts: %d / %d / %d / %d\n", "greedy with full knowledge (bound)", h[1], h[2], h[3], h[4]);
+    // one CU's workgroups in index order: (workgroup: SIMD of wavefront 0, SIMD of wavefront 1)
+    const uint32_t cu0 = wg.begin()->second.cu;
+    printf("    the workgroups on one CU:");
+    for (auto &p : wg) if (p.second.cu == cu0) printf("  %u:(%u,%u)", p.first, p.second.simd[0], p.second.simd[1]);
+    printf("\n");
+    (void)name;
+}
+
 template <int LDS_WORDS>
 static void run(const char *name, unsigned wgs, unsigned threads, int wall_khz, hipStream_t st) {
     const unsigned wpw = threads / 64;
@@ -73,6 +114,7 @@ static void run(const char *name, unsigned wgs, unsigned threads, int wall_khz, 
     }
     CK(hipMemcpy(h.data(), d, sizeof(rec) * h.size(), hipMemcpyDeviceToHost));
     report(name, h, (int)wpw, wall_khz);
+    if (wpw == 2) report_roles(name, h);
     CK(hipFree(d));
 }
 
