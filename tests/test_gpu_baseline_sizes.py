@@ -119,3 +119,28 @@ def test_sliver_past_whole_rounds_of_wavefronts(oracle, n, kernel):
         expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
         ok, bm = _lib.verify_packed(dg, pk, sg, n, mode, shared=True, want_bitmap=True)
         assert not ok and bits(bm, n) == expect, "mode %d" % mode
+
+
+def test_one_call_of_a_million_signatures(oracle):
+    """Maximum-size edge: ONE host call of 1,048,653 signatures (ragged: not a multiple of 64; 16 times config 4's QC) - the
+    bulk-copy staging, a 2.7 GB workspace, whole rounds of one-lane wavefronts plus a sliver - ~0.4 % corrupted individually,
+    bit-exact against the oracle in BATCH and STRICT, and in BATCH_RLC (the combination rejects, the per-signature kernels
+    localise: BATCH's bitmap); the uncorrupted set is accepted by the combination itself."""
+    base, n = 1024, 1024 * 1024 + 77
+    dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
+    reps = (n + base - 1) // base
+    pk_t, sg_t = (pk * reps)[:32 * n], (sg * reps)[:64 * n]
+    dg2, pk_c, sg_c, bad = synth.corrupt(dg, pk_t, sg_t, n, True, rate_byte=1)
+    assert 1000 < len(bad) < n // 100
+    for mode in (_lib.BATCH, _lib.STRICT):
+        expect = oracle_verify_many(oracle, dg2, 0, pk_c, sg_c, n, mode)
+        assert 0 < sum(1 for b in expect if not b) <= len(bad)
+        ok, bm = _lib.verify_packed(dg2, pk_c, sg_c, n, mode, shared=True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect, "mode %d" % mode
+        if mode == _lib.BATCH:
+            ok, bm = _lib.verify_packed(dg2, pk_c, sg_c, n, _lib.BATCH_RLC, shared=True, want_bitmap=True)
+            assert not ok and bits(bm, n) == expect, "BATCH_RLC localisation"
+    ok, bm = _lib.verify_packed(dg, pk_t, sg_t, n, _lib.BATCH_RLC, shared=True, want_bitmap=True)
+    assert ok and all(bits(bm, n))
+    ok, _ = _lib.verify_packed(dg, pk_t, sg_t, n, _lib.STRICT, shared=True)
+    assert ok
