@@ -417,6 +417,7 @@ def ensure_init():
 # in verify_batches (two signatures per quad; elsewhere it behaves as 3).  Other variants exist
 # only in -DHS_AB_VARIANTS builds (2 quad stage 2 / two-lane inversion, 10, 13: four-lane cached forms).
 KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED, KERNEL_FUSED_PAIRS = 0, 1, 3, 4
+KERNEL_CACHED_C = 5          # key cache: chains + batched finish by compression at any size (cold calls: as KERNEL_AUTO)
 
 
 def _buf(b):

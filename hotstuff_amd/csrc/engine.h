@@ -39,7 +39,8 @@ bool engine_ready();
 }  // namespace hs
 
 // kernel choices of a context (hs_ed25519_ctx_set_kernel)
-enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3, HS_K_FUSED_PAIRS = 4 };
+enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3, HS_K_FUSED_PAIRS = 4,
+       HS_K_CACHED_C = 5 };       // key cache: chains + batched finish by compression at any size (cold calls: as HS_K_AUTO)
 
 struct hs_ed25519_ctx {
     int slot = 0, device = 0;

@@ -743,6 +743,117 @@ k_verify_cached_lane2r_batches(keyset_view ks, u32 nkeys, const u32 *__restrict_
     cached_lane2r_block<true>(s_r, s_in, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.bitmap32, B.nreject, nullptr);
 }
 
+// ---- the "c" forms: chains first, then a batched finish by compression (verify_cached.h, cfin_*) -------------------------
+// The latency kernel above spends a third of its instructions on the R wavefronts' square roots (3.4 M of 10.8 M VALU
+// instructions at 6,667 signatures, profiles/r4_boxes/box_*_pmc_sq.json).  Where a call is not alone on the chip - batch
+// lists, contexts marked concurrent, ring slots - or is large, latency is not what counts and that third can go: a
+// workgroup is TWO chain wavefronts (64 signatures, two lanes each, inputs staged through LDS) that leave R' = (X : Y : Z)
+// and the flags in the context's workspace, and a second, tiny launch finishes HS_CFIN_M signatures per lane with one
+// inversion (finish lane L of a batch takes signatures L, L + nl, L + 2 nl, ...: consecutive lanes read consecutive
+// signatures of every workspace row, and step j of a wavefront is one 64-bit word of the accept bitmap).
+template <bool STAGED>
+__device__ __forceinline__ void cached_chain2_block(u32 *s_in, u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16,
+                                                    msg_src msgs, const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
+                                                    u32 *__restrict__ fin, u32 np, const u32 *__restrict__ skip) {
+    if (skip && *skip) return;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool strict = (mode & HS_MODE_STRICT) != 0;
+    const u32 i0 = block * 64;
+    const u32 *s_sig = s_in, *s_msg = s_in + 64 * 16;
+    if (STAGED) {
+        const u32 cnt = min(64u, n - i0);
+        const uint4 *gs = reinterpret_cast<const uint4 *>(sigs + (size_t)16 * i0);
+        uint4 *ss = reinterpret_cast<uint4 *>(s_in);
+        if (threadIdx.x < cnt * 4) ss[threadIdx.x] = gs[threadIdx.x];
+        if (threadIdx.x + 128 < cnt * 4) ss[threadIdx.x + 128] = gs[threadIdx.x + 128];
+        if (msgs.stride_words) {
+            const uint4 *gm = reinterpret_cast<const uint4 *>(msgs.digests + (size_t)8 * i0);
+            uint4 *sm = reinterpret_cast<uint4 *>(s_in + 64 * 16);
+            if (threadIdx.x < cnt * 2) sm[threadIdx.x] = gm[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    const u32 i = i0 + wave * 32 + (lane >> 1);
+    const bool active = i < n;
+    const u32 j = active ? i : n - 1;
+    const u32 ki_raw = key_idx[j];
+    const bool known = ki_raw < nkeys;
+    const u32 ki = known ? ki_raw : 0;
+    u32 kw[8], sw[8], msg[8];
+    bool ok;
+    if (STAGED) {
+        if (msgs.stride_words) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) msg[t] = s_msg[8 * (j - i0) + t];
+        } else load_msg(msg, msgs, 0);
+        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, s_sig + 16 * (j - i0), msg, true, true);
+    } else {
+        load_msg(msg, msgs, j);
+        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sigs + (size_t)16 * j, msg, true, true);
+    }
+    const u32 fl = ks.flag[ki];
+    ok = ok && known && (fl & HS_F_ONCURVE);
+    if (strict) ok = ok && !(fl & HS_F_SMALL);
+    ge_p3 acc;
+    cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw);
+    if (active && !(lane & 1u)) cfin_store(fin, np, i, acc, ok);
+}
+// one wavefront of finish lanes: lanes fblock * 64 ... of a batch whose finish grid is nl lanes wide
+__device__ __forceinline__ void cached_finish_block(u32 fblock, u32 *__restrict__ fin, u32 np, u32 nl, u32 n, const u32 *__restrict__ sigs, u32 mode,
+                                                    unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    const u32 words_per_step = nl / 64;
+    if (skip && *skip) {                 // the combination already vouched for every signature (hs_rlc.hip)
+        if (threadIdx.x == 0)
+            for (u32 j = 0; j < HS_CFIN_M; j++) {
+                const u32 word = j * words_per_step + fblock, first = word * 64;
+                if (first < n) { const u32 lanes = min(64u, n - first); bitmap[word] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1); }
+            }
+        return;
+    }
+    const u32 bits = cfin_lane(fin, np, fblock * 64 + threadIdx.x, nl, n, sigs, (mode & HS_MODE_STRICT) != 0);
+    u32 bad = 0;
+#pragma unroll
+    for (u32 j = 0; j < HS_CFIN_M; j++) {
+        const u32 word = j * words_per_step + fblock, first = word * 64;
+        if (first < n) {                 // uniform over the wavefront
+            const unsigned long long mask = __ballot((bits >> j) & 1u);
+            if (threadIdx.x == 0) { bitmap[word] = mask; bad += min(64u, n - first) - (u32)__popcll(mask); }
+        }
+    }
+    if (threadIdx.x == 0 && nreject && bad) atomicAdd(nreject, bad);
+}
+__global__ void __launch_bounds__(128, HS_CACHED2R_WAVES)
+k_cached_chain2(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs, const u32 *__restrict__ key_idx,
+                const u32 *__restrict__ sigs, u32 n, u32 mode, u32 *__restrict__ fin, u32 np, const u32 *__restrict__ skip) {
+    __shared__ __attribute__((aligned(16))) u32 s_in[HS_CACHED_STAGE_WORDS];
+    cached_chain2_block<true>(s_in, blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, fin, np, skip);
+}
+__global__ void __launch_bounds__(64)
+k_cached_finish(u32 *__restrict__ fin, u32 np, u32 nl, u32 n, const u32 *__restrict__ sigs, u32 mode,
+                unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
+    cached_finish_block(blockIdx.x, fin, np, nl, n, sigs, mode, bitmap, nreject, skip);
+}
+// the same pair over a list of batches
+struct cachedc_batch { msg_src msgs; const u32 *key_idx, *sigs; unsigned long long *bitmap; u32 *nreject; u32 *fin; u32 n, mode, np, nl, first_block, first_f; };
+struct cachedc_batch_list { cachedc_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+__global__ void __launch_bounds__(128, HS_CACHED2R_WAVES)
+k_cached_chain2_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cachedc_batch_list L) {
+    __shared__ __attribute__((aligned(16))) u32 s_in[HS_CACHED_STAGE_WORDS];
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
+    const cachedc_batch &B = L.b[k];
+    cached_chain2_block<true>(s_in, blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode, B.fin, B.np, nullptr);
+}
+__global__ void __launch_bounds__(64)
+k_cached_finish_batches(cachedc_batch_list L) {
+    u32 k = 0;
+#pragma unroll
+    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_f) k = t;
+    const cachedc_batch &B = L.b[k];
+    cached_finish_block(blockIdx.x - B.first_f, B.fin, B.np, B.nl, B.n, B.sigs, B.mode, B.bitmap, B.nreject, nullptr);
+}
+
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches and for long batch lists
 // `block` = this wavefront's index within its batch (64 signatures per wavefront)
 __device__ __forceinline__ void cached_lane_block(u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
@@ -821,6 +932,14 @@ int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrid
 // kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
 // (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
 static const size_t kCachedLane1Min = 98304;
+// key cache, single calls: where the two-launch form - chains, then the batched finish by compression - takes over.  Its
+// second launch is a tail of ~0.11 ms (sixteen signatures per lane and one 254-squaring inversion on a handful of lone
+// wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
+// four calls in flight 338 -> 419 M signatures/s at 66,667, 353 / 391 -> 442 at 131,072 (317 against 339 - 350 at 32,768:
+// not yet); a LONE call 0.727 -> 0.665 ms at 262,144 (0.403 against 0.385 at 131,072: not yet).  Batch lists of small
+// batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch: the tail is as long as
+// the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
+static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{196608};
 // hs_ed25519_verify_device_batches picks its kernel by what the caller hands over at once (measured, DESIGN.md
 // section 5): up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight
 // batches that total 8,192 signatures the one-lane pair over the batch list (k_prepare_batches + k_verify_batches: the
@@ -966,7 +1085,7 @@ extern "C" int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *c, int concurrent) 
 extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
     if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_kernel: null context");
     const int old = c->kernel;
-    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED || which == HS_K_FUSED_PAIRS
+    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED || which == HS_K_FUSED_PAIRS || which == HS_K_CACHED_C
 #ifdef HS_AB_VARIANTS
         || which == 2 || which == 10 || which == 12 || which == 13
 #endif
@@ -1070,6 +1189,8 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0');
+    if (const char *e = getenv("HS_ED25519_CACHED_C_MIN")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min.store((size_t)v); }
+    if (const char *e = getenv("HS_ED25519_CACHED_C_MIN_LONE")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min_lone.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
@@ -1148,7 +1269,14 @@ extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, 
     if (k == HS_K_LANE || (k == HS_K_AUTO && count >= g_lane_min_batches.load() && count * 1024 >= kLaneMinTotal)) return "k_verify_batches";
     return k == HS_K_FUSED_PAIRS || (k == HS_K_AUTO && count >= g_pairs_min_batches.load()) ? "k_verify_fused_pairs_batches" : "k_verify_fused_batches";
 }
-extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) { return n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r"; }
+// what a LONE call of n signatures through the key cache runs (a context marked concurrent switches to k_cached_chain2 earlier)
+extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
+    return n >= g_cached_c_min_lone.load() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
+}
+static bool cached_c_form(const hs_ed25519_ctx *ctx, size_t n) {
+    if (ctx->kernel == HS_K_CACHED_C) return true;
+    return ctx->kernel == HS_K_AUTO && n >= (ctx->several_in_flight ? g_cached_c_min.load() : g_cached_c_min_lone.load());
+}
 
 // One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's
 // start/stop events) instead of bracketing it with marker packets: at 16 concurrent queues two
@@ -1420,6 +1548,48 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
     u32 nkeys = (u32)ks->nkeys;
     const u32 *p_bt = g_devs[ctx->slot].base_tab16;
     size_t done = 0;
+    if (ctx->kernel == HS_K_CACHED_C) {
+        // by selector only: chains + the batched finish over the list (k_cached_chain2_batches, k_cached_finish_batches), every
+        // batch with its own slice of the context's workspace - for lists of small batches the finish launch is a tail as long
+        // as the chains themselves (185 against 269 M verifies/s at four 1,024-signature batches per launch)
+        size_t total = 0;
+        for (size_t i = 0; i < count; i++) total += round_up(batches[i].n, 64);
+        if (total == 0) return 0;
+        int rc = ctx_reserve(ctx, total, ctx->staging);      // HS_CFIN_ROWS words per signature of workspace_words' 643
+        if (rc) return rc;
+        size_t ws_off = 0;
+        while (done < count) {
+            cachedc_batch_list L;
+            L.count = 0;
+            u32 blocks = 0, fblocks = 0;
+            for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
+                const hs_ed25519_batch &b = batches[done];
+                if (b.n == 0) continue;
+                cachedc_batch &f = L.b[L.count++];
+                rc = make_digest_src(f.msgs, b.d_digests, b.digest_stride);
+                if (rc) return rc;
+                f.key_idx = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap = (unsigned long long *)b.d_bitmap;
+                f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode;
+                f.np = (u32)round_up(b.n, 64); f.nl = (u32)round_up((b.n + HS_CFIN_M - 1) / HS_CFIN_M, 64);
+                f.fin = ctx->d_ws + (size_t)HS_CFIN_ROWS * ws_off;
+                ws_off += f.np;
+                f.first_block = blocks; f.first_f = fblocks;
+                blocks += f.np / 64; fblocks += f.nl / 64;
+            }
+            if (!L.count) continue;
+            const bool rec = ctx->ev_slots && (ctx->ev_seq++ % ctx->ev_every) == 0;
+            const size_t slot = rec ? ctx->ev_calls++ % ctx->ev_slots : 0;
+            hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
+            if (ev) ctx->ev_mid[slot] = 1;
+            void *ac[] = { &kv, &nkeys, &p_bt, &L };
+            void *af[] = { &L };
+            HS_HIP(launch1((const void *)k_cached_chain2_batches, dim3(blocks), dim3(128), ac, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr),
+                   "launch k_cached_chain2_batches");
+            HS_HIP(launch1((const void *)k_cached_finish_batches, dim3(fblocks), dim3(64), af, st, nullptr, ev ? ev[2] : nullptr),
+                   "launch k_cached_finish_batches");
+        }
+        return 0;
+    }
     while (done < count) {
         cached_batch_list L;
         L.count = 0;
@@ -1626,6 +1796,20 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
     if (ev) ctx->ev_mid[slot] = 0;
     hipEvent_t e0 = ev ? ev[0] : nullptr, e2 = ev ? ev[2] : nullptr;
     const int forced = ctx->kernel;
+    if (cached_c_form(ctx, n)) {
+        // chains, then HS_CFIN_M signatures per finish lane (verify_cached.h): R' and the flags pass through the context's workspace
+        int rc = ctx_reserve(ctx, n, ctx->staging);
+        if (rc) return rc;
+        u32 *fin = ctx->d_ws;
+        u32 nl = (u32)round_up((n + HS_CFIN_M - 1) / HS_CFIN_M, 64), np_ = np;
+        unsigned long long *p_bm64 = (unsigned long long *)d_bitmap;
+        void *ac[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &fin, &np_, &p_skip };
+        void *af[] = { &fin, &np_, &nl, &nn, &p_sg, &mode_, &p_bm64, &p_nr, &p_skip };
+        if (ev) ctx->ev_mid[slot] = 1;
+        HS_HIP(launch1((const void *)k_cached_chain2, dim3(np / 64), dim3(128), ac, st, e0, ev ? ev[1] : nullptr), "launch k_cached_chain2");
+        HS_HIP(launch1((const void *)k_cached_finish, dim3(nl / 64), dim3(64), af, st, nullptr, e2), "launch k_cached_finish");
+        return 0;
+    }
 #ifdef HS_AB_VARIANTS
     if (forced == 2) { HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane2"); return 0; }
     if (forced == 10) { HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, st, e0, e2), "launch k_verify_cached"); return 0; }

@@ -461,6 +461,86 @@ HS_Q void cached_lane2_chain(ge_p3 &acc, const u32 *atab, const u32 *b16, u32 kw
     ge_add_p3(acc, mine, other);
 }
 #endif
+// ---- finishing by compression, one inversion per HS_CFIN_M signatures ("c" forms) ----------------------------------
+// cached_finish above inverts Z per signature; the default latency kernel avoids that by having a third wavefront
+// decompress the R's beside the chains - 254 squarings either way, a third of a key-cache verification's instructions.
+// An inversion, unlike a square root, batches (Montgomery): a lane that finishes M signatures one after the other needs
+// ONE inversion and 4 multiplications per signature.  Lanes of a wavefront share their instruction stream, so the batch
+// must be sequential work of ONE lane - hence a second, tiny kernel: the chain kernel leaves every signature's R' =
+// (X : Y : Z) and its format / key flags in a structure-of-arrays workspace, and a finish lane walks HS_CFIN_M of them:
+//      pre_j = Z_0 ... Z_j  (stored);   inv = 1 / pre_{M-1};   backwards:  1/Z_j = inv pre_{j-1},  inv = inv Z_j
+// then x' = X / Z, y' = Y / Z against R's 32 bytes exactly as cached_finish does (y' == y_R mod p and the parity of x' ==
+// the sign bit, or x' == 0: equivalent to "decompress R leniently, compare as points"), Z != 0 or the signature is
+// rejected and its Z replaced by 1 in the products (fail closed, and a faulted accumulator cannot spoil its neighbours).
+// STRICT's [8]R = O test is made on R's encoded y (ge_is_small_order_affine): an accepted signature has R' == R.
+// Per signature: 5 multiplications + 1/16 inversion ~ 45 wave-instructions, against ~ 500 for a square root per signature.
+// Workspace rows (stride np = n rounded up to 64): X[10] Y[10] Z[10] flags[1] pre[10].
+#define HS_CFIN_M 16
+#define HS_CFIN_ROWS 41
+HS_HD void cfin_store(u32 *fin, u32 np, u32 i, const ge_p3 &acc, bool ok) {
+    fe x = acc.X, y = acc.Y, z = acc.Z;
+    fe_carry(x); fe_carry(y); fe_carry(z);
+#pragma unroll
+    for (int j = 0; j < 10; j++) { fin[(size_t)j * np + i] = x.v[j]; fin[(size_t)(10 + j) * np + i] = y.v[j]; fin[(size_t)(20 + j) * np + i] = z.v[j]; }
+    fin[(size_t)30 * np + i] = ok ? 1u : 0u;
+}
+HS_HD void cfin_load(fe &r, const u32 *fin, u32 np, u32 row0, u32 i) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) r.v[j] = fin[(size_t)(row0 + j) * np + i];
+}
+// One finish lane: its signatures are first, first + step, ... (at most HS_CFIN_M of them, those below n).  sigs: the batch's
+// packed signatures (R's encoding = the first 8 words of each).  Returns bit j = signature first + j step accepted.
+// Control flow is uniform: a lane past its last signature works on signature `first` again (or 0) and drops the result.
+HS_HD u32 cfin_lane(u32 *fin, u32 np, u32 first, u32 step, u32 n, const u32 *sigs, bool strict) {
+    fe pre = fe_small(1);
+#pragma nounroll
+    for (int j = 0; j < HS_CFIN_M; j++) {
+        const u32 s = first + (u32)j * step;
+        const bool valid = s < n;
+        const u32 i = valid ? s : (first < n ? first : 0u);
+        fe z; cfin_load(z, fin, np, 20, i);
+        const bool use = valid && !fe_iszero(z);
+        fe zz; fe_select(zz, z, fe_small(1), !use);
+        fe_mul(pre, pre, zz);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 10; t++) fin[(size_t)(31 + t) * np + s] = pre.v[t];
+        }
+    }
+    fe inv; fe_invert(inv, pre);
+    u32 bits = 0;
+#pragma nounroll
+    for (int j = HS_CFIN_M - 1; j >= 0; j--) {
+        const u32 s = first + (u32)j * step;
+        const bool valid = s < n;
+        const u32 i = valid ? s : (first < n ? first : 0u);
+        fe x, y, z, prev;
+        cfin_load(z, fin, np, 20, i);
+        const bool znz = !fe_iszero(z);
+        const bool use = valid && znz;
+        if (j > 0 && valid) cfin_load(prev, fin, np, 31, s - step); else prev = fe_small(1);      // valid at j implies valid at j - 1
+        fe zinv; fe_mul(zinv, inv, prev);
+        fe zz; fe_select(zz, z, fe_small(1), !use);
+        fe_mul(inv, inv, zz);
+        cfin_load(x, fin, np, 0, i); cfin_load(y, fin, np, 10, i);
+        fe_mul(x, x, zinv); fe_mul(y, y, zinv);
+        u32 renc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) renc[t] = sigs[(size_t)16 * i + t];
+        u32 xw[8], yw[8], ew[8];
+        fe_to_words(xw, x); fe_to_words(yw, y);
+        fe ye; fe_from_words(ye, renc);
+        fe_to_words(ew, ye);
+        u32 dy = 0, nz = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { dy |= yw[t] ^ ew[t]; nz |= xw[t]; }
+        bool ok = fin[(size_t)30 * np + i] != 0 && znz && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0);
+        if (strict) ok = ok && !ge_is_small_order_affine(ye);
+        if (ok && valid) bits |= 1u << j;
+    }
+    return bits;
+}
+
 // finishing against a decompressed R (one-lane forms): flags of R as in cached_quad_match_point
 HS_HD bool cached_lane_match_point(const ge_p3 &acc, const fe &rx, const fe &ry, u32 r_flags, bool strict) {
     bool ok = (r_flags & HS_F_ONCURVE) != 0;

@@ -203,7 +203,8 @@ int emu_sc_digits3(const uint8_t *x32, int8_t *digits) {
 // Every finishing form must reject an all-zero accumulator (what an arithmetic fault leaves behind:
 // it is absorbing under the addition formulas and satisfies X == x*Z, Y == y*Z trivially).
 // Bit i of the result is set when form i ACCEPTED it: 0 lane, 1 quad point match, 2 quad
-// encoding match (inversion), 3 one-lane cached finish.  Batch mode, R = (sqrt(-1), 0) / y = 0.
+// encoding match (inversion), 3 one-lane cached finish, 4 the batched finish (cfin_lane; bit 5: it spoilt a genuine
+// neighbour).  Batch mode, R = (sqrt(-1), 0) / y = 0.
 uint32_t emu_zero_accumulator_accepts(void) {
     fe zero, one; fe_0(zero); fe_1(one);
     ge_p3 acc; acc.X = acc.Y = acc.Z = acc.T = zero;
@@ -217,6 +218,18 @@ uint32_t emu_zero_accumulator_accepts(void) {
     u32 renc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // encoding of y = 0, sign 0
     if (q_quad_all(q_match_encoding(q_mul(q, q_invert(q_perm<2, 2, 2, 2>(q))), renc))) out |= 4;
     if (cached_finish(acc, renc, false)) out |= 8;
+    {   // the batched finish: a zeroed accumulator among genuine neighbours (which must still be accepted: bit 16 set = they were not)
+        const u32 np = 64;
+        std::vector<u32> fin((size_t)HS_CFIN_ROWS * np, 0), sg(16 * 3, 0);
+        ge_p3 p; ge_p1p1 t; ge_dbl(t, b); ge_p1p1_to_p3(p, t, true);          // 2B with Z != 1
+        fe zi, ax, ay; fe_invert(zi, p.Z); fe_mul(ax, p.X, zi); fe_mul(ay, p.Y, zi);
+        u32 good[8]; fe_to_words(good, ay); { u32 xw[8]; fe_to_words(xw, ax); good[7] |= (xw[0] & 1) << 31; }
+        cfin_store(fin.data(), np, 0, p, true); cfin_store(fin.data(), np, 1, acc, true); cfin_store(fin.data(), np, 2, p, true);
+        for (int i = 0; i < 8; i++) { sg[i] = good[i]; sg[16 + i] = renc[i]; sg[32 + i] = good[i]; }
+        const u32 bits = cfin_lane(fin.data(), np, 0, 1, 3, sg.data(), false);     // one lane, its three signatures in a row
+        if (bits & 2) out |= 16;
+        if ((bits & 5) != 5) out |= 32;
+    }
     return out;
 }
 // sanity of the same four forms on a genuine point: acc = 3B scaled by Z = 5, R = 3B
@@ -232,6 +245,13 @@ uint32_t emu_genuine_point_accepts(void) {
     u32 renc[8]; fe_to_words(renc, ay); { u32 xw[8]; fe_to_words(xw, ax); renc[7] |= (xw[0] & 1) << 31; }
     if (q_quad_all(q_match_encoding(q_mul(q, q_invert(q_perm<2, 2, 2, 2>(q))), renc))) out |= 4;
     if (cached_finish(p, renc, false)) out |= 8;
+    {
+        const u32 np = 64;
+        std::vector<u32> fin((size_t)HS_CFIN_ROWS * np, 0), sg(16, 0);
+        cfin_store(fin.data(), np, 0, p, true);
+        for (int i = 0; i < 8; i++) sg[i] = renc[i];
+        if (cfin_lane(fin.data(), np, 0, 64, 1, sg.data(), false) == 1u) out |= 16;
+    }
     return out;
 }
 // ---- committee key cache (verify_cached.h) ----
@@ -378,9 +398,43 @@ void emu_lane2_split_trace(const uint8_t *k32, const uint8_t *s32, int odd, int3
 // lane_form = 1: the one-lane-per-signature core (verify_cached_lane), 0: the quad core
 static int g_cached_lane_form = 0;
 void emu_cached_set_lane_form(int v) { g_cached_lane_form = v; }
+// lane_form 4: the "c" forms (k_cached_chain2 + k_cached_finish): two-lane chains leave R' and the flags in the workspace,
+// finish lanes walk HS_CFIN_M signatures each with one inversion (cfin_store / cfin_lane, verify_cached.h)
+static void emu_verify_cached_c(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys,
+                                const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
+                                uint32_t mode, uint8_t *out) {
+    if (!n) return;
+    const u32 np = (u32)((n + 63) / 64 * 64);
+    std::vector<u32> fin((size_t)HS_CFIN_ROWS * np, 0), sw32(16 * n);
+    memcpy(sw32.data(), sigs, 64 * n);
+    (void)emu_base16();
+    const bool strict = (mode & HS_MODE_STRICT) != 0;
+    for (size_t i = 0; i < n; i++) {
+        const u32 ki_raw = key_idx[i];
+        const bool known = ki_raw < nkeys;
+        const u32 ki = known ? ki_raw : 0;
+        u32 pk[8], sig[16], msg[8], kw[8], sw[8];
+        load_words(pk, pks + 32 * ki, 8); load_words(sig, sigs + 64 * i, 16); load_words(msg, msgs + msg_stride * i, 8);
+        bool ok = prepare_scalars(kw, sw, pk, sig, msg, true, true);
+        const u32 fl = flag[ki];
+        ok = ok && known && (fl & HS_F_ONCURVE);
+        if (strict) ok = ok && !(fl & HS_F_SMALL);
+        ge_p3 pa, pb, acc;
+        lane2_split_chain(pa, tab + ki * (size_t)HS_KS_KEY_WORDS, g_b16, kw, sw, false);
+        lane2_split_chain(pb, tab + ki * (size_t)HS_KS_KEY_WORDS, g_b16, kw, sw, true);
+        ge_add_p3(acc, pa, pb);
+        cfin_store(fin.data(), np, (u32)i, acc, ok);
+    }
+    const u32 nl = (u32)(((n + HS_CFIN_M - 1) / HS_CFIN_M + 63) / 64 * 64);
+    for (u32 L = 0; L < nl; L++) {
+        const u32 bits = cfin_lane(fin.data(), np, L, nl, (u32)n, sw32.data(), strict);
+        for (int j = 0; j < HS_CFIN_M; j++) { const size_t sidx = L + (size_t)j * nl; if (sidx < n) out[sidx] = (bits >> j) & 1; }
+    }
+}
 void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys, const uint32_t *btab,
                        const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
                        uint32_t mode, uint8_t *out) {
+    if (g_cached_lane_form == 4) { emu_verify_cached_c(tab, flag, pks, nkeys, msgs, msg_stride, key_idx, sigs, n, mode, out); return; }
     for (size_t i = 0; i < n; i++) {
         const u32 ki = key_idx[i];
         if (ki >= nkeys) { out[i] = 0; continue; }

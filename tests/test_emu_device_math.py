@@ -240,7 +240,7 @@ def _emu_cached(emu, keys, key_idx, msgs, stride, sigs, n, mode, lane_form=0):
     return out.raw
 
 
-@pytest.mark.parametrize("lane_form", [0, 1, 2, 3])
+@pytest.mark.parametrize("lane_form", [0, 1, 2, 3, 4])
 def test_cached_path_on_edge_vectors(emu, edge_vectors, lane_form):
     """Committee key cache algorithm (verify_cached.h: per-key window tables, 64 table additions,
     R checked through one inversion instead of a decompression): the vector's key is
@@ -283,11 +283,12 @@ def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
     assert [bool(b) for b in out.raw] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("lane_form", [0, 1, 2, 3])
+@pytest.mark.parametrize("lane_form", [0, 1, 2, 3, 4])
 def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz, lane_form):
     """lane_form 0 = quad core finishing by inversion, 1 = one lane per signature,
     2 = quad chain + separately decompressed R compared as points (the 5-wavefront kernel),
-    3 = one-lane chains + separately decompressed R (the default three-wavefront kernel)."""
+    3 = one-lane chains + separately decompressed R (the default three-wavefront kernel),
+    4 = two-lane chains, then finish lanes compressing HS_CFIN_M signatures each with one inversion (the "c" forms)."""
     vec = torsion_fuzz[:40]
     n = len(vec)
     msgs = b"".join(bytes.fromhex(v["msg"]) for v in vec)
@@ -300,12 +301,12 @@ def test_torsion_fuzz_on_cached_path(emu, torsion_fuzz, lane_form):
 def test_every_finishing_form_fails_closed_on_a_zero_accumulator(emu):
     """An all-zero accumulator is absorbing under the addition formulas and satisfies
     X == x_R * Z and Y == y_R * Z for every R; it is what a faulted doubling produced on the GPU
-    once (the v_subrev_u32_dpp trap) and every signature verified.  All four ways the
-    kernels finish must reject it - and still accept a genuine point."""
+    once (the v_subrev_u32_dpp trap) and every signature verified.  All five ways the
+    kernels finish must reject it - and still accept a genuine point (the batched finish also its genuine neighbours)."""
     import ctypes
     emu.emu_zero_accumulator_accepts.restype = ctypes.c_uint32
     emu.emu_genuine_point_accepts.restype = ctypes.c_uint32
-    assert emu.emu_genuine_point_accepts() == 0b1111
+    assert emu.emu_genuine_point_accepts() == 0b11111
     assert emu.emu_zero_accumulator_accepts() == 0
 
 

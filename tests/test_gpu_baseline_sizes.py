@@ -63,14 +63,15 @@ def test_pairs_form_vs_oracle_at_baseline_size(oracle, n):
     run.close()
 
 
-def test_one_lane_cached_kernel_reached_by_size(oracle):
-    """n = 197,632 > 98,304: hs_ed25519_verify_shared_cached dispatches k_verify_cached_lane by size.
-    1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted individually."""
+def test_large_cached_call_takes_the_batched_finish_by_size(oracle):
+    """n = 197,632 >= 196,608: hs_ed25519_verify_shared_cached dispatches the chains + batched-finish pair by size (12,352
+    finish lanes walking 16 signatures each).  1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted
+    individually."""
     base = 1024
     dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
     reps = 193
     n = base * reps
-    assert n > 98304 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane"
+    assert n > 98304 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_cached_chain2"
     pk_t, sg_t = pk * reps, sg * reps
     dg2, pk_t, sg_t, bad = synth.corrupt(dg, pk_t, sg_t, n, True, rate_byte=8)
     keys = [pk[32 * i:32 * i + 32] for i in range(base)]
@@ -105,6 +106,16 @@ def test_concurrent_hint_changes_the_form_not_the_verdicts(oracle, n):
     assert runs[2].bits(dg, pk, sg, n, _lib.BATCH_RLC, True) == expect                         # rejected by the RLC, localised behind it
     vdg, vpk, vsg = synth.make_batch(n, shared=True, cache_dir=CACHE)
     assert all(runs[2].bits(vdg, vpk, vsg, n, _lib.BATCH_RLC, True)) and runs[2].ctx.rlc_last()[0] == 1
+    if n >= 49152:
+        # the key cache follows the hint too: a context that is not alone takes two-lane chains + the batched finish by compression
+        # from 49,152 signatures (k_cached_chain2 + k_cached_finish) where a lone one keeps the R-wavefront kernel - same bits
+        keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+        ks = _lib.KeySet(keys)
+        for mode in (_lib.BATCH, _lib.STRICT):
+            expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, mode)
+            for r in runs[:2]:
+                assert r.bits(dg, None, sg, n, mode, True, keyset=ks, keys=keys) == expect
+        ks.close()
     for r in runs:
         r.close()
 

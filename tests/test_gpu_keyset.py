@@ -185,10 +185,11 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     ks.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, "cached-lane", "cached-lane2r"])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, "cached-lane", "cached-lane2r", "cached-c"])
 def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     """160 randomized torsion-mix signatures labelled by the big-int oracle, through both cold
-    kernels and both key-cache kernels (forced per context), both modes."""
+    kernels and the three key-cache forms (forced per context: one lane, two lanes + R wavefront, chains + batched finish
+    by compression), both modes."""
     vec = torsion_fuzz
     n = len(vec)
     dg = b"".join(H(v["msg"]) for v in vec)
@@ -196,7 +197,7 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     sg = b"".join(H(v["sig"]) for v in vec)
     if isinstance(kernel, str):
         ks = _lib.KeySet(keys)
-        r = DeviceRunner(n, kernel=_lib.KERNEL_LANE if kernel == "cached-lane" else _lib.KERNEL_FUSED)
+        r = DeviceRunner(n, kernel={"cached-lane": _lib.KERNEL_LANE, "cached-lane2r": _lib.KERNEL_FUSED, "cached-c": _lib.KERNEL_CACHED_C}[kernel])
         strict = r.bits(dg, None, sg, n, _lib.STRICT, False, keyset=ks, keys=keys)
         batch = r.bits(dg, None, sg, n, _lib.BATCH, False, keyset=ks, keys=keys)
         r.close()
@@ -210,11 +211,12 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, _lib.KERNEL_CACHED_C])
 def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
-    """The default cached kernel up to 98,304 signatures is the three-wavefront one (two lanes per
-    signature + concurrent R decompression); above, one lane per signature.  Force each on small
-    inputs: edge vectors in both modes and a corrupted QC vs the oracle."""
+    """The default cached kernel up to 98,304 signatures is the three-wavefront one (two lanes per signature + concurrent
+    R decompression), one lane per signature above, and for the largest calls two-lane chains + a batched finish by
+    compression (k_cached_chain2 + k_cached_finish).  Force each on small inputs: edge vectors in both modes and a
+    corrupted QC vs the oracle (700 signatures: 64 finish lanes walking 11 each)."""
     r = DeviceRunner(1024, kernel=kernel)
     n = len(edge_vectors)
     keys = [H(v["pk"]) for v in edge_vectors]

@@ -78,7 +78,7 @@ def test_every_path_respects_the_limb_bounds(emu_check, edge_vectors, torsion_fu
     ki = np.arange(k, dtype=np.uint32)
     sm, ss = b"".join(msgs[i] for i in sub), b"".join(sigs[i] for i in sub)
     out = B(k)
-    for form in (0, 1, 2, 3):
+    for form in (0, 1, 2, 3, 4):
         emu.emu_cached_set_lane_form(form)
         for mode in (0, 1):
             emu.emu_verify_cached(tab.ctypes.data_as(ctypes.c_void_p), flag.ctypes.data_as(ctypes.c_void_p), keys, S(k),

@@ -1,0 +1,102 @@
+"""Key cache: the three forms by size on one box - the latency kernel (two lanes per signature + a third wavefront decompressing
+the R's: k_verify_cached_lane2r), the one-lane kernel (k_verify_cached_lane), and the two-launch "c" form (two-lane chains,
+then sixteen signatures per finish lane compressed with one inversion: k_cached_chain2 + k_cached_finish) - p50 and kernel time
+of a LONE device-resident call and signatures/s with four contexts kept busy; then the bench's committee_cached row (batch
+lists: sixteen contexts x four 1,024-signature batches per launch) with the list default (c form) against the R-wavefront kernel.
+
+    python tools/cached_c_ab.py > profiles/r4_j_cached_c_ab.md        (synthetic sets signed on the GPU)"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+SIZES = [int(x) for x in os.environ.get("HS_SWEEP_SIZES", "1024,6667,16384,24576,32768,66667,131072,262144").split(",")]
+
+
+def sweep():
+    import torch
+    import synth
+    from hotstuff_amd import _lib
+    _lib.init(0, 8192)
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    nmax = max(SIZES)
+    seeds = b"".join(synth.key_seed(7_000_000 + i) for i in range(nmax))
+    pks = _lib.public_keys(seeds, nmax)
+    secrets = b"".join(seeds[32 * i:32 * i + 32] + pks[32 * i:32 * i + 32] for i in range(nmax))
+    dg = synth.shared_digest(5)
+    sg = _lib.sign_batch(secrets, dg, nmax, shared=True)
+    ks = _lib.KeySet([pks[32 * i:32 * i + 32] for i in range(nmax)])
+    d_dg, d_sg = t(dg), t(sg)
+    d_ki = torch.arange(nmax, dtype=torch.int32, device=dev)
+    forms = (("lane2r", _lib.KERNEL_FUSED), ("lane", _lib.KERNEL_LANE), ("c", _lib.KERNEL_CACHED_C))
+    print("| signatures | " + " | ".join("%s p50 / kernel ms" % f for f, _ in forms) + " | " + " | ".join("%s M sig/s, 4 in flight" % f for f, _ in forms) + " |")
+    print("|---|" + "---|" * (2 * len(forms)))
+    for n in SIZES:
+        row_l, row_t = [], []
+        for name, kernel in forms:
+            nctx = 4
+            ctxs = [_lib.DeviceContext(n) for _ in range(nctx)]
+            for c in ctxs:
+                c.set_kernel(kernel)
+            ctxs[0].set_profiling(64)
+            bms = [torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev) for _ in range(nctx)]
+            nrs = torch.zeros(nctx, dtype=torch.int32, device=dev)
+            sts = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+            torch.cuda.synchronize(dev)
+
+            def call(j):
+                ctxs[j].verify_cached(ks, d_dg.data_ptr(), 0, d_ki.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bms[j].data_ptr(), nrs[j:].data_ptr(), 0)
+            lat = []
+            for i in range(44):
+                sts[0].synchronize(); t0 = time.perf_counter(); call(0); sts[0].synchronize()
+                if i >= 4:
+                    lat.append(time.perf_counter() - t0)
+            assert bool((bms[0].view(torch.int64)[: n // 64] == -1).all()) and int(nrs[0].item()) == 0, (name, n)
+            a, b, k = ctxs[0].kernel_times()
+            ctxs[0].set_profiling(0)
+            for j in range(nctx):
+                call(j)
+            for s_ in sts:
+                s_.synchronize()
+            reps = 8
+            t0 = time.perf_counter()
+            for i in range(reps):
+                for j in range(nctx):
+                    call(j)
+            for s_ in sts:
+                s_.synchronize()
+            wall = time.perf_counter() - t0
+            for c in ctxs:
+                c.close()
+            lat.sort()
+            row_l.append("%.4f / %.4f" % (lat[len(lat) // 2] * 1e3, (a + b) / max(1, k)))
+            row_t.append("%.1f" % (reps * nctx * n / wall / 1e6))
+        print("| %d | %s | %s |" % (n, " | ".join(row_l), " | ".join(row_t)), flush=True)
+    ks.close()
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        return sweep()
+    print("# key cache: latency kernel / one-lane kernel / chains + batched finish by compression, same box\n")
+    o = subprocess.run([sys.executable, os.path.abspath(__file__), "sweep"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(o.stdout if o.returncode == 0 else "sweep FAILED: " + (o.stderr or o.stdout)[-800:], flush=True)
+    for name, extra in (("batch lists: default (c form)", []), ("batch lists: R-wavefront kernel (--kernel fused)", ["--kernel", "fused"])):
+        o = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-qc"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        if o.returncode != 0:
+            print("## bench, %s\nFAILED: %s" % (name, (o.stderr or o.stdout)[-600:]), flush=True)
+            continue
+        j = json.loads(o.stdout.strip().splitlines()[-1])
+        cc = j.get("committee_cached") or {}
+        print("## bench committee_cached, %s\n%.1f M verifies/s (kernels %.4f ms per launch, chain part %s), 66,667-signature call %s ms (%s)\n" % (
+            name, (cc.get("value") or 0) / 1e6, cc.get("avg_kernel_ms") or 0, cc.get("avg_chain_kernel_ms"),
+            (cc.get("large_committee") or {}).get("avg_kernel_ms"), (cc.get("large_committee") or {}).get("kernel")), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,11 @@ for l in sys.stdin:
     print('device-resident, sixteen batches per launch, $P partitions: %.2f M  kernels %s' % (j['value'] / 1e6, j['kernels_ms']))"
     done
     ;;
+j)  # key cache: chains + batched finish by compression (the "c" form) - parity first, then the three forms by size and the batch lists
+    timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; sed -n 2,3p ${O}_ifetch.txt | cut -c1-120
+    timeout 900 python -m pytest tests/test_gpu_keyset.py tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py tests/test_gpu_ring.py tests/test_gpu_rlc.py -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" ${O}_pytest.txt | tail -3; grep -E "^(FAILED|ERROR|E  )" ${O}_pytest.txt | head -20
+    timeout 1200 python tools/cached_c_ab.py > ${O}_cached_c_ab.md 2>${O}_cached_c_ab.err; echo "cached_c_ab rc=$?"; cat ${O}_cached_c_ab.md | cut -c1-400
+    ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only
     ;;
