@@ -90,6 +90,7 @@ struct dev_state {
     int live[2] = {0, 0};
     unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
+    float feed_ns = 0.f;                     // ns per 8-byte instruction a lone wavefront is fed on this GPU (k_feed_probe at init; 0 = not measured)
 };
 extern std::mutex g_mu;
 extern std::condition_variable g_cv;

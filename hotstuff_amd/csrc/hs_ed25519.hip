@@ -952,7 +952,19 @@ static const size_t kLaneMinTotal = 8192;
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{32768};
 static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
-static std::atomic<bool> g_oct_split{true};            // HS_ED25519_OCT_SPLIT=0: the one-wavefront eight-lane form (k_verify_fused8) instead of the split one
+static std::atomic<int> g_oct_split{-1};               // HS_ED25519_OCT_SPLIT=0 / 1: the one-wavefront eight-lane form (k_verify_fused8) / the split one at every size; -1 = by size and box
+// The split form (main + helper wavefront) up to half a wavefront slot per SIMD - 512 workgroups, every main and helper alone on
+// a SIMD: it wins on every box (0.276 -> 0.238 ms at 64 signatures, 0.283 -> 0.268 at 4,096 on a fast-feeding box; 0.302 ->
+// 0.259, 0.305 -> 0.278 on a slow-feeding one).  Above, mains share SIMDs with other workgroups' helpers for their first ~50 us:
+// on a slow-feeding box the split still wins (0.311 -> 0.278 ms at 6,667), on a fast-feeding one it loses (0.283 -> 0.292) -
+// profiles/r4_c_oct_split_ab.md, r4_m_oct_split_ab_fast_box.md.  feed_ns: dev_state::feed_ns (0 = unknown: treated as slow-feeding,
+// two boxes in three are).
+static bool oct_split_for(size_t n, size_t simds, float feed_ns) {
+    const int forced = g_oct_split.load();
+    if (forced >= 0) return forced != 0;
+    if (n * 2 <= simds * 8) return true;
+    return !(feed_ns > 0.f && feed_ns < 3.0f);
+}
 static const size_t kQuadMaxBatch = 32768;
 // the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
 // (enqueue_cold): -19 % on the call's p50 up to 16,384 signatures past the round (1.03 against 1.27 ms at 66,667 ... 73,728,
@@ -1134,6 +1146,37 @@ static int build_base_tables(dev_state &d) {
     if (rc) free_base_tables(d);
     return rc;
 }
+// How fast does this GPU feed a lone wavefront its instructions?  The pool's boxes come in two classes (DESIGN.md 8.1,
+// tools/ifetch_probe): 2.0 ns per 8-byte instruction on some, 4.1 ns on the others, same silicon name, clocks and firmware.
+// The one decision in the library that flips with the class is measured once per device at init (8,192 straight-line
+// instructions on one wavefront, ~30 us): the split form of the eight-lane cold kernel between 4,097 and 8,192 signatures
+// (oct_split_for).  Timed on the device with the constant-rate wall clock.
+__global__ void __launch_bounds__(64) k_feed_probe(unsigned long long *out, u32 seed) {
+    u32 x = seed + threadIdx.x;
+    unsigned long long best = ~0ull;
+    for (int pass = 0; pass < 4; pass++) {          // the first pass also warms the instruction cache: the minimum counts
+        const unsigned long long t0 = wall_clock64();
+        asm volatile(".rept 2048\n v_add_u32 %0, 0x12345, %0\n .endr" : "+v"(x));
+        const unsigned long long t1 = wall_clock64();
+        if (t1 - t0 < best) best = t1 - t0;
+    }
+    if (threadIdx.x == 0) out[0] = best;
+    if (x == 0xdeadbeefu) out[1] = x;
+}
+static void measure_feed(dev_state &d) {
+    d.feed_ns = 0.f;
+    int khz = 0;
+    unsigned long long *d_out = nullptr, h = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d.ordinal) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
+    if (hipMalloc((void **)&d_out, 16) != hipSuccess) { (void)hipGetLastError(); return; }
+    u32 seed = 1;
+    void *a[] = { &d_out, &seed };
+    if (hipLaunchKernel((const void *)k_feed_probe, dim3(1), dim3(64), a, 0, nullptr) == hipSuccess &&
+        hipMemcpy(&h, d_out, 8, hipMemcpyDeviceToHost) == hipSuccess && h && h != ~0ull)
+        d.feed_ns = (float)((double)h * 1e6 / khz / 2048.0);
+    else (void)hipGetLastError();
+    (void)hipFree(d_out);
+}
 // Pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for.  The budget that matters is
 // the GPU's, not the process's: the driver's hardware scheduler runs ~28 user queues at once ACROSS ALL PROCESSES, and one
 // queue more oversubscribes its runlist - every process is then time-sliced (four tenants with seven queues each: 75 M
@@ -1188,7 +1231,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     }
     if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
     if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
-    if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0');
+    if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0' ? 1 : 0);
     if (const char *e = getenv("HS_ED25519_CACHED_C_MIN")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_CACHED_C_MIN_LONE")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min_lone.store((size_t)v); }
     if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
@@ -1213,6 +1256,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         hipDeviceProp_t prop;
         HS_HIP(hipGetDeviceProperties(&prop, ordinals[i]), "hipGetDeviceProperties");
         devs[i].cus = (unsigned)prop.multiProcessorCount;
+        measure_feed(devs[i]);
     }
     HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
     g_devs.swap(devs);
@@ -1256,7 +1300,8 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
-    if (n <= simds * 8 && n <= g_oct_max_batch.load()) return g_oct_split.load() ? "k_verify_fused8h" : "k_verify_fused8";
+    if (n <= simds * 8 && n <= g_oct_max_batch.load())
+        return oct_split_for(n, simds, g_init.load() && !g_devs.empty() ? g_devs[0].feed_ns : 0.f) ? "k_verify_fused8h" : "k_verify_fused8";
     if (n <= g_quad_max_batch.load()) return n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3";
     const size_t tail = n % (simds * 64);       // a sliver past whole rounds of wavefronts rides in the stage-2 launch (enqueue_cold)
     return n > simds * 64 && tail && tail <= g_tail_max.load() ? "k_verify_tail" : "k_verify";
@@ -1332,7 +1377,7 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         // several whole-chip calls at once (the slots of a round ring, hs_ed25519_ctx_set_concurrent) twice the wavefronts
         // per signature cost throughput (41 against 53 M signatures/s from four ring slots): four lanes per signature then.
         if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n) {
-            if (g_oct_split.load())
+            if (oct_split_for(n, simds, g_devs[ctx->slot].feed_ns))
                 HS_HIP(launch1((const void *)k_verify_fused8h, dim3(np / 8), dim3(128), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                        "launch k_verify_fused8h");
             else

@@ -43,7 +43,8 @@ def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
         assert not ok and bits(bm, n) == expect, "cold path, mode %d" % mode
         ok, bm = ks.verify_packed(dg, packed, sg, n, mode, shared=True, want_bitmap=True)
         assert not ok and bits(bm, n) == expect, "key-cache path, mode %d" % mode
-    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() == ("k_verify_fused8h" if n <= 8192 else ("k_verify_fused" if n <= 16384 else ("k_verify_fused3" if n <= 32768 else "k_verify_tail")))
+    # 4,097 ... 8,192 signatures: the split eight-lane form on a slow-feeding box, the one-wavefront form on a fast-feeding one (measured at init)
+    assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() in (("k_verify_fused8h", "k_verify_fused8") if n <= 8192 else (("k_verify_fused" if n <= 16384 else ("k_verify_fused3" if n <= 32768 else "k_verify_tail")),))
     assert _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane2r"
     ks.close()
 
