@@ -156,6 +156,24 @@ j)  # key cache: chains + batched finish by compression (the "c" form) - parity 
     timeout 900 python -m pytest tests/test_gpu_keyset.py tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py tests/test_gpu_ring.py tests/test_gpu_rlc.py -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" ${O}_pytest.txt | tail -3; grep -E "^(FAILED|ERROR|E  )" ${O}_pytest.txt | head -20
     timeout 1200 python tools/cached_c_ab.py > ${O}_cached_c_ab.md 2>${O}_cached_c_ab.err; echo "cached_c_ab rc=$?"; cat ${O}_cached_c_ab.md | cut -c1-400
     ;;
+o)  # the round's last confirmation: suite, smoke, the driver's bench
+    timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; sed -n 2,2p ${O}_ifetch.txt | cut -c1-100
+    timeout 1200 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" ${O}_pytest.txt | tail -3
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+    timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench_default.json.txt 2>${O}_bench_default.err; echo "bench rc=$?"
+    python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r4_o_bench_default.json.txt").read().strip().splitlines()[-1])
+q = j.get("qc_verify_latency", {})
+print("headline %.2f M | kernels %s | qc cold %s kernel %s (%s) | cached %s kernel %s | e2e %.1f M" % (j["value"] / 1e6, j["kernels_ms"], q.get("p10_p50_p99_ms_device_resident"), q.get("kernel_ms_device_resident"), q.get("kernel"),
+      q.get("committee_cached", {}).get("p10_p50_p99_ms_device_resident"), q.get("committee_cached", {}).get("kernel_ms_device_resident"), j["end_to_end"]["value"] / 1e6))
+cc = j["committee_cached"]
+print("cached %.1f M (%s, %.4f ms)  large committee %s" % (cc["value"] / 1e6, cc["kernel"], cc["avg_kernel_ms"], {k: cc["large_committee"].get(k) for k in ("kernel", "avg_kernel_ms", "value")}))
+print("roofline", {k: j["roofline"].get(k) for k in ("frac", "chip_frac", "achieved", "traffic", "avg_kernel_ms")}, "int", {k: (j.get("int_roofline") or {}).get(k) for k in ("frac", "issue_frac")})
+print("cpu", {k: j["cpu_baseline"].get(k) for k in ("value", "cores", "kind")}, "rlc_ab", json.dumps(j.get("rlc_ab"))[:300])
+for r in j.get("multi_process", {}).get("rows", []): print(r)
+PY
+    ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only
     ;;
