@@ -269,6 +269,41 @@ def test_cached_path_vs_c_oracle_random(emu, oracle):
     assert not got[2] and got[:2] == oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)[:2]
 
 
+def test_batched_finish_over_two_blocks_of_finish_lanes_vs_c_oracle(emu, oracle):
+    """The "c" form's finish lanes take signatures L, L + nl, L + 2 nl, ... (cfin_lane): 1,100 signatures by 12 committee keys,
+    per-signature digests, ~30 % with one bit flipped somewhere in (digest, R, s) or pointing outside the key set - nl = 128
+    (two wavefronts of finish lanes, 9 signatures each at most, ragged tails) - both modes against the C oracle."""
+    import hashlib
+    import struct
+    import synth
+    nk, n = 12, 1100
+    keys = [synth.sign(synth.key_seed(900 + k), b"x" * 32)[0] for k in range(nk)]
+    dg = bytearray(); sg = bytearray(); pk = bytearray(); idx = []
+    for i in range(n):
+        k = i % nk
+        m = hashlib.sha512(b"emu-c" + struct.pack("<I", i)).digest()[:32]
+        _, s_ = synth.sign(synth.key_seed(900 + k), m)
+        dg += m; sg += s_; pk += keys[k]; idx.append(k)
+    for i in range(0, n, 3):
+        h = hashlib.sha512(b"emu-bad" + struct.pack("<I", i)).digest()
+        if h[0] % 4 == 0:
+            dg[32 * i + h[1] % 32] ^= 1 << (h[2] % 8)
+        elif h[0] % 4 == 1:
+            sg[64 * i + h[1] % 32] ^= 1 << (h[2] % 8)
+        elif h[0] % 4 == 2:
+            sg[64 * i + 32 + h[1] % 32] ^= 1 << (h[2] % 8)
+        else:
+            idx[i] = 77                                  # not a committee member
+    for mode in (0, 1):
+        want = bytearray(oracle_verify_many(oracle, bytes(dg), 32, bytes(pk), bytes(sg), n, mode))
+        for i in range(n):
+            if idx[i] >= nk:
+                want[i] = 0
+        got = _emu_cached(emu, b"".join(keys), idx, bytes(dg), 32, bytes(sg), n, mode, lane_form=4)
+        assert got == bytes(want)
+        assert 250 < sum(1 for b in got if not b) < 450
+
+
 @pytest.mark.parametrize("fn", ["emu_verify", "emu_verify_quad", "emu_verify_quad3", "emu_verify_oct", "emu_verify_oct_split"])
 def test_torsion_fuzz_on_device_math(emu, torsion_fuzz, fn):
     vec = torsion_fuzz
