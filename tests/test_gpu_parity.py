@@ -550,3 +550,28 @@ def test_mixed_concurrent_callers(oracle):
     assert not any(x.is_alive() for x in threads), "a caller is stuck"
     assert not errors, errors[:5]
     ks.close()
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_both_eight_lane_forms_on_any_box(oracle, edge_vectors, torsion_fuzz, split):
+    """Between 4,097 and 8,192 signatures the library picks the one-wavefront eight-lane kernel on a fast-feeding GPU and the
+    split one (main + helper wavefront) on a slow-feeding one (k_feed_probe at init), so one box exercises only one of them at
+    QC size.  Pin each through the environment in a process of its own: all labelled vectors in both modes, and a ~3 %
+    corrupted 6,667-signature QC bit-exact against the oracle."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HS_ED25519_OCT_SPLIT=split)
+    o = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oct_form_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert o.returncode == 0, o.stderr[-2000:]
+    got = json.loads(o.stdout.strip().splitlines()[-1])
+    assert got["kernel"] == ("k_verify_fused8h" if split == "1" else "k_verify_fused8")
+    vs = list(edge_vectors) + list(torsion_fuzz)
+    assert [bool(b) for b in got["strict"]] == [v["strict"] for v in vs]
+    assert [bool(b) for b in got["batch"]] == [v["cofactorless"] for v in vs]
+    m = 6667
+    qdg, qpk, qsg = synth.make_batch(m, shared=True, cache_dir=CACHE)
+    qdg, qpk, qsg, bad = synth.corrupt(qdg, qpk, qsg, m, True, rate_byte=8)
+    for mode in (_lib.BATCH, _lib.STRICT):
+        assert bytes.fromhex(got["qc"][str(mode)]) == oracle_verify_many(oracle, qdg, 0, qpk, qsg, m, mode)
