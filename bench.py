@@ -82,11 +82,12 @@ MAD_PER_VERIFY = {
 }
 MAD_PEAK_PER_S = 2.96e13    # 48.2 lane-ops/clk/CU x 256 CUs x 2.4e9 (measured, 8 waves/SIMD)
 # Total VALU issue (VERDICT r3 "Next round" #4: the fraction that actually binds).  SQ counters of the headline pair
-# (profiles/r3_pmc_sq.json: SQ_INSTS_VALU of k_prepare_batches + k_verify_batches per verification, 52.4 % of them v_mad_u64_u32)
+# (profiles/r4_p_pmc_sq_headline.json, round 4's kernels: SQ_INSTS_VALU of k_prepare_batches 1,262.9 + k_verify_batches 4,050.4 per
+# verification - round 3: 5,349.7 -, 52.8 % of them v_mad_u64_u32: 179,390 lane-operations = 2,803 wave-instructions)
 # against what 1,024 SIMDs can issue of THAT mix at the microbenchmarked best rates (profiles/r1_ubench_valu.txt, 8 wavefronts
 # per SIMD: 5.32 cycles per wave64 v_mad_u64_u32, 2.5 per plain 32-bit instruction) at 2.4 GHz.
-VALU_WAVE_INSTS_PER_VERIFY = {"k_verify_batches": 5349.7}
-MAD_SHARE_OF_VALU = 0.524
+VALU_WAVE_INSTS_PER_VERIFY = {"k_verify_batches": 5313.3}
+MAD_SHARE_OF_VALU = 0.528
 CYCLES_PER_WAVE_INST_MIX = MAD_SHARE_OF_VALU * 5.32 + (1 - MAD_SHARE_OF_VALU) * 2.5
 SIMDS, SCLK_HZ = 1024, 2.4e9
 
@@ -1140,7 +1141,7 @@ def main():
                 out["int_roofline"].update({
                     "issue_frac": round(wi_s / cap, 4), "valu_wave_insts_per_verify": VALU_WAVE_INSTS_PER_VERIFY[kname],
                     "valu_wave_insts_per_s": round(wi_s, 1), "simd_issue_capacity_per_s": round(cap, 1),
-                    "issue_note": "all VALU wave-instructions of the launch pair (SQ_INSTS_VALU, profiles/r3_pmc_sq.json; %.1f %% are "
+                    "issue_note": "all VALU wave-instructions of the launch pair (SQ_INSTS_VALU, profiles/r4_p_pmc_sq_headline.json; %.1f %% are "
                                   "v_mad_u64_u32) x value, over %d SIMDs x %.1f GHz / %.2f cycles per wave-instruction of that mix "
                                   "(profiles/r1_ubench_valu.txt): the bound that binds this kernel" % (
                                       100 * MAD_SHARE_OF_VALU, SIMDS, SCLK_HZ / 1e9, CYCLES_PER_WAVE_INST_MIX)})

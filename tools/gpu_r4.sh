@@ -174,6 +174,23 @@ print("cpu", {k: j["cpu_baseline"].get(k) for k in ("value", "cores", "kind")}, 
 for r in j.get("multi_process", {}).get("rows", []): print(r)
 PY
     ;;
+p)  # round-4 evidence beside the headline: SQ counters of the launch pair, kernel stats of the FULL default command, streamed rounds for 10 s
+    timeout 60 tools/ifetch_probe > ${O}_ifetch.txt 2>&1; sed -n 2,2p ${O}_ifetch.txt | cut -c1-100
+    rm -rf /tmp/pmc_sq; timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_sq -o p -- python bench.py --steps 3 --warmup 1 --no-extras --no-cpu > /dev/null 2> ${O}_pmc_sq.err; echo "pmc sq rc=$?"
+    python tools/rocpd_pmc.py $(find /tmp/pmc_sq -name "*results.db" | head -1) k_verify_batches k_prepare_batches > ${O}_pmc_sq_headline.json; python - <<'PY'
+import json
+j = json.load(open("gpurun_out/r4_p_pmc_sq_headline.json"))
+tot = 0
+for k, v in sorted(j.items()):
+    per = v["SQ_INSTS_VALU"]["avg_per_dispatch"] / 16384
+    tot += per
+    print(k, "VALU wave-instructions per verification %.1f" % per, {c: round(x["avg_per_dispatch"]) for c, x in v.items() if c in ("SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY")})
+print("pair: %.1f per verification" % tot)
+PY
+    rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu > ${O}_bench_under_rocprof.json.txt 2> ${O}_kt.err; echo "rocprof full rc=$?"
+    python tools/rocpd_summary.py $(find /tmp/kt -name "*results.db" | head -1) > ${O}_bench_default_kernel_stats.csv; head -14 ${O}_bench_default_kernel_stats.csv | cut -c1-60,150-
+    timeout 200 python tools/streamed_10s.py 10 > ${O}_streamed_10s.md 2>${O}_streamed.err; echo "streamed rc=$?"; cat ${O}_streamed_10s.md
+    ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only
     ;;
