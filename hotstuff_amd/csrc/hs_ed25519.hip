@@ -799,21 +799,21 @@ __device__ __forceinline__ void cached_chain2_block(u32 *s_in, u32 block, const 
     if (active && !(lane & 1u)) cfin_store(fin, np, i, acc, ok);
 }
 // one wavefront of finish lanes: lanes fblock * 64 ... of a batch whose finish grid is nl lanes wide
-__device__ __forceinline__ void cached_finish_block(u32 fblock, u32 *__restrict__ fin, u32 np, u32 nl, u32 n, const u32 *__restrict__ sigs, u32 mode,
+__device__ __forceinline__ void cached_finish_block(u32 fblock, u32 *__restrict__ fin, u32 np, u32 nl, u32 m, u32 n, const u32 *__restrict__ sigs, u32 mode,
                                                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
     const u32 words_per_step = nl / 64;
     if (skip && *skip) {                 // the combination already vouched for every signature (hs_rlc.hip)
         if (threadIdx.x == 0)
-            for (u32 j = 0; j < HS_CFIN_M; j++) {
+            for (u32 j = 0; j < m; j++) {
                 const u32 word = j * words_per_step + fblock, first = word * 64;
                 if (first < n) { const u32 lanes = min(64u, n - first); bitmap[word] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1); }
             }
         return;
     }
-    const u32 bits = cfin_lane(fin, np, fblock * 64 + threadIdx.x, nl, n, sigs, (mode & HS_MODE_STRICT) != 0);
+    const u32 bits = cfin_lane(fin, np, fblock * 64 + threadIdx.x, nl, n, sigs, (mode & HS_MODE_STRICT) != 0, (int)m);
     u32 bad = 0;
-#pragma unroll
-    for (u32 j = 0; j < HS_CFIN_M; j++) {
+#pragma nounroll
+    for (u32 j = 0; j < m; j++) {
         const u32 word = j * words_per_step + fblock, first = word * 64;
         if (first < n) {                 // uniform over the wavefront
             const unsigned long long mask = __ballot((bits >> j) & 1u);
@@ -829,13 +829,13 @@ k_cached_chain2(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src 
     cached_chain2_block<true>(s_in, blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, fin, np, skip);
 }
 __global__ void __launch_bounds__(64)
-k_cached_finish(u32 *__restrict__ fin, u32 np, u32 nl, u32 n, const u32 *__restrict__ sigs, u32 mode,
+k_cached_finish(u32 *__restrict__ fin, u32 np, u32 nl, u32 m, u32 n, const u32 *__restrict__ sigs, u32 mode,
                 unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    cached_finish_block(blockIdx.x, fin, np, nl, n, sigs, mode, bitmap, nreject, skip);
+    cached_finish_block(blockIdx.x, fin, np, nl, m, n, sigs, mode, bitmap, nreject, skip);
 }
 // the same pair over a list of batches
 struct cachedc_batch { msg_src msgs; const u32 *key_idx, *sigs; unsigned long long *bitmap; u32 *nreject; u32 *fin; u32 n, mode, np, nl, first_block, first_f; };
-struct cachedc_batch_list { cachedc_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count; };
+struct cachedc_batch_list { cachedc_batch b[HS_MAX_BATCHES_PER_LAUNCH]; u32 count, m; };
 __global__ void __launch_bounds__(128, HS_CACHED2R_WAVES)
 k_cached_chain2_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cachedc_batch_list L) {
     __shared__ __attribute__((aligned(16))) u32 s_in[HS_CACHED_STAGE_WORDS];
@@ -851,7 +851,7 @@ k_cached_finish_batches(cachedc_batch_list L) {
 #pragma unroll
     for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_f) k = t;
     const cachedc_batch &B = L.b[k];
-    cached_finish_block(blockIdx.x - B.first_f, B.fin, B.np, B.nl, B.n, B.sigs, B.mode, B.bitmap, B.nreject, nullptr);
+    cached_finish_block(blockIdx.x - B.first_f, B.fin, B.np, B.nl, L.m, B.n, B.sigs, B.mode, B.bitmap, B.nreject, nullptr);
 }
 
 // the throughput form: one lane per signature (verify_cached_lane), for the largest batches and for long batch lists
@@ -933,13 +933,14 @@ int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrid
 // (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
 static const size_t kCachedLane1Min = 98304;
 // key cache, single calls: where the two-launch form - chains, then the batched finish by compression - takes over.  Its
-// second launch is a tail of ~0.11 ms (sixteen signatures per lane and one 254-squaring inversion on a handful of lone
-// wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
-// four calls in flight 338 -> 419 M signatures/s at 66,667, 353 / 391 -> 442 at 131,072 (317 against 339 - 350 at 32,768:
-// not yet); a LONE call 0.727 -> 0.665 ms at 262,144 (0.403 against 0.385 at 131,072: not yet).  Batch lists of small
-// batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch: the tail is as long as
-// the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
-static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{196608};
+// second launch is a tail of 0.07 - 0.11 ms (four to sixteen signatures per lane and one 254-squaring inversion on a handful of
+// lone wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
+// four calls in flight 341 -> 414 M signatures/s at 49,152 - 66,667, 353 / 382 -> 436 - 441 at 131,072 (343 against 346 - 353
+// at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the one-lane kernel's 0.40 and the
+// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) - above 98,304, where the one-lane kernel used to take
+// over.  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
+// the tail is as long as the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
+static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{98305};
 // hs_ed25519_verify_device_batches picks its kernel by what the caller hands over at once (measured, DESIGN.md
 // section 5): up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight
 // batches that total 8,192 signatures the one-lane pair over the batch list (k_prepare_batches + k_verify_batches: the
@@ -1316,7 +1317,7 @@ extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, 
 }
 // what a LONE call of n signatures through the key cache runs (a context marked concurrent switches to k_cached_chain2 earlier)
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
-    return n >= g_cached_c_min_lone.load() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
+    return n >= g_cached_c_min_lone.load() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");      // (the middle case needs HS_ED25519_CACHED_C_MIN_LONE raised)
 }
 static bool cached_c_form(const hs_ed25519_ctx *ctx, size_t n) {
     if (ctx->kernel == HS_K_CACHED_C) return true;
@@ -1605,7 +1606,7 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
         size_t ws_off = 0;
         while (done < count) {
             cachedc_batch_list L;
-            L.count = 0;
+            L.count = 0; L.m = 4;
             u32 blocks = 0, fblocks = 0;
             for (; done < count && L.count < HS_MAX_BATCHES_PER_LAUNCH; done++) {
                 const hs_ed25519_batch &b = batches[done];
@@ -1615,7 +1616,7 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
                 if (rc) return rc;
                 f.key_idx = (const u32 *)b.d_pks; f.sigs = (const u32 *)b.d_sigs; f.bitmap = (unsigned long long *)b.d_bitmap;
                 f.nreject = b.d_nreject; f.n = (u32)b.n; f.mode = b.mode;
-                f.np = (u32)round_up(b.n, 64); f.nl = (u32)round_up((b.n + HS_CFIN_M - 1) / HS_CFIN_M, 64);
+                f.np = (u32)round_up(b.n, 64); f.nl = (u32)round_up((b.n + L.m - 1) / L.m, 64);
                 f.fin = ctx->d_ws + (size_t)HS_CFIN_ROWS * ws_off;
                 ws_off += f.np;
                 f.first_block = blocks; f.first_f = fblocks;
@@ -1846,10 +1847,13 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
         int rc = ctx_reserve(ctx, n, ctx->staging);
         if (rc) return rc;
         u32 *fin = ctx->d_ws;
-        u32 nl = (u32)round_up((n + HS_CFIN_M - 1) / HS_CFIN_M, 64), np_ = np;
+        // signatures per finish lane: 4 for a call that is alone (the tail is latency: 0.290 against 0.337 ms at 66,667), 8 among
+        // others (414 against 410 M signatures/s with four in flight; 16 only wins from ~131,072: 441 against 436 M)
+        u32 m = ctx->several_in_flight ? (n >= 131072 ? 16u : 8u) : 4u;
+        u32 nl = (u32)round_up((n + m - 1) / m, 64), np_ = np;
         unsigned long long *p_bm64 = (unsigned long long *)d_bitmap;
         void *ac[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &fin, &np_, &p_skip };
-        void *af[] = { &fin, &np_, &nl, &nn, &p_sg, &mode_, &p_bm64, &p_nr, &p_skip };
+        void *af[] = { &fin, &np_, &nl, &m, &nn, &p_sg, &mode_, &p_bm64, &p_nr, &p_skip };
         if (ev) ctx->ev_mid[slot] = 1;
         HS_HIP(launch1((const void *)k_cached_chain2, dim3(np / 64), dim3(128), ac, st, e0, ev ? ev[1] : nullptr), "launch k_cached_chain2");
         HS_HIP(launch1((const void *)k_cached_finish, dim3(nl / 64), dim3(64), af, st, nullptr, e2), "launch k_cached_finish");

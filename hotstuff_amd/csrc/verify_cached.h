@@ -475,7 +475,7 @@ HS_Q void cached_lane2_chain(ge_p3 &acc, const u32 *atab, const u32 *b16, u32 kw
 // STRICT's [8]R = O test is made on R's encoded y (ge_is_small_order_affine): an accepted signature has R' == R.
 // Per signature: 5 multiplications + 1/16 inversion ~ 45 wave-instructions, against ~ 500 for a square root per signature.
 // Workspace rows (stride np = n rounded up to 64): X[10] Y[10] Z[10] flags[1] pre[10].
-#define HS_CFIN_M 16
+#define HS_CFIN_M 16          // the most signatures a finish lane takes (its accept bits are a 16-bit mask); the kernels take m <= HS_CFIN_M as an argument
 #define HS_CFIN_ROWS 41
 HS_HD void cfin_store(u32 *fin, u32 np, u32 i, const ge_p3 &acc, bool ok) {
     fe x = acc.X, y = acc.Y, z = acc.Z;
@@ -491,10 +491,13 @@ HS_HD void cfin_load(fe &r, const u32 *fin, u32 np, u32 row0, u32 i) {
 // One finish lane: its signatures are first, first + step, ... (at most HS_CFIN_M of them, those below n).  sigs: the batch's
 // packed signatures (R's encoding = the first 8 words of each).  Returns bit j = signature first + j step accepted.
 // Control flow is uniform: a lane past its last signature works on signature `first` again (or 0) and drops the result.
-HS_HD u32 cfin_lane(u32 *fin, u32 np, u32 first, u32 step, u32 n, const u32 *sigs, bool strict) {
+// m: signatures per finish lane (1 ... HS_CFIN_M; uniform over the launch).  Fewer = a shorter tail (the lane's own 1,100
+// instructions per signature; the inversion's 29 K stay) for more finish wavefronts: same box, 66,667 signatures alone
+// 0.337 / 0.305 / 0.290 ms at m = 16 / 8 / 4, four in flight 410 / 414 / 410 M signatures/s; 131,072: 441 / 436 / 430 M.
+HS_HD u32 cfin_lane(u32 *fin, u32 np, u32 first, u32 step, u32 n, const u32 *sigs, bool strict, int m = HS_CFIN_M) {
     fe pre = fe_small(1);
 #pragma nounroll
-    for (int j = 0; j < HS_CFIN_M; j++) {
+    for (int j = 0; j < m; j++) {
         const u32 s = first + (u32)j * step;
         const bool valid = s < n;
         const u32 i = valid ? s : (first < n ? first : 0u);
@@ -510,7 +513,7 @@ HS_HD u32 cfin_lane(u32 *fin, u32 np, u32 first, u32 step, u32 n, const u32 *sig
     fe inv; fe_invert(inv, pre);
     u32 bits = 0;
 #pragma nounroll
-    for (int j = HS_CFIN_M - 1; j >= 0; j--) {
+    for (int j = m - 1; j >= 0; j--) {
         const u32 s = first + (u32)j * step;
         const bool valid = s < n;
         const u32 i = valid ? s : (first < n ? first : 0u);

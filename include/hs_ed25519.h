@@ -305,9 +305,9 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
 /* Per-context kernel choice, for tests and A/B measurements (the host-pointer calls always use
  * the default): 0 = by batch size (cold: eight lanes per signature up to 8,192 signatures, the fused
  * four-lanes-per-signature kernels up to 32,768, k_prepare + k_verify above; key cache: k_verify_cached_lane2r - two lanes per
- * signature and a third wavefront decompressing the R's beside them - up to 98,304 signatures and for batch lists, the one-lane
- * kernel above, and from 196,608 signatures (49,152 on a context marked concurrent) the two-launch form: two-lane chains, then
- * sixteen signatures per finish lane compressed with ONE inversion), 1 = the one-lane-per-signature kernels, 3 = the fused /
+ * signature and a third wavefront decompressing the R's beside them - up to 98,304 signatures and for batch lists; above
+ * (from 49,152 on a context marked concurrent) the two-launch form: two-lane chains, then four to sixteen signatures per finish
+ * lane compressed with ONE inversion), 1 = the one-lane-per-signature kernels, 3 = the fused /
  * two-lane + R-wavefront kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
  * the batch count (3 pins it to the one-signature-per-quad form, 1 to the one-lane pair over the
  * batch list), 5 = key cache: the two-launch form at any size, batch lists included (cold calls as 0, except that a cold batch
@@ -330,8 +330,8 @@ int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *ctx, int concurrent);
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 const char *hs_ed25519_cached_kernel_for(size_t n);        /* for a LONE n-signature key-cache call (k_verify_cached_lane2r up to 98,304
-                                                            * signatures, k_verify_cached_lane above, from 196,608 - on a context marked
-                                                            * concurrent from 49,152 - k_cached_chain2 followed by k_cached_finish) */
+                                                            * signatures; above - on a context marked concurrent from 49,152 -
+                                                            * k_cached_chain2 followed by k_cached_finish) */
 const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count);   /* hs_ed25519_verify_device_batches of `count` batches */
 
 /* ---- one call over several GPUs (BASELINE configs[3]: a 100,000-validator QC on 8 x MI355X) ----

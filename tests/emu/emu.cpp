@@ -400,6 +400,7 @@ static int g_cached_lane_form = 0;
 void emu_cached_set_lane_form(int v) { g_cached_lane_form = v; }
 // lane_form 4: the "c" forms (k_cached_chain2 + k_cached_finish): two-lane chains leave R' and the flags in the workspace,
 // finish lanes walk HS_CFIN_M signatures each with one inversion (cfin_store / cfin_lane, verify_cached.h)
+static int g_cfin_m = HS_CFIN_M;
 static void emu_verify_cached_c(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys,
                                 const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
                                 uint32_t mode, uint8_t *out) {
@@ -425,16 +426,17 @@ static void emu_verify_cached_c(const uint32_t *tab, const uint32_t *flag, const
         ge_add_p3(acc, pa, pb);
         cfin_store(fin.data(), np, (u32)i, acc, ok);
     }
-    const u32 nl = (u32)(((n + HS_CFIN_M - 1) / HS_CFIN_M + 63) / 64 * 64);
+    const u32 m = (u32)g_cfin_m;          // signatures per finish lane: 16 (form 4) or 4 (form 5), as the kernels take it
+    const u32 nl = (u32)(((n + m - 1) / m + 63) / 64 * 64);
     for (u32 L = 0; L < nl; L++) {
-        const u32 bits = cfin_lane(fin.data(), np, L, nl, (u32)n, sw32.data(), strict);
-        for (int j = 0; j < HS_CFIN_M; j++) { const size_t sidx = L + (size_t)j * nl; if (sidx < n) out[sidx] = (bits >> j) & 1; }
+        const u32 bits = cfin_lane(fin.data(), np, L, nl, (u32)n, sw32.data(), strict, (int)m);
+        for (u32 j = 0; j < m; j++) { const size_t sidx = L + (size_t)j * nl; if (sidx < n) out[sidx] = (bits >> j) & 1; }
     }
 }
 void emu_verify_cached(const uint32_t *tab, const uint32_t *flag, const uint8_t *pks, size_t nkeys, const uint32_t *btab,
                        const uint8_t *msgs, size_t msg_stride, const uint32_t *key_idx, const uint8_t *sigs, size_t n,
                        uint32_t mode, uint8_t *out) {
-    if (g_cached_lane_form == 4) { emu_verify_cached_c(tab, flag, pks, nkeys, msgs, msg_stride, key_idx, sigs, n, mode, out); return; }
+    if (g_cached_lane_form == 4 || g_cached_lane_form == 5) { g_cfin_m = g_cached_lane_form == 4 ? HS_CFIN_M : 4; emu_verify_cached_c(tab, flag, pks, nkeys, msgs, msg_stride, key_idx, sigs, n, mode, out); return; }
     for (size_t i = 0; i < n; i++) {
         const u32 ki = key_idx[i];
         if (ki >= nkeys) { out[i] = 0; continue; }

@@ -64,14 +64,14 @@ def test_pairs_form_vs_oracle_at_baseline_size(oracle, n):
     run.close()
 
 
-@pytest.mark.parametrize("reps,kernel", [(193, "k_cached_chain2"), (98, "k_verify_cached_lane")])
+@pytest.mark.parametrize("reps,kernel", [(193, "k_cached_chain2"), (98, "k_cached_chain2")])
 def test_large_cached_call_takes_the_batched_finish_by_size(oracle, reps, kernel):
-    """n = 197,632 >= 196,608: hs_ed25519_verify_shared_cached dispatches the chains + batched-finish pair by size (12,352
-    finish lanes walking 16 signatures each).  1,024 distinct committee keys, their votes tiled 193 times, ~3 % corrupted
+    """n = 197,632 and 100,352 > 98,304: hs_ed25519_verify_shared_cached dispatches the chains + batched-finish pair by size
+    (a lone call: four signatures per finish lane).  1,024 distinct committee keys, their votes tiled, ~3 % corrupted
     individually."""
     base = 1024
     dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)
-    n = base * reps          # 100,352: the one-lane kernel by size
+    n = base * reps
     assert n > 98304 and _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == kernel
     pk_t, sg_t = pk * reps, sg * reps
     dg2, pk_t, sg_t, bad = synth.corrupt(dg, pk_t, sg_t, n, True, rate_byte=8)
