@@ -1,10 +1,11 @@
 """Key cache: the three forms by size on one box - the latency kernel (two lanes per signature + a third wavefront decompressing
 the R's: k_verify_cached_lane2r), the one-lane kernel (k_verify_cached_lane), and the two-launch "c" form (two-lane chains,
-then sixteen signatures per finish lane compressed with one inversion: k_cached_chain2 + k_cached_finish) - p50 and kernel time
-of a LONE device-resident call and signatures/s with four contexts kept busy; then the bench's committee_cached row (batch
-lists: sixteen contexts x four 1,024-signature batches per launch) with the list default (c form) against the R-wavefront kernel.
+then four to sixteen signatures per finish lane compressed with one inversion: k_cached_chain2 + k_cached_finish) - p50 and
+kernel time of a LONE device-resident call and signatures/s with four contexts kept busy (marked concurrent).  The batch-list
+comparison of profiles/r4_j_cached_c_ab.md (the c form as the list default: 185 against 269 M verifies/s) was taken at commit
+9323e7c, where the lists still defaulted to it.
 
-    python tools/cached_c_ab.py > profiles/r4_j_cached_c_ab.md        (synthetic sets signed on the GPU)"""
+    python tools/cached_c_ab.py [sweep]        (synthetic sets signed on the GPU; HS_SWEEP_SIZES=a,b,c)"""
 import json
 import os
 import subprocess
@@ -87,17 +88,6 @@ def main():
     print("# key cache: latency kernel / one-lane kernel / chains + batched finish by compression, same box\n")
     o = subprocess.run([sys.executable, os.path.abspath(__file__), "sweep"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(o.stdout if o.returncode == 0 else "sweep FAILED: " + (o.stderr or o.stdout)[-800:], flush=True)
-    for name, extra in (("batch lists: default (c form)", []), ("batch lists: R-wavefront kernel (--kernel fused)", ["--kernel", "fused"])):
-        o = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-qc"] + extra,
-                           capture_output=True, text=True, timeout=600, cwd=ROOT)
-        if o.returncode != 0:
-            print("## bench, %s\nFAILED: %s" % (name, (o.stderr or o.stdout)[-600:]), flush=True)
-            continue
-        j = json.loads(o.stdout.strip().splitlines()[-1])
-        cc = j.get("committee_cached") or {}
-        print("## bench committee_cached, %s\n%.1f M verifies/s (kernels %.4f ms per launch, chain part %s), 66,667-signature call %s ms (%s)\n" % (
-            name, (cc.get("value") or 0) / 1e6, cc.get("avg_kernel_ms") or 0, cc.get("avg_chain_kernel_ms"),
-            (cc.get("large_committee") or {}).get("avg_kernel_ms"), (cc.get("large_committee") or {}).get("kernel")), flush=True)
 
 
 if __name__ == "__main__":
