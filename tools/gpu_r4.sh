@@ -191,6 +191,21 @@ PY
     python tools/rocpd_summary.py $(find /tmp/kt -name "*results.db" | head -1) > ${O}_bench_default_kernel_stats.csv; head -14 ${O}_bench_default_kernel_stats.csv | cut -c1-60,150-
     timeout 200 python tools/streamed_10s.py 10 > ${O}_streamed_10s.md 2>${O}_streamed.err; echo "streamed rc=$?"; cat ${O}_streamed_10s.md
     ;;
+s)  # sanitizer runs at the round's last code (host side built with -fsanitize=thread / address,undefined; __graft_entry__.build_sanitized)
+    for kind in tsan asan; do
+        d=build/san/$kind
+        [ -x $d/stress_host ] || { echo "no $kind build"; continue; }
+        if [ $kind = tsan ]; then export TSAN_OPTIONS="suppressions=$PWD/tests/cpp/tsan.supp history_size=4 second_deadlock_stack=1 exitcode=66 log_path=$PWD/${O}_tsan_report"
+        else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"; fi
+        timeout 60 $d/stress_host canary > ${O}_${kind}_canary.txt 2>&1; echo "$kind canary rc=$? (66 / 67 = the detector fired)"
+        rm -f ${O}_${kind}_report*
+        timeout 300 $d/stress_host 6 > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
+        PYTHONPATH=tools:tests python tests/test_gpu_cpp_mirror.py fixture /tmp/mirror_fixture.bin && timeout 200 $d/mirror_tests /tmp/mirror_fixture.bin > ${O}_${kind}_mirror.txt 2>&1; echo "$kind mirror_tests rc=$?"; grep -c "^ok" ${O}_${kind}_mirror.txt; grep "^FAIL" ${O}_${kind}_mirror.txt | head
+        unset TSAN_OPTIONS ASAN_OPTIONS UBSAN_OPTIONS
+        ls ${O}_${kind}_report* 2>/dev/null | head -5
+        grep -h "SUMMARY" ${O}_${kind}_report* 2>/dev/null | sort | uniq -c | sort -rn | head -10
+    done
+    ;;
 env)  # what box is this: clocks, identity, memory latency, wavefront placement - nothing else
     env_record only
     ;;
