@@ -937,10 +937,16 @@ static const size_t kCachedLane1Min = 98304;
 // lone wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
 // four calls in flight 341 -> 414 M signatures/s at 49,152 - 66,667, 353 / 382 -> 436 - 441 at 131,072 (343 against 346 - 353
 // at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the one-lane kernel's 0.40 and the
-// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) - above 98,304, where the one-lane kernel used to take
-// over.  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
+// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) on a fast-feeding box - above 98,304, where the one-lane
+// kernel takes over; on a slow-feeding box the one-lane kernel still wins there (profiles/r4_t_cached_c_slow_box.md).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
 // the tail is as long as the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
-static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{98305};
+// A lone call between 98,305 and 196,607 signatures follows the box (dev_state::feed_ns): on a fast-feeding GPU the two-launch form
+// (0.369 against the one-lane kernel's 0.40 ms at 131,072), on a slow-feeding one the one-lane kernel (0.4135 against 0.444).
+static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{0};      // 0 = by box: 98,305 fast-feeding, 196,608 otherwise
+static size_t cached_c_min_lone(float feed_ns) {
+    const size_t v = g_cached_c_min_lone.load();
+    return v ? v : (feed_ns > 0.f && feed_ns < 3.0f ? (size_t)98305 : (size_t)196608);
+}
 // hs_ed25519_verify_device_batches picks its kernel by what the caller hands over at once (measured, DESIGN.md
 // section 5): up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight
 // batches that total 8,192 signatures the one-lane pair over the batch list (k_prepare_batches + k_verify_batches: the
@@ -1317,11 +1323,12 @@ extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, 
 }
 // what a LONE call of n signatures through the key cache runs (a context marked concurrent switches to k_cached_chain2 earlier)
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
-    return n >= g_cached_c_min_lone.load() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");      // (the middle case needs HS_ED25519_CACHED_C_MIN_LONE raised)
+    const float feed = g_init.load() && !g_devs.empty() ? g_devs[0].feed_ns : 0.f;
+    return n >= cached_c_min_lone(feed) ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
 }
 static bool cached_c_form(const hs_ed25519_ctx *ctx, size_t n) {
     if (ctx->kernel == HS_K_CACHED_C) return true;
-    return ctx->kernel == HS_K_AUTO && n >= (ctx->several_in_flight ? g_cached_c_min.load() : g_cached_c_min_lone.load());
+    return ctx->kernel == HS_K_AUTO && n >= (ctx->several_in_flight ? g_cached_c_min.load() : cached_c_min_lone(g_devs[ctx->slot].feed_ns));
 }
 
 // One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's

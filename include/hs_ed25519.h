@@ -330,8 +330,9 @@ int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *ctx, int concurrent);
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 const char *hs_ed25519_cached_kernel_for(size_t n);        /* for a LONE n-signature key-cache call (k_verify_cached_lane2r up to 98,304
-                                                            * signatures; above - on a context marked concurrent from 49,152 -
-                                                            * k_cached_chain2 followed by k_cached_finish) */
+                                                            * signatures; above, k_cached_chain2 followed by k_cached_finish - on a GPU the
+                                                            * init probe found slow-feeding from 196,608 only, k_verify_cached_lane in
+                                                            * between; on a context marked concurrent the two-launch form from 49,152) */
 const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count);   /* hs_ed25519_verify_device_batches of `count` batches */
 
 /* ---- one call over several GPUs (BASELINE configs[3]: a 100,000-validator QC on 8 x MI355X) ----
