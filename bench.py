@@ -801,6 +801,8 @@ def main():
     print("bench: rank %d/%d up, %d GPU(s) visible" % (rank, world, ndev), file=sys.stderr, flush=True)
     if ndev == 0:
         print("bench: rank %d: no GPU visible - the engine has no CPU path" % rank, file=sys.stderr, flush=True)
+        if world > 1:
+            time.sleep(1.0)        # let the peers print their own line before the launcher tears them down with this rank
         sys.exit(3)
     # fewer GPUs than ranks (a 1-GPU rehearsal of `--gpus N`): ranks share devices, and since RCCL refuses two ranks on
     # one device the control plane (barrier, max over ranks, the bitmaps' all-gather) runs over gloo; the line says so

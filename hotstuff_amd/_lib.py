@@ -15,9 +15,11 @@ try:
 except ValueError:
     _tenants = 1
 def hw_queue_budget(tenants):
-    """The value hs_ed25519_init_devices gives GPU_MAX_HW_QUEUES (hs_ed25519.hip: narrow pool + wide pool + 2, at most 16).
-    The runtime reads the variable at its first device call, which in a Python process is torch's - before the library's own
-    setenv can matter - so the wrapper sets it at import, from the SAME formula (the two used to differ)."""
+    """hs_ed25519_hw_queue_budget(tenants) restated (hs_ed25519.hip: 16 for a process alone; for co-tenants narrow pool +
+    wide pool + 1, the process's default stream: 11 / 6 / 4 for 2 / 4 / 8 tenants; tests hold the two equal).
+    The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises - in a Python process at torch's first device call - and the
+    library itself no longer touches the environment (round 5): the HOST exports the variable before any thread starts.  This
+    wrapper is the host here, and import time is its main()."""
     t = max(1, min(8, int(tenants)))
     if t == 1:
         return 16
@@ -218,6 +220,12 @@ def lib():
                 l.hs_ed25519_shard_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
                 l.hs_ed25519_hw_queue_budget.argtypes = [ctypes.c_uint]
                 l.hs_ed25519_hw_queue_budget.restype = ctypes.c_uint
+                l.hs_ed25519_abi_version.argtypes = []
+                l.hs_ed25519_abi_version.restype = ctypes.c_uint32
+                l.hs_ed25519_config_dump.argtypes = [ctypes.c_char_p, sz]
+                l.hs_ed25519_config_dump.restype = sz
+                l.hs_ed25519_autotune.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+                l.hs_ed25519_autotune.restype = ctypes.c_int
                 l.hs_ed25519_ring_slot_ctx.argtypes = [vp, ctypes.c_uint]
                 l.hs_ed25519_ring_slot_ctx.restype = vp
                 _lib = l
@@ -414,10 +422,36 @@ def ensure_init():
 
 # DeviceContext.set_kernel: 0 = by batch size; 1 = one lane per signature (cold: k_prepare + k_verify,
 # key cache: k_verify_cached_lane); 3 = fused / two-lane kernels at any size; 4 = the pairs form of the fused kernel
-# in verify_batches (two signatures per quad; elsewhere it behaves as 3).  Other variants exist
-# only in -DHS_AB_VARIANTS builds (2 quad stage 2 / two-lane inversion, 10, 13: four-lane cached forms).
+# in verify_batches (two signatures per quad; elsewhere it behaves as 3).
 KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED, KERNEL_FUSED_PAIRS = 0, 1, 3, 4
 KERNEL_CACHED_C = 5          # key cache: chains + batched finish by compression at any size (cold calls: as KERNEL_AUTO)
+KERNEL_OCT, KERNEL_OCT_SPLIT = 6, 7   # cold single calls of <= 8 signatures per SIMD: k_verify_fused8 / k_verify_fused8h whatever the autotune chose
+ABI_VERSION = 0x00050000     # HS_ED25519_ABI_VERSION of include/hs_ed25519_core.h this binding was written against (test: == the header's)
+
+
+def abi_version():
+    """hs_ed25519_abi_version(): what the loaded library was built from (no GPU needed)."""
+    return int(lib().hs_ed25519_abi_version())
+
+
+def config_dump():
+    """hs_ed25519_config_dump() parsed: every value the library resolved at init (pools, thresholds, env overrides, autotune)."""
+    import json
+    l = lib()
+    need = l.hs_ed25519_config_dump(None, 0)
+    buf = ctypes.create_string_buffer(need + 1)
+    l.hs_ed25519_config_dump(buf, need + 1)
+    return json.loads(buf.value.decode())
+
+
+def autotune(slot=0):
+    """hs_ed25519_autotune(slot): (pick, {"k_verify_fused8": ms, "k_verify_fused8h": ms}) measured now on that device slot."""
+    ensure_init()
+    ms = (ctypes.c_double * 2)()
+    rc = lib().hs_ed25519_autotune(int(slot), ms)
+    if rc < 0:
+        raise EngineError("hs_ed25519_autotune: %s" % last_error())
+    return ("k_verify_fused8h" if rc else "k_verify_fused8"), {"k_verify_fused8": ms[0], "k_verify_fused8h": ms[1]}
 
 
 def _buf(b):

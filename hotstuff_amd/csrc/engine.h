@@ -40,7 +40,11 @@ bool engine_ready();
 
 // kernel choices of a context (hs_ed25519_ctx_set_kernel)
 enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3, HS_K_FUSED_PAIRS = 4,
-       HS_K_CACHED_C = 5 };       // key cache: chains + batched finish by compression at any size (cold calls: as HS_K_AUTO)
+       HS_K_CACHED_C = 5,         // key cache: chains + batched finish by compression at any size (cold calls: as HS_K_AUTO)
+       HS_K_OCT = 6, HS_K_OCT_SPLIT = 7 };   // cold single calls of <= 8 signatures per SIMD: k_verify_fused8 / k_verify_fused8h whatever the autotune chose
+
+// selectors that only concern cold single calls of up to 8 signatures per SIMD behave as HS_K_AUTO everywhere else
+inline bool hs_k_auto_like(int k) { return k == HS_K_AUTO || k == HS_K_OCT || k == HS_K_OCT_SPLIT; }
 
 struct hs_ed25519_ctx {
     int slot = 0, device = 0;
@@ -48,6 +52,8 @@ struct hs_ed25519_ctx {
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     unsigned part = 0;            // which slice (narrow pool contexts)
+    unsigned cus = 0;             // compute units the context's own stream may use (the whole device unless the stream is CU-masked):
+                                  // what the kernel choice sizes "one wavefront per SIMD" from (a tenant's share, not the chip)
     bool overflow = false;        // lent over the pool's cap (pool_get's escape from a self-deadlock): destroyed on return, never pooled
     std::shared_ptr<std::atomic<int>> held;   // taken for a TICKET: the submitting thread's count of contexts it has out (pool_put drops it)
     size_t cap = 0;               // signatures
@@ -90,7 +96,10 @@ struct dev_state {
     int live[2] = {0, 0};
     unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
-    float feed_ns = 0.f;                     // ns per 8-byte instruction a lone wavefront is fed on this GPU (k_feed_probe at init; 0 = not measured)
+    // hs_ed25519_autotune: kernel time of the two eight-lane cold forms on a canned 6,667-signature batch on THIS device
+    // ([0] k_verify_fused8, [1] k_verify_fused8h; 0 = not measured) and the faster one (-1 = not measured: the split form)
+    float oct_ms[2] = {0.f, 0.f};
+    int oct_pick = -1;
 };
 extern std::mutex g_mu;
 extern std::condition_variable g_cv;
@@ -127,6 +136,9 @@ void host_abandon(host_job &job);                          // after a failed sub
 const uint8_t *host_job_bitmap(const host_job &job);       // the pinned bitmap (valid until finish)
 // hs_wire.hip
 void wire_release(hs_ed25519_ctx *c);
+int public_keys_device(hs_ed25519_ctx *ctx, const uint8_t *d_seeds, size_t n, uint8_t *d_pks, void *stream);   // n x 32-byte seeds -> n x 32-byte keys
+// hs_tune.hip
+int autotune_slot(int slot, double ms[2]);
 // hs_rlc.hip
 void rlc_release(hs_ed25519_ctx *c);
 int rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream = nullptr);     // all allocation of an n-signature RLC call, ahead of time

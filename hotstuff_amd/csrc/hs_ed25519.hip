@@ -11,8 +11,8 @@
 //                                         wavefront decompressing the R's beside the chains
 //               k_verify_cached_lane      above: one lane per signature
 //   k_tc_digests                          timeout-certificate digests ahead of any of the above
-//   (-DHS_AB_VARIANTS additionally builds k_verify_cached, _5w, _lane2: measured
-//    and beaten forms kept for A/B runs, not part of the shipped library)
+//   (the beaten forms k_verify_cached, _5w, _lane2 of rounds 1-3 left the tree in round 5: `git show cd3b106:hotstuff_amd/csrc/hs_ed25519.hip`,
+//    numbers in profiles/HISTORY.md section 9)
 // Every verify kernel takes an optional `skip` word: when the batch random-linear-combination
 // check (hs_rlc.hip) has already accepted the whole batch it writes an all-ones bitmap and leaves.
 // Host side here: init / device slots (one or more GPUs), contexts (stream + device buffers + optional
@@ -30,6 +30,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <vector>
+#include <string>
+#include <utility>
 #include "verify.h"
 #include "verify_quad.h"
 #include "verify_cached.h"
@@ -453,163 +455,6 @@ k_base16_build(const u32 *__restrict__ t8, u32 *__restrict__ proj) {
     if (e >= HS_B16_WINDOWS * HS_B16_ENTRIES) return;
     base16_entry_projective(proj + (size_t)e * HS_KS_PROJ_WORDS, t8, e / HS_B16_ENTRIES, e % HS_B16_ENTRIES);
 }
-#ifdef HS_AB_VARIANTS
-// verification against a key set: one quad per signature, 64 table additions + 1 inversion
-__global__ void __launch_bounds__(64, 3)
-k_verify_cached(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
-                const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
-    const u32 i = blockIdx.x * 16 + (threadIdx.x >> 2);
-    const bool active = i < n;
-    const u32 j = active ? i : n - 1;
-    const u32 ki_raw = key_idx[j];
-    const bool known = ki_raw < nkeys;
-    const u32 ki = known ? ki_raw : 0;
-    const u32 *sig = sigs + (size_t)16 * j;
-    u32 kw[8], sw[8], renc[8], msg[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) renc[t] = sig[t];
-    load_msg(msg, msgs, j);
-    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
-    const u32 fl = ks.flag[ki];
-    ok = ok && known && (fl & HS_F_ONCURVE);
-    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
-    const bool curve = verify_cached_core(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
-    unsigned long long m = __ballot(ok && curve && active);
-    m &= 0x1111111111111111ull;         // the verdict is quad-uniform: take lane 0 of each quad
-    m = (m | (m >> 3)) & 0x0303030303030303ull;
-    m = (m | (m >> 6)) & 0x000f000f000f000full;
-    m = (m | (m >> 12)) & 0x000000ff000000ffull;
-    m = (m | (m >> 24)) & 0xffffull;
-    if (threadIdx.x == 0) {
-        bitmap16[blockIdx.x] = (unsigned short)m;
-        if (nreject) {
-            const u32 first = blockIdx.x * 16;
-            const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
-            const u32 bad = sigs_here - (u32)__popcll(m);
-            if (bad) atomicAdd(nreject, bad);
-        }
-    }
-}
-
-// Latency form of the cached path: a workgroup of FIVE wavefronts covers 64 signatures.
-// Wavefronts 0-3 run the quad addition chains (16 signatures each); wavefront 4 meanwhile
-// decompresses the 64 R's, one lane per signature, and hands (x_R, y_R, flags) over through LDS.
-// After the barrier the chains finish with a projective comparison (2 multiplications) instead
-// of an inversion: the square root is off the critical path.
-__global__ void __launch_bounds__(320)
-k_verify_cached_5w(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
-                   const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                   unsigned short *__restrict__ bitmap16, u32 *__restrict__ nreject) {
-    __shared__ u32 s_r[21][64];          // [limb of x (0-9), limb of y (10-19), flags (20)][signature in block]
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const bool strict = (mode & HS_MODE_STRICT) != 0;
-    qv acc;
-    bool ok = false, active = false;
-    if (wave == 4) {
-        const u32 i = blockIdx.x * 64 + lane;
-        const u32 j = i < n ? i : n - 1;
-        u32 enc[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) enc[t] = sigs[(size_t)16 * j + t];
-        ge_p3 R;
-        u32 fl = ge_decompress(R, enc) ? HS_F_ONCURVE : 0;
-        if (strict) fl |= ge_is_small_order_affine(R.Y) ? HS_F_SMALL : 0;
-#pragma unroll
-        for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
-        s_r[20][lane] = fl;
-    } else {
-        const u32 i = blockIdx.x * 64 + wave * 16 + (lane >> 2);
-        active = i < n;
-        const u32 j = active ? i : n - 1;
-        const u32 ki_raw = key_idx[j];
-        const bool known = ki_raw < nkeys;
-        const u32 ki = known ? ki_raw : 0;
-        const u32 *sig = sigs + (size_t)16 * j;
-        u32 kw[8], sw[8], msg[8];
-        load_msg(msg, msgs, j);
-        ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
-        const u32 fl = ks.flag[ki];
-        ok = ok && known && (fl & HS_F_ONCURVE);
-        if (strict) ok = ok && !(fl & HS_F_SMALL);
-        acc = cached_quad_chain(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw);
-    }
-    __syncthreads();
-    if (wave == 4) return;
-    const u32 slot = wave * 16 + (lane >> 2);
-    fe rx, ry;
-#pragma unroll
-    for (int t = 0; t < 10; t++) { rx.v[t] = s_r[t][slot]; ry.v[t] = s_r[10 + t][slot]; }
-    const bool curve = cached_quad_match_point(acc, rx, ry, s_r[20][slot], strict);
-    unsigned long long m = __ballot(ok && curve && active);
-    m &= 0x1111111111111111ull;         // the verdict is quad-uniform: take lane 0 of each quad
-    m = (m | (m >> 3)) & 0x0303030303030303ull;
-    m = (m | (m >> 6)) & 0x000f000f000f000full;
-    m = (m | (m >> 12)) & 0x000000ff000000ffull;
-    m = (m | (m >> 24)) & 0xffffull;
-    if (lane == 0) {
-        bitmap16[blockIdx.x * 4 + wave] = (unsigned short)m;
-        if (nreject) {
-            const u32 first = blockIdx.x * 64 + wave * 16;
-            const u32 sigs_here = first < n ? min(16u, n - first) : 0u;
-            const u32 bad = sigs_here - (u32)__popcll(m);
-            if (bad) atomicAdd(nreject, bad);
-        }
-    }
-}
-
-// two lanes per signature (verify_cached_lane2): a wavefront covers 32 signatures
-__global__ void __launch_bounds__(64)
-k_verify_cached_lane2(keyset_view ks, u32 nkeys, const u32 *__restrict__ btab, msg_src msgs,
-                      const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                      u32 *__restrict__ bitmap32, u32 *__restrict__ nreject) {
-    const u32 i = blockIdx.x * 32 + (threadIdx.x >> 1);
-    const bool active = i < n;
-    const u32 j = active ? i : n - 1;
-    const u32 ki_raw = key_idx[j];
-    const bool known = ki_raw < nkeys;
-    const u32 ki = known ? ki_raw : 0;
-    const u32 *sig = sigs + (size_t)16 * j;
-    u32 kw[8], sw[8], renc[8], msg[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) renc[t] = sig[t];
-    load_msg(msg, msgs, j);
-    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true);
-    const u32 fl = ks.flag[ki];
-    ok = ok && known && (fl & HS_F_ONCURVE);
-    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
-    const bool curve = verify_cached_lane2(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, btab, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
-    unsigned long long m = __ballot(ok && curve && active);
-    m &= m >> 1;                         // both lanes of the pair
-    m &= 0x5555555555555555ull;          // gather bit 2q -> bit q
-    m = (m | (m >> 1)) & 0x3333333333333333ull;
-    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
-    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
-    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
-    m = (m | (m >> 16)) & 0xffffffffull;
-    if (threadIdx.x == 0) {
-        bitmap32[blockIdx.x] = (u32)m;
-        if (nreject) {
-            const u32 first = blockIdx.x * 32;
-            const u32 sigs_here = first < n ? min(32u, n - first) : 0u;
-            const u32 bad = sigs_here - (u32)__popcll(m);
-            if (bad) atomicAdd(nreject, bad);
-        }
-    }
-}
-
-#endif  // HS_AB_VARIANTS
-#ifdef HS_CACHED_TRACE
-// Probe builds only (build/variant/libhs_trace.so, tools/cached_trace.py): every wavefront of k_verify_cached_lane2r writes the
-// constant-rate clock at its phase boundaries - which phase of a key-cache QC stretches when the grid grows, or between two boxes?
-__device__ unsigned long long *g_cached_trace = nullptr;
-extern "C" int hs_debug_set_cached_trace(unsigned long long *d_buf) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_cached_trace), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
-}
-#define HS_TRACE(slot) do { if (g_cached_trace && lane == 0) g_cached_trace[((size_t)block * 3 + wave) * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define HS_TRACE(slot) do { } while (0)
-#endif
 // Two lanes per signature with the square root off the chains: a workgroup of THREE wavefronts
 // covers 64 signatures.  Wavefronts 0 and 1 run the paired addition chains (32 signatures each);
 // wavefront 2 meanwhile decompresses the 64 R's one lane each and hands (x_R, y_R, flags) over
@@ -635,7 +480,6 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u
     const bool strict = (mode & HS_MODE_STRICT) != 0;
     ge_p3 acc;
     bool ok = false, active = false;
-    HS_TRACE(0);
     const u32 i0 = block * 64;
     const u32 *s_sig = s_in, *s_msg = s_in + 64 * 16;
     if (HS_CACHED_STAGED) {
@@ -663,7 +507,6 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u
 #pragma unroll
         for (int t = 0; t < 10; t++) { s_r[t][lane] = R.X.v[t]; s_r[10 + t][lane] = R.Y.v[t]; }
         s_r[20][lane] = fl;
-        HS_TRACE(2);
     } else {
         const u32 i = block * 64 + wave * 32 + (lane >> 1);
         active = i < n;
@@ -685,12 +528,9 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u
         const u32 fl = ks.flag[ki];
         ok = ok && known && (fl & HS_F_ONCURVE);
         if (strict) ok = ok && !(fl & HS_F_SMALL);
-        HS_TRACE(1);
         cached_lane2_chain(acc, ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw);
-        HS_TRACE(2);
     }
     __syncthreads();
-    HS_TRACE(3);
     if (wave == 2) return;
     const u32 slot = wave * 32 + (lane >> 1);
     fe rx, ry;
@@ -714,7 +554,6 @@ __device__ __forceinline__ void cached_lane2r_block(u32 (*s_r)[64], u32 *s_in, u
             if (bad) atomicAdd(nreject, bad);
         }
     }
-    HS_TRACE(4);
 }
 #ifndef HS_CACHED2R_WAVES
 #define HS_CACHED2R_WAVES 3             // wavefronts per SIMD the kernel is compiled for: 3 = 165 VGPRs, no scratch (4 = at most 128: A/B below)
@@ -938,15 +777,13 @@ static const size_t kCachedLane1Min = 98304;
 // four calls in flight 341 -> 414 M signatures/s at 49,152 - 66,667, 353 / 382 -> 436 - 441 at 131,072 (343 against 346 - 353
 // at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the one-lane kernel's 0.40 and the
 // R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) on a fast-feeding box - above 98,304, where the one-lane
-// kernel takes over; on a slow-feeding box the one-lane kernel still wins there (profiles/r4_t_cached_c_slow_box.md).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
+// kernel used to take over (on some boxes the one-lane kernel still wins there by 7 %, profiles/r4_t_cached_c_slow_box.md).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
 // the tail is as long as the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
-// A lone call between 98,305 and 196,607 signatures follows the box (dev_state::feed_ns): on a fast-feeding GPU the two-launch form
-// (0.369 against the one-lane kernel's 0.40 ms at 131,072), on a slow-feeding one the one-lane kernel (0.4135 against 0.444).
-static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{0};      // 0 = by box: 98,305 fast-feeding, 196,608 otherwise
-static size_t cached_c_min_lone(float feed_ns) {
-    const size_t v = g_cached_c_min_lone.load();
-    return v ? v : (feed_ns > 0.f && feed_ns < 3.0f ? (size_t)98305 : (size_t)196608);
-}
+// A lone call takes the two-launch form above 98,304 signatures on every GPU (round 5: round 4 switched there by an init-time proxy
+// for "the box's class", worth +8 % / -7 % in a range past every BASELINE config; a size switch that needs a per-box oracle and
+// buys < 10 % is not worth its branch - VERDICT r4 item 4).
+static std::atomic<size_t> g_cached_c_min{49152}, g_cached_c_min_lone{98305};
+static size_t cached_c_min_lone() { return g_cached_c_min_lone.load(); }
 // hs_ed25519_verify_device_batches picks its kernel by what the caller hands over at once (measured, DESIGN.md
 // section 5): up to three batches the one-signature-per-quad form (latency), from four the pairs form, from eight
 // batches that total 8,192 signatures the one-lane pair over the batch list (k_prepare_batches + k_verify_batches: the
@@ -959,18 +796,20 @@ static const size_t kLaneMinTotal = 8192;
 // SIMD), so a single batch fills the chip's 1,024 SIMDs at 16,384 signatures; HS_ED25519_QUAD_MAX_BATCH overrides (A/B runs).
 static std::atomic<size_t> g_quad_max_batch{32768};
 static std::atomic<size_t> g_oct_max_batch{8192};      // HS_ED25519_OCT_MAX_BATCH: 0 switches the eight-lane latency kernel off (A/B runs)
-static std::atomic<int> g_oct_split{-1};               // HS_ED25519_OCT_SPLIT=0 / 1: the one-wavefront eight-lane form (k_verify_fused8) / the split one at every size; -1 = by size and box
-// The split form (main + helper wavefront) up to half a wavefront slot per SIMD - 512 workgroups, every main and helper alone on
-// a SIMD: it wins on every box (0.276 -> 0.238 ms at 64 signatures, 0.283 -> 0.268 at 4,096 on a fast-feeding box; 0.302 ->
-// 0.259, 0.305 -> 0.278 on a slow-feeding one).  Above, mains share SIMDs with other workgroups' helpers for their first ~50 us:
-// on a slow-feeding box the split still wins (0.311 -> 0.278 ms at 6,667), on a fast-feeding one it loses (0.283 -> 0.292) -
-// profiles/r4_c_oct_split_ab.md, r4_m_oct_split_ab_fast_box.md.  feed_ns: dev_state::feed_ns (0 = unknown: treated as slow-feeding,
-// two boxes in three are).
-static bool oct_split_for(size_t n, size_t simds, float feed_ns) {
+static std::atomic<int> g_oct_split{-1};               // HS_ED25519_OCT_SPLIT=0 / 1: the one-wavefront eight-lane form (k_verify_fused8) / the split one at every size; -1 = by size and measurement
+static std::atomic<int> g_autotune{1};                 // HS_ED25519_AUTOTUNE=0: no measurement at init (the split form throughout)
+// The split form (main + helper wavefront) up to half a wavefront slot per SIMD - every main and helper alone on a SIMD: it wins
+// on every box measured (0.276 -> 0.238 ms at 64 signatures, 0.283 -> 0.268 at 4,096; 0.302 -> 0.259, 0.305 -> 0.278 on others).
+// Above, mains share SIMDs with other workgroups' helpers for their first ~50 us, and which form wins depends on the GPU - by
+// 3 - 10 % in either direction on boxes of one SKU, firmware and clock (profiles/r4_c_oct_split_ab.md, r4_m_oct_split_ab_fast_box.md).
+// Round 4 inferred it from an instruction-feed probe; the driver's box then ran the inferred form 14 % slower than the probe's
+// class promised.  Round 5 measures the thing itself: hs_ed25519_autotune times both forms on a canned
+// 6,667-signature batch at init and `pick` is the faster one on THIS device (-1 = not measured: the split form).
+static bool oct_split_for(size_t n, size_t simds, int pick) {
     const int forced = g_oct_split.load();
     if (forced >= 0) return forced != 0;
     if (n * 2 <= simds * 8) return true;
-    return !(feed_ns > 0.f && feed_ns < 3.0f);
+    return pick != 0;
 }
 static const size_t kQuadMaxBatch = 32768;
 // the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
@@ -1047,6 +886,8 @@ int hs::ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t
     hs_ed25519_ctx *c = new (std::nothrow) hs_ed25519_ctx();
     if (!c) return fail(HS_ED25519_E_NOMEM, "ctx_create: out of memory");
     c->slot = slot; c->device = device;
+    c->cus = g_devs[slot].cus;
+    if (cu_mask) { unsigned pc = 0; for (uint32_t w = 0; w < mask_words; w++) pc += (unsigned)__builtin_popcount(cu_mask[w]); if (pc) c->cus = pc; }
     hipError_t e = cu_mask ? hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask)
                            : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, cu_mask ? "hipExtStreamCreateWithCUMask" : "hipStreamCreate", e); }
@@ -1104,11 +945,8 @@ extern "C" int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *c, int concurrent) 
 extern "C" int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *c, int which) {
     if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_kernel: null context");
     const int old = c->kernel;
-    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED || which == HS_K_FUSED_PAIRS || which == HS_K_CACHED_C
-#ifdef HS_AB_VARIANTS
-        || which == 2 || which == 10 || which == 12 || which == 13
-#endif
-    ) c->kernel = which;
+    if (which == HS_K_AUTO || which == HS_K_LANE || which == HS_K_FUSED || which == HS_K_FUSED_PAIRS || which == HS_K_CACHED_C ||
+        which == HS_K_OCT || which == HS_K_OCT_SPLIT) c->kernel = which;
     else return fail(HS_ED25519_E_ARG, "ctx_set_kernel: unknown kernel");
     return old;
 }
@@ -1153,37 +991,6 @@ static int build_base_tables(dev_state &d) {
     if (rc) free_base_tables(d);
     return rc;
 }
-// How fast does this GPU feed a lone wavefront its instructions?  The pool's boxes come in two classes (DESIGN.md 8.1,
-// tools/ifetch_probe): 2.0 ns per 8-byte instruction on some, 4.1 ns on the others, same silicon name, clocks and firmware.
-// The one decision in the library that flips with the class is measured once per device at init (8,192 straight-line
-// instructions on one wavefront, ~30 us): the split form of the eight-lane cold kernel between 4,097 and 8,192 signatures
-// (oct_split_for).  Timed on the device with the constant-rate wall clock.
-__global__ void __launch_bounds__(64) k_feed_probe(unsigned long long *out, u32 seed) {
-    u32 x = seed + threadIdx.x;
-    unsigned long long best = ~0ull;
-    for (int pass = 0; pass < 4; pass++) {          // the first pass also warms the instruction cache: the minimum counts
-        const unsigned long long t0 = wall_clock64();
-        asm volatile(".rept 2048\n v_add_u32 %0, 0x12345, %0\n .endr" : "+v"(x));
-        const unsigned long long t1 = wall_clock64();
-        if (t1 - t0 < best) best = t1 - t0;
-    }
-    if (threadIdx.x == 0) out[0] = best;
-    if (x == 0xdeadbeefu) out[1] = x;
-}
-static void measure_feed(dev_state &d) {
-    d.feed_ns = 0.f;
-    int khz = 0;
-    unsigned long long *d_out = nullptr, h = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d.ordinal) != hipSuccess || khz <= 0) { (void)hipGetLastError(); return; }
-    if (hipMalloc((void **)&d_out, 16) != hipSuccess) { (void)hipGetLastError(); return; }
-    u32 seed = 1;
-    void *a[] = { &d_out, &seed };
-    if (hipLaunchKernel((const void *)k_feed_probe, dim3(1), dim3(64), a, 0, nullptr) == hipSuccess &&
-        hipMemcpy(&h, d_out, 8, hipMemcpyDeviceToHost) == hipSuccess && h && h != ~0ull)
-        d.feed_ns = (float)((double)h * 1e6 / khz / 2048.0);
-    else (void)hipGetLastError();
-    (void)hipFree(d_out);
-}
 // Pools of a process that is one of `tenants` on its GPU, and the hardware queues they ask for.  The budget that matters is
 // the GPU's, not the process's: the driver's hardware scheduler runs ~28 user queues at once ACROSS ALL PROCESSES, and one
 // queue more oversubscribes its runlist - every process is then time-sliced (four tenants with seven queues each: 75 M
@@ -1204,9 +1011,18 @@ extern "C" unsigned hs_ed25519_hw_queue_budget(unsigned tenants) {
     if (tenants == 1) return 16;
     return (unsigned)(pool_narrow_for(tenants) + pool_wide_for(tenants) + 1);
 }
+// the environment knobs init found set (name, value), for hs_ed25519_config_dump; written under g_mu by init only
+static std::vector<std::pair<std::string, std::string>> g_env_seen;
+static int g_hw_queues_env = 0;             // GPU_MAX_HW_QUEUES as init found it (0 = unset: the HIP runtime's default of 4)
+static const char *env_knob(const char *name) {
+    const char *e = getenv(name);
+    if (e) g_env_seen.emplace_back(name, e);
+    return e;
+}
+extern "C" uint32_t hs_ed25519_abi_version(void) { return HS_ED25519_ABI_VERSION; }
 extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
     if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     if (g_init.load()) {
         // idempotent for the same device list; a different one would silently run on the wrong GPUs
         bool same = g_devs.size() == count;
@@ -1216,36 +1032,49 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         if (max_batch > g_max_batch.load()) g_max_batch.store(max_batch);
         return 0;
     }
-    // The pool, the ring slots and the CU-partitioned contexts each want a hardware queue of their
-    // own; HIP's default of 4 multiplexes them (streamed rounds: 22 vs 34 M signatures/s).  The
-    // runtime reads this when it initialises, so it only takes effect when this library is the
-    // process's first HIP user (the Rust node); an explicit setting by the host is respected.
-    // HS_ED25519_KEEP_ENV=1: the host process does not want its environment touched at all.
-    if (const char *e = getenv("HS_ED25519_TENANTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) { kTenants = (unsigned)v; if (kTenantIndex >= kTenants) kTenantIndex = 0; } }
-    if (const char *e = getenv("HS_ED25519_TENANT_INDEX")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < kTenants) kTenantIndex = (unsigned)v; }
+    // Every knob is read here, once (hs_ed25519_config_dump reports what was resolved; INTEGRATION.md has the table).
+    g_env_seen.clear();
+    if (const char *e = env_knob("HS_ED25519_TENANTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) { kTenants = (unsigned)v; if (kTenantIndex >= kTenants) kTenantIndex = 0; } }
+    if (const char *e = env_knob("HS_ED25519_TENANT_INDEX")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < kTenants) kTenantIndex = (unsigned)v; }
     kMaxPool[0] = 4; kMaxPool[1] = 16; kPoolPartitions = 8;
     if (kTenants > 1) {
         kMaxPool[1] = pool_narrow_for(kTenants);
         kMaxPool[0] = pool_wide_for(kTenants);
         kPoolPartitions = tenant_partitions(kTenants);
     }
-    if (const char *e = getenv("HS_ED25519_TENANT_WIDE")) kTenantWide = e[0] != '0';
-    const char *keep = getenv("HS_ED25519_KEEP_ENV");
-    if (!(keep && keep[0] == '1')) {
-        char q[8];
-        snprintf(q, sizeof q, "%u", hs_ed25519_hw_queue_budget(kTenants));
-        setenv("GPU_MAX_HW_QUEUES", q, 0);
+    if (const char *e = env_knob("HS_ED25519_TENANT_WIDE")) kTenantWide = e[0] != '0';
+    // The pools, the ring slots and the CU-partitioned contexts each want a hardware queue of their own; HIP's default of 4
+    // multiplexes them (streamed rounds: 22 vs 34 M signatures/s).  The runtime reads GPU_MAX_HW_QUEUES when IT initialises,
+    // so the variable belongs to the host's main(), before any thread exists: glibc's setenv is not
+    // safe against a concurrent getenv, and the reference's node is a multi-thread tokio runtime (node/src/main.rs:57) - a
+    // library must not touch the environment from inside it.  Only HS_ED25519_SET_ENV=1 - a host that
+    // says it is single-threaded here and has not started HIP yet - still gets the old setenv (without overwrite).
+    // Otherwise: compare, and leave a warning for hs_ed25519_last_error when the budget is not there.
+    const unsigned budget = hs_ed25519_hw_queue_budget(kTenants);
+    {
+        const char *set_env = env_knob("HS_ED25519_SET_ENV");
+        if (set_env && set_env[0] == '1') {
+            char q[8];
+            snprintf(q, sizeof q, "%u", budget);
+            setenv("GPU_MAX_HW_QUEUES", q, 0);
+        }
+        const char *have_q = getenv("GPU_MAX_HW_QUEUES");
+        g_hw_queues_env = have_q ? atoi(have_q) : 0;
     }
-    if (const char *e = getenv("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
-    if (const char *e = getenv("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
-    if (const char *e = getenv("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0' ? 1 : 0);
-    if (const char *e = getenv("HS_ED25519_CACHED_C_MIN")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min.store((size_t)v); }
-    if (const char *e = getenv("HS_ED25519_CACHED_C_MIN_LONE")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min_lone.store((size_t)v); }
-    if (const char *e = getenv("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
-    if (const char *e = getenv("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
-    if (const char *e = getenv("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
-    if (const char *e = getenv("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
-    if (const char *e = getenv("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
+    g_pairs_min_batches.store(4); g_lane_min_batches.store(8); g_oct_split.store(-1); g_autotune.store(1);
+    g_cached_c_min.store(49152); g_cached_c_min_lone.store(98305); g_oct_max_batch.store(8192); g_tail_max.store(kTailMax); g_quad_max_batch.store(32768);
+    if (const char *e = env_knob("HS_ED25519_PAIRS_MIN_BATCHES")) { const long v = atol(e); g_pairs_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = env_knob("HS_ED25519_LANE_MIN_BATCHES")) { const long v = atol(e); g_lane_min_batches.store(v > 0 ? (size_t)v : (size_t)-1); }
+    if (const char *e = env_knob("HS_ED25519_OCT_SPLIT")) g_oct_split.store(e[0] != '0' ? 1 : 0);
+    if (const char *e = env_knob("HS_ED25519_AUTOTUNE")) g_autotune.store(e[0] != '0' ? 1 : 0);
+    if (const char *e = env_knob("HS_ED25519_CACHED_C_MIN")) { const long long v = atoll(e); if (v >= 0) g_cached_c_min.store((size_t)v); }
+    if (const char *e = env_knob("HS_ED25519_CACHED_C_MIN_LONE")) { const long long v = atoll(e); if (v > 0) g_cached_c_min_lone.store((size_t)v); }
+    if (const char *e = env_knob("HS_ED25519_OCT_MAX_BATCH")) { const long v = atol(e); if (v >= 0 && v <= 32768) g_oct_max_batch.store((size_t)v); }
+    if (const char *e = env_knob("HS_ED25519_TAIL_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) g_tail_max.store((size_t)v); }
+    if (const char *e = env_knob("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
+    if (const char *e = env_knob("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
+    if (const char *e = env_knob("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
+    (void)env_knob("HS_ED25519_MIN_GPU_BATCH"); (void)env_knob("HS_ED25519_SHARD_MSM_MIN");      // read where they are used; listed in the dump
     int have = 0;
     HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");
     for (size_t i = 0; i < count; i++)
@@ -1263,12 +1092,27 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         hipDeviceProp_t prop;
         HS_HIP(hipGetDeviceProperties(&prop, ordinals[i]), "hipGetDeviceProperties");
         devs[i].cus = (unsigned)prop.multiProcessorCount;
-        measure_feed(devs[i]);
     }
     HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
     g_devs.swap(devs);
     g_max_batch.store(max_batch ? max_batch : 1024);
     g_init.store(true);
+    const bool tune = g_autotune.load() && g_oct_split.load() < 0;
+    const int queues = g_hw_queues_env;
+    lk.unlock();
+    // measured kernel choice (hs_tune.hip), outside the lock: it runs ordinary calls on a context of its own.  A failure
+    // costs the measurement, not the engine: the slot keeps the default form and the text says why.
+    char warn[256] = "";
+    if (tune)
+        for (size_t i = 0; i < count; i++)
+            if (hs::autotune_slot((int)i, nullptr) < 0)
+                snprintf(warn, sizeof warn, "hs_ed25519_init: warning: autotune on device slot %zu failed (%.120s); the split eight-lane form stays the default", i, t_err);
+    if (!warn[0] && (unsigned)queues < budget)
+        snprintf(warn, sizeof warn, "hs_ed25519_init: warning: GPU_MAX_HW_QUEUES is %s%.0d but the pools want %u hardware queues "
+                 "(hs_ed25519_hw_queue_budget): export it in main() before the HIP runtime starts, or streams will share queues",
+                 queues ? "" : "unset (HIP's default: 4)", queues, budget);
+    snprintf(t_err, sizeof t_err, "%s", warn);
+    (void)hipSetDevice(ordinals[0]);
     return 0;
 }
 extern "C" int hs_ed25519_init(int device, size_t max_batch) { return hs_ed25519_init_devices(&device, 1, max_batch); }
@@ -1289,6 +1133,46 @@ extern "C" void hs_ed25519_shutdown(void) {
 }
 extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
 
+// what init resolved, as JSON (include/hs_ed25519.h); no device call
+extern "C" size_t hs_ed25519_config_dump(char *buf, size_t cap) {
+    std::string o;
+    char t[512];
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t pm = g_pairs_min_batches.load(), lm = g_lane_min_batches.load();
+    snprintf(t, sizeof t, "{\"abi_version\": %u, \"initialised\": %s, \"tenants\": %u, \"tenant_index\": %u, \"tenant_wide\": %s, "
+             "\"pool_wide\": %d, \"pool_narrow\": %d, \"pool_partitions\": %u, \"hw_queue_budget\": %u, \"gpu_max_hw_queues_env\": %d, ",
+             (unsigned)HS_ED25519_ABI_VERSION, g_init.load() ? "true" : "false", kTenants, kTenantIndex, kTenantWide ? "true" : "false",
+             kMaxPool[0], kMaxPool[1], kPoolPartitions, hs_ed25519_hw_queue_budget(kTenants), g_hw_queues_env);
+    o += t;
+    snprintf(t, sizeof t, "\"max_batch_hint\": %zu, \"narrow_pool_max_batch\": %zu, \"zero_copy_max\": %zu, \"oct_max_batch\": %zu, \"oct_split_forced\": %d, "
+             "\"autotune\": %d, \"quad_max_batch\": %zu, \"tail_max\": %zu, \"pairs_min_batches\": %lld, \"lane_min_batches\": %lld, \"lane_min_total\": %zu, "
+             "\"cached_lane1_min\": %zu, \"cached_c_min_concurrent\": %zu, \"cached_c_min_lone\": %zu, \"rlc_min_batch\": %zu, "
+             "\"min_gpu_batch\": {\"cold\": %zu, \"key_cache\": %zu}, ",
+             g_max_batch.load(), (size_t)kPartitionMaxBatch, (size_t)kZeroCopyMax, g_oct_max_batch.load(), g_oct_split.load(), g_autotune.load(),
+             g_quad_max_batch.load(), g_tail_max.load(), pm == (size_t)-1 ? -1ll : (long long)pm, lm == (size_t)-1 ? -1ll : (long long)lm, kLaneMinTotal,
+             kCachedLane1Min, g_cached_c_min.load(), g_cached_c_min_lone.load(), hs_ed25519_rlc_min_batch(),
+             hs_ed25519_min_gpu_batch(0), hs_ed25519_min_gpu_batch(1));
+    o += t;
+    o += "\"devices\": [";
+    for (size_t i = 0; i < g_devs.size(); i++) {
+        const dev_state &d = g_devs[i];
+        snprintf(t, sizeof t, "%s{\"slot\": %zu, \"ordinal\": %d, \"cus\": %u, \"oct_ms\": {\"k_verify_fused8\": %.4f, \"k_verify_fused8h\": %.4f}, "
+                 "\"oct_pick\": \"%s\", \"oct_form_4097_8192\": \"%s\"}", i ? ", " : "", i, d.ordinal, d.cus, d.oct_ms[0], d.oct_ms[1],
+                 d.oct_pick < 0 ? "not measured" : (d.oct_pick ? "k_verify_fused8h" : "k_verify_fused8"),
+                 oct_split_for(6667, (size_t)d.cus * 4, d.oct_pick) ? "k_verify_fused8h" : "k_verify_fused8");
+        o += t;
+    }
+    o += "], \"env_seen\": {";
+    for (size_t i = 0; i < g_env_seen.size(); i++) {
+        std::string v;
+        for (char ch : g_env_seen[i].second) if (ch != '"' && ch != '\\' && (unsigned char)ch >= 0x20) v += ch;
+        o += (i ? ", \"" : "\"") + g_env_seen[i].first + "\": \"" + v + "\"";
+    }
+    o += "}}";
+    if (buf && cap) { const size_t k = o.size() < cap - 1 ? o.size() : cap - 1; memcpy(buf, o.data(), k); buf[k] = 0; }
+    return o.size();
+}
+
 // Below this many signatures per call the GPU round trip (launch + one wavefront's serial chain,
 // ~0.40 ms cold / ~0.13 ms with the keys registered) costs more than verifying on one CPU core
 // (~40-50 us per ed25519-dalek strict verification): the Rust shim keeps such calls - the
@@ -1302,13 +1186,13 @@ extern "C" size_t hs_ed25519_min_gpu_batch(int keys_registered) {
 
 static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
     const int f = ctx ? ctx->kernel : HS_K_AUTO;
-    if (f == HS_K_AUTO) return n <= g_quad_max_batch.load() ? HS_K_FUSED : HS_K_LANE;
+    if (f == HS_K_AUTO || f == HS_K_CACHED_C || f == HS_K_OCT || f == HS_K_OCT_SPLIT) return n <= g_quad_max_batch.load() ? HS_K_FUSED : HS_K_LANE;
     return f == HS_K_FUSED_PAIRS ? HS_K_FUSED : f;      // the pairs form only exists for verify_device_batches
 }
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
     if (n <= simds * 8 && n <= g_oct_max_batch.load())
-        return oct_split_for(n, simds, g_init.load() && !g_devs.empty() ? g_devs[0].feed_ns : 0.f) ? "k_verify_fused8h" : "k_verify_fused8";
+        return oct_split_for(n, simds, g_init.load() && !g_devs.empty() ? g_devs[0].oct_pick : -1) ? "k_verify_fused8h" : "k_verify_fused8";
     if (n <= g_quad_max_batch.load()) return n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3";
     const size_t tail = n % (simds * 64);       // a sliver past whole rounds of wavefronts rides in the stage-2 launch (enqueue_cold)
     return n > simds * 64 && tail && tail <= g_tail_max.load() ? "k_verify_tail" : "k_verify";
@@ -1323,12 +1207,11 @@ extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, 
 }
 // what a LONE call of n signatures through the key cache runs (a context marked concurrent switches to k_cached_chain2 earlier)
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
-    const float feed = g_init.load() && !g_devs.empty() ? g_devs[0].feed_ns : 0.f;
-    return n >= cached_c_min_lone(feed) ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
+    return n >= cached_c_min_lone() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
 }
 static bool cached_c_form(const hs_ed25519_ctx *ctx, size_t n) {
     if (ctx->kernel == HS_K_CACHED_C) return true;
-    return ctx->kernel == HS_K_AUTO && n >= (ctx->several_in_flight ? g_cached_c_min.load() : cached_c_min_lone(g_devs[ctx->slot].feed_ns));
+    return hs_k_auto_like(ctx->kernel) && n >= (ctx->several_in_flight ? g_cached_c_min.load() : cached_c_min_lone());
 }
 
 // One kernel launch.  With events the dispatch itself is time-stamped (hipExtLaunchKernel's
@@ -1379,13 +1262,18 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         HS_HIP(launch1((const void *)k_verify_fused_pairs_batches, dim3(np / 32), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_fused_pairs_batches");
     } else if (kern == HS_K_FUSED) {
-        // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above
-        const size_t simds = (size_t)g_devs[ctx->slot].cus * 4;
+        // 4-bit windows while the batch is at most one wavefront per SIMD (40,960 B of LDS per wavefront), 3-bit above.
+        // "Per SIMD" = of the CUs this context's stream may use: a tenant's wide context or a narrow pool context is confined to
+        // a slice of the chip, and a form tuned for one workgroup per SIMD would be oversubscribed there.
+        const size_t simds = (size_t)(ctx->cus ? ctx->cus : g_devs[ctx->slot].cus) * 4;
         // eight lanes per signature: still one wavefront per SIMD at most - for a call that has the chip to itself.  With
         // several whole-chip calls at once (the slots of a round ring, hs_ed25519_ctx_set_concurrent) twice the wavefronts
         // per signature cost throughput (41 against 53 M signatures/s from four ring slots): four lanes per signature then.
-        if (n <= simds * 8 && ctx->kernel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n) {
-            if (oct_split_for(n, simds, g_devs[ctx->slot].feed_ns))
+        const int ksel = ctx->kernel == HS_K_CACHED_C ? HS_K_AUTO : ctx->kernel;      // a key-cache selector leaves cold calls alone
+        const bool oct_forced = ksel == HS_K_OCT || ksel == HS_K_OCT_SPLIT;
+        if (n <= simds * 8 && (oct_forced || (ksel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n))) {
+            const bool split = oct_forced ? ksel == HS_K_OCT_SPLIT : oct_split_for(n, simds, g_devs[ctx->slot].oct_pick);
+            if (split)
                 HS_HIP(launch1((const void *)k_verify_fused8h, dim3(np / 8), dim3(128), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                        "launch k_verify_fused8h");
             else
@@ -1408,9 +1296,9 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         // time - profiles/r3_concurrent_ab.txt.)
         // Not behind an RLC stage (d_skip: the kernels here are its rare fallback and return at once when it accepted), and
         // not when several whole-chip calls run at once (the sliver's wavefronts then only compete with the other calls').
-        const size_t round_sigs = (size_t)g_devs[ctx->slot].cus * 4 * 64;
+        const size_t round_sigs = (size_t)(ctx->cus ? ctx->cus : g_devs[ctx->slot].cus) * 4 * 64;
         const size_t tail = round_sigs ? n % round_sigs : 0;
-        if (ctx->kernel == HS_K_AUTO && !d_skip && !ctx->several_in_flight && n > round_sigs && tail && tail <= g_tail_max.load()) {
+        if ((hs_k_auto_like(ctx->kernel) || ctx->kernel == HS_K_CACHED_C) && !d_skip && !ctx->several_in_flight && n > round_sigs && tail && tail <= g_tail_max.load()) {
             const size_t main_n = n - tail;                      // a multiple of 64: the tail's bitmap starts on a word
             msg_src tmsgs = msgs;
             tmsgs.digests = msgs.digests + (size_t)msgs.stride_words * main_n;
@@ -1540,7 +1428,7 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (!ctx || (!batches && count)) return fail(HS_ED25519_E_ARG, "verify_device_batches: null context / list");
     { const int rc = check_batch_list(batches, count, 16, "verify_device_batches"); if (rc) return rc; }
-    if (count == 1 && ctx->kernel == HS_K_AUTO && batches[0].n) {
+    if (count == 1 && hs_k_auto_like(ctx->kernel) && batches[0].n) {
         // a list of one is a single batch: it gets the single-batch kernels (the eight-lane latency form up to 8,192 signatures)
         msg_src m;
         const int rc = make_digest_src(m, batches[0].d_digests, batches[0].digest_stride);
@@ -1553,13 +1441,13 @@ extern "C" int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed
     // enough batches per launch that the shorter form's extra wavefronts would only queue; HS_K_FUSED / HS_K_FUSED_PAIRS
     // on the context force either
     bool lane = ctx->kernel == HS_K_LANE;
-    if (ctx->kernel == HS_K_AUTO && count >= g_lane_min_batches.load()) {
+    if (hs_k_auto_like(ctx->kernel) && count >= g_lane_min_batches.load()) {
         size_t total = 0;
         for (size_t i = 0; i < count; i++) total += batches[i].n;
         lane = total >= kLaneMinTotal;
     }
     if (lane) return enqueue_lane_batches(ctx, batches, count, st);
-    const bool pairs = ctx->kernel == HS_K_FUSED_PAIRS || (ctx->kernel == HS_K_AUTO && count >= g_pairs_min_batches.load());
+    const bool pairs = ctx->kernel == HS_K_FUSED_PAIRS || (hs_k_auto_like(ctx->kernel) && count >= g_pairs_min_batches.load());
     const u32 per_block = pairs ? 32 : 16;
     size_t done = 0;
     while (done < count) {
@@ -1834,11 +1722,7 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
     const u32 np = (u32)round_up(n, 64);
     keyset_view kv; kv.tab = ks->d_tab; kv.pk = ks->d_pk; kv.flag = ks->d_flag;
     u32 nkeys = (u32)ks->nkeys, nn = (u32)n, mode_ = mode;
-    // the default kernels read the base point's 16-bit table; the A/B variants below still take the 8-bit one
     const u32 *p_bt = g_devs[ctx->slot].base_tab16, *p_ki = d_key_idx, *p_sg = (const u32 *)d_sigs;
-#ifdef HS_AB_VARIANTS
-    if (ctx->kernel == 2 || ctx->kernel == 10 || ctx->kernel == 13) p_bt = g_devs[ctx->slot].base_tab;
-#endif
     unsigned short *p_bm = (unsigned short *)d_bitmap;
     u32 *p_nr = d_nreject;
     const u32 *p_skip = d_skip;
@@ -1855,8 +1739,9 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
         if (rc) return rc;
         u32 *fin = ctx->d_ws;
         // signatures per finish lane: 4 for a call that is alone (the tail is latency: 0.290 against 0.337 ms at 66,667), 8 among
-        // others (414 against 410 M signatures/s with four in flight; 16 only wins from ~131,072: 441 against 436 M)
-        u32 m = ctx->several_in_flight ? (n >= 131072 ? 16u : 8u) : 4u;
+        // others (414 against 410 M signatures/s with four in flight; 16 from 131,072 bought 1 % - 441 against 436 M - and was
+        // retired in round 5 with the other sub-5 % switches)
+        u32 m = ctx->several_in_flight ? 8u : 4u;
         u32 nl = (u32)round_up((n + m - 1) / m, 64), np_ = np;
         unsigned long long *p_bm64 = (unsigned long long *)d_bitmap;
         void *ac[] = { &kv, &nkeys, &p_bt, &msgs, &p_ki, &p_sg, &nn, &mode_, &fin, &np_, &p_skip };
@@ -1866,12 +1751,7 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
         HS_HIP(launch1((const void *)k_cached_finish, dim3(nl / 64), dim3(64), af, st, nullptr, e2), "launch k_cached_finish");
         return 0;
     }
-#ifdef HS_AB_VARIANTS
-    if (forced == 2) { HS_HIP(launch1((const void *)k_verify_cached_lane2, dim3(np / 32), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane2"); return 0; }
-    if (forced == 10) { HS_HIP(launch1((const void *)k_verify_cached, dim3(np / 16), dim3(64), a, st, e0, e2), "launch k_verify_cached"); return 0; }
-    if (forced == 13) { HS_HIP(launch1((const void *)k_verify_cached_5w, dim3(np / 64), dim3(320), a, st, e0, e2), "launch k_verify_cached_5w"); return 0; }
-#endif
-    if (forced == HS_K_LANE || (forced == HS_K_AUTO && n > kCachedLane1Min))
+    if (forced == HS_K_LANE || (hs_k_auto_like(forced) && n > kCachedLane1Min))
         HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane");
     else
         HS_HIP(launch1((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, st, e0, e2), "launch k_verify_cached_lane2r");

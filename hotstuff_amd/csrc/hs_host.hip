@@ -36,13 +36,21 @@ bool hs::bitmap_all_ones(const uint8_t *bm, size_t n) {
 // of magnitude above a call's duration, so ordinary contention (more synchronous callers than contexts) never gets near it
 // and the pools stay at their caps - which is what keeps the streams within the 16 hardware queues.
 static const std::chrono::milliseconds kPoolPatience(1000);
-// Contexts this thread has out as TICKETS (hs_ed25519_submit), per pool.  Counted on the context, not on the ticket: a ticket
-// may be collected by another thread, and the count must follow the context back to the pool wherever that happens - hence
-// a shared counter that outlives the thread.
+// Contexts this thread has out as TICKETS (hs_ed25519_submit), per (device slot, pool).  Counted on the context, not on the
+// ticket: a ticket may be collected by another thread, and the count must follow the context back to the pool wherever that
+// happens - hence shared counters that outlive the thread.  Per slot AND pool: a thread with tickets out on slot A
+// must not be lent an over-cap context on slot B, whose contexts other threads hold and will return.
+// Hand-off caveat (include/hs_ed25519.h, tickets): the escape below looks at what the CALLING thread submitted; a thread that
+// collects tickets submitted by another has a count of zero and waits like any other caller.
 namespace {
 struct held_counts {
-    std::shared_ptr<std::atomic<int>> n[2];
-    held_counts() { n[0] = std::make_shared<std::atomic<int>>(0); n[1] = std::make_shared<std::atomic<int>>(0); }
+    std::vector<std::shared_ptr<std::atomic<int>>> n;      // [2 * slot + pool]
+    std::shared_ptr<std::atomic<int>> &at(int slot, int k) {
+        const size_t i = 2 * (size_t)slot + (size_t)k;
+        if (n.size() <= i) n.resize(i + 1);
+        if (!n[i]) n[i] = std::make_shared<std::atomic<int>>(0);
+        return n[i];
+    }
 };
 thread_local held_counts t_held;
 }
@@ -76,7 +84,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
             if (k == 1) d.part_busy[c->part % 64]++;
             // a whole-chip call that finds another one in flight on its device runs the throughput forms (enqueue_cold)
             else c->several_in_flight = d.live[0] - (int)d.free_ctx[0].size() > 1;
-            if (nowait) { c->held = t_held.n[k]; c->held->fetch_add(1, std::memory_order_relaxed); }
+            if (nowait) { c->held = t_held.at(slot, k); c->held->fetch_add(1, std::memory_order_relaxed); }
             *out = c;
             return 0;
         }
@@ -94,7 +102,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
         if (g_cv.wait_until(lk, deadline) == std::cv_status::timeout) {          // (other pools' returns wake it too: one deadline per wait)
             if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_shutdown was called");
             if (g_devs[slot].free_ctx[k].empty()) {
-                if (t_held.n[k]->load(std::memory_order_relaxed) > 0) { g_devs[slot].live[k]++; overflow = true; break; }
+                if (t_held.at(slot, k)->load(std::memory_order_relaxed) > 0) { g_devs[slot].live[k]++; overflow = true; break; }
                 waiting = false;                     // others hold them: wait on
             }
         }
@@ -126,7 +134,7 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     c->part = part;
     c->overflow = overflow;
     c->several_in_flight = others_busy;
-    if (nowait) { c->held = t_held.n[k]; c->held->fetch_add(1, std::memory_order_relaxed); }
+    if (nowait) { c->held = t_held.at(slot, k); c->held->fetch_add(1, std::memory_order_relaxed); }
     if (k == 1) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].part_busy[part % 64]++; lk.unlock(); }
     *out = c;
     return 0;

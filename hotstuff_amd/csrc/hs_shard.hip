@@ -306,6 +306,7 @@ size_t msm_min() {
     if (const char *e = getenv("HS_ED25519_SHARD_MSM_MIN")) { const long long x = atoll(e); if (x > 0) return (size_t)x; }
     return hs_ed25519_rlc_min_batch() * (size_t)(dev_slots() > 0 ? dev_slots() : 1);
 }
+std::atomic<unsigned long long> s_msm_rccl_fallbacks{0};      // combinations that went through the host exchange because RCCL could not be set up
 // 1 = the combination over all shards accepted, 0 = it did not (localise), < 0 = engine error
 int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n) {
     const int k = dev_slots();
@@ -358,7 +359,8 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
     std::vector<int> live;
     for (int s = 0; s < k; s++) if (jobs[s].c) live.push_back(s);
     u32 *d_flag = nullptr;
-    if (rccl && (int)live.size() == k) {
+    bool via_rccl = rccl && (int)live.size() == k;
+    if (via_rccl) {
         // all-gather of the 384-byte records over xGMI; slot `first` (= 0 here) joins what it received
         std::lock_guard<std::mutex> lk(s_mu);
         rc = rccl_ensure();
@@ -368,7 +370,19 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
                 hipMemcpyAsync(gs->buf[s] + (size_t)s * kRlcPartBytes, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToDevice, jobs[s].c->stream) != hipSuccess)
                 rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the partial point");
         }
-        if (!rc) {
+        if (rc) {
+            // The collective could not be SET UP (no librccl, ncclCommInitAll refused this device list, no memory for the gather
+            // buffers): every device still holds its 384-byte record, and the host exchange below needs nothing else - so the call
+            // verifies through it instead of failing.  An error once the grouped call has started is returned as before.
+            (void)hipGetLastError();
+            s_msm_rccl_fallbacks++;
+            via_rccl = false;
+            rc = 0;
+        }
+    }
+    if (via_rccl) {
+        {
+            std::lock_guard<std::mutex> lk(s_mu);
             ncclResult_t r = s_rccl.GroupStart();
             for (int s = 0; s < k && r == ncclSuccess; s++)
                 r = s_rccl.AllGather(gs->buf[s] + (size_t)s * kRlcPartBytes, gs->buf[s], kRlcPartBytes, ncclUint8, s_comms[s], jobs[s].c->stream);
@@ -427,7 +441,8 @@ extern "C" int hs_ed25519_set_shard_msm_min(size_t n) { s_msm_override.store(n);
 extern "C" int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts) {
     if (calls) *calls = s_msm_calls.load();
     if (accepts) *accepts = s_msm_accepts.load();
-    return 0;
+    const unsigned long long f = s_msm_rccl_fallbacks.load();
+    return f > 0x7fffffffull ? 0x7fffffff : (int)f;
 }
 
 extern "C" int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,

@@ -192,6 +192,18 @@ extern "C" int hs_ed25519_sign_batch(const uint8_t *secrets, const uint8_t *dige
     if (e != hipSuccess || e2 != hipSuccess) return fail(HS_ED25519_E_DEVICE, "sign_batch", e != hipSuccess ? e : e2);
     return 0;
 }
+// device buffers: n 32-byte seeds -> n 32-byte public keys, on the context's stream (or `stream`)
+int hs::public_keys_device(hs_ed25519_ctx *ctx, const uint8_t *d_seeds, size_t n, uint8_t *d_pks, void *stream) {
+    if (!ctx || !d_seeds || !d_pks || n == 0 || n > 0x3fffffffu) return fail(HS_ED25519_E_ARG, "public_keys_device: bad arguments");
+    const u32 *btab = dev_base_table(ctx->slot);
+    if (!btab) return HS_ED25519_E_DEVICE;
+    HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const u32 *p_sd = (const u32 *)d_seeds; u32 nn = (u32)n; u32 *p_pk = (u32 *)d_pks;
+    void *a[] = { &p_sd, &nn, &btab, &p_pk };
+    HS_HIP(hipLaunchKernel((const void *)k_public_keys, dim3((nn + 63) / 64), dim3(64), a, 0, stream ? (hipStream_t)stream : ctx->stream),
+           "launch k_public_keys");
+    return 0;
+}
 extern "C" int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *pks_out) {
     if (!engine_ready()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (n == 0) return 0;
@@ -200,20 +212,15 @@ extern "C" int hs_ed25519_public_keys(const uint8_t *seeds, size_t n, uint8_t *p
     int rc = pool_get(&c, 0, (size_t)-1);
     if (rc) return rc;
     struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
-    const u32 *btab = dev_base_table(c->slot);
-    if (!btab) return HS_ED25519_E_DEVICE;
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     uint8_t *d = nullptr;
     HS_HIP(hipMalloc((void **)&d, 64 * n), "hipMalloc key buffers");
     hipError_t e = hipMemcpyAsync(d, seeds, 32 * n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        const u32 *p_sd = (const u32 *)d; u32 nn = (u32)n; u32 *p_pk = (u32 *)(d + 32 * n);
-        void *a[] = { &p_sd, &nn, &btab, &p_pk };
-        e = hipLaunchKernel((const void *)k_public_keys, dim3((nn + 63) / 64), dim3(64), a, 0, c->stream);
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(pks_out, d + 32 * n, 32 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) rc = public_keys_device(c, d, n, d + 32 * n, c->stream);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(pks_out, d + 32 * n, 32 * n, hipMemcpyDeviceToHost, c->stream);
     const hipError_t e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
+    if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess) return fail(HS_ED25519_E_DEVICE, "public_keys", e != hipSuccess ? e : e2);
     return 0;
 }

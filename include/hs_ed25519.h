@@ -1,87 +1,21 @@
-/* hs_ed25519.h - C ABI of the MI355X batch Ed25519 verification engine.
+/* hs_ed25519.h - the EXTENDED C ABI of the MI355X batch Ed25519 verification engine.
  *
- * The reference (asonnino/hotstuff) has no FFI today; its boundary for this
- * path is two Rust associated functions in crypto/src/lib.rs:
- *
- *   Signature::verify(&self, &Digest, &PublicKey)            lib.rs:200-204
- *   Signature::verify_batch(&Digest, I: IntoIterator<...>)   lib.rs:206-219
- *
- * reached from consensus/src/messages.rs:64,144,258 (single), :197 (QC::verify,
- * one shared digest) and :307-313 (TC::verify, one digest per vote).  These
- * entry points are what a Rust `extern "C"` block in crypto/src/lib.rs binds
- * (INTEGRATION.md shows the shim).  Plain pointers and sizes only.
- *
- * Data formats (reference types, crypto/src/lib.rs:21-22, 65-66, 178-182):
- *   digest  32 bytes                         (Digest)
- *   pk      32 bytes, compressed Edwards y   (PublicKey)
- *   sig     64 bytes, R (part1) || s (part2) (Signature::flatten, lib.rs:193-198)
- * Arrays are packed: element i of `pks` is at pks + 32*i, of `sigs` at
- * sigs + 64*i, of `digests` at digests + 32*i.
- *
- * Verdict semantics (mode):
- *   HS_ED25519_BATCH  (0)  the equation ed25519-dalek 1.0.1 `verify_batch`
- *                          checks, decided per signature: s < L, A and R on the
- *                          curve, [k](-A) + [s]B == R as points, cofactorless,
- *                          no small-order rejection.  The call accepts iff every
- *                          signature does.  (dalek's randomised sum gives the same
- *                          answer on every input where dalek is deterministic; on
- *                          crafted inputs with a torsion component in A or R its
- *                          answer depends on its random z_i - there the engine
- *                          returns this per-signature verdict.  DESIGN.md section 3.)
- *   HS_ED25519_STRICT (1)  `PublicKey::verify_strict`: BATCH plus reject when
- *                          [8]R == O or [8]A == O.
- *   HS_ED25519_BATCH_RLC (2)  ed25519-dalek 1.0.1 `verify_batch` as it computes it: ONE
- *                          random linear combination  -[sum z_i s_i]B + sum [z_i]R_i +
- *                          sum [z_i h_i mod L]A_i == O  over the whole call (127-bit z_i - dalek
- *                          draws 128 bits; one bit less keeps the signed radix-256 recoding inside
- *                          16 windows - Pippenger multi-scalar multiplication on the GPU).  If it holds the
- *                          call accepts (bitmap all ones); if it does not, the per-signature
- *                          BATCH kernels run in the same call and localise the rejects, so the
- *                          verdict and bitmap are then exactly BATCH's.  Identical to BATCH on
- *                          every input where dalek is deterministic (SURVEY.md 8a classes i / ii);
- *                          on crafted torsion inputs (class iii) it can accept where BATCH
- *                          rejects, with dalek's own probability.  z_i = low 127 bits of
- *                          SHA-512((process secret ^ call number) || h_i || s_i || i):
- *                          unpredictable to whoever built the batch and independent from call to
- *                          call, as dalek's thread_rng draws are (hs_ed25519_set_rlc_key pins the
- *                          key AND drops the call number: reproducible coefficients for tests).
- *
- * Return value of every verify call:
- *    1  every signature accepted (n == 0 -> 1, as lib.rs:206-219 returns Ok)
- *    0  at least one signature rejected
- *   <0  engine error (HS_ED25519_E_*); the caller must treat it as Err - the
- *       engine never reports success on failure and has no CPU fallback inside.
- * bitmap (optional, may be NULL): bit (i & 7) of byte (i >> 3) is 1 iff
- * signature i was accepted; ceil(n/8) bytes are written.
- *
- * Thread safety: every function may be called concurrently from any thread
- * (the reference's tests call verify from several threads of one process,
- * SURVEY.md 8b); calls are served from an internal pool of stream contexts.
+ * include/hs_ed25519_core.h (included below) holds what the reference's shim binds - the twelve functions that replace
+ * crypto/src/lib.rs:200-219 - together with the data formats, verdict semantics, return values and thread-safety
+ * rules, which apply to every function here as well.  This header adds everything else: several GPUs, tenancy,
+ * caller-owned pinned buffers, device-pointer calls, batch lists, the round ring, tickets, sharded calls, wire
+ * decode, batch signing, and the probes / read-outs the bench and the tests use.  A maintainer reviewing the
+ * drop-in reads the core header; nothing in it depends on this one.
  */
 #ifndef HS_ED25519_H
 #define HS_ED25519_H
 
-#include <stddef.h>
-#include <stdint.h>
+#include "hs_ed25519_core.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define HS_ED25519_BATCH 0u
-#define HS_ED25519_STRICT 1u
-#define HS_ED25519_BATCH_RLC 2u
-
-#define HS_ED25519_E_NOT_INIT (-1) /* hs_ed25519_init not called or failed        */
-#define HS_ED25519_E_DEVICE (-2)   /* HIP runtime error (see hs_ed25519_last_error) */
-#define HS_ED25519_E_ARG (-3)      /* null / misaligned pointer, bad mode           */
-#define HS_ED25519_E_NOMEM (-4)    /* allocation failure                            */
-#define HS_ED25519_E_BUSY (-5)     /* hs_ed25519_submit only: every pool context is in flight - wait on a ticket, retry */
-
-/* Select the GPU (HIP ordinal), upload the base-point table and pre-size the
- * context pool for batches of `max_batch` signatures (contexts grow on demand).
- * Idempotent and thread-safe.  Returns 0 or HS_ED25519_E_*. */
-int hs_ed25519_init(int device, size_t max_batch);
 /* Several GPUs behind one process (the reference node is one process: consensus/src/messages.rs:197
  * is called from the single Core task).  `ordinals[0..count)` are HIP device ordinals; entry s becomes
  * device slot s, slot 0 being the primary device every non-sharded call uses.  The same ordinal may
@@ -89,17 +23,17 @@ int hs_ed25519_init(int device, size_t max_batch);
  * different list after a successful init is HS_ED25519_E_ARG (shutdown first). */
 int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch);
 int hs_ed25519_device_count(void);        /* device slots, 0 before init */
-void hs_ed25519_shutdown(void);
 /* Several node processes on ONE GPU (the reference's `fab local` runs four node processes on one host,
  * benchmark/benchmark/local.py:94-104).  Tell the engine, before hs_ed25519_init, that this
  * process is tenant `index` of `tenants` (1..8) on its GPU: it then takes 1/tenants of the stream budget (the
  * device multiplexes every process's streams; past ~16 in flight throughput collapses) and confines its small
  * calls to its own 1/tenants of the compute units, so co-tenants do not stack their batches on the same CUs.
  * Environment HS_ED25519_TENANTS / HS_ED25519_TENANT_INDEX do the same for an unmodified host.  Verdicts are
- * identical with or without it.  hs_ed25519_init exports GPU_MAX_HW_QUEUES (one hardware queue per stream
- * context) unless the host already set it or HS_ED25519_KEEP_ENV=1 forbids touching the environment. */
+ * identical with or without it.  The pools then want hs_ed25519_hw_queue_budget(tenants) hardware queues: the HOST
+ * exports that as GPU_MAX_HW_QUEUES before the HIP runtime starts (hs_ed25519_core.h, hs_ed25519_init). */
 int hs_ed25519_set_tenancy(unsigned tenants, unsigned index);
-/* The GPU_MAX_HW_QUEUES value hs_ed25519_init exports for a process that is one of `tenants` (1..8) on its GPU: 16 for a
+/* The GPU_MAX_HW_QUEUES value the host should export (in main(), before any thread starts and before the HIP runtime
+ * initialises; hs_ed25519_init itself only sets it under HS_ED25519_SET_ENV=1) for a process that is one of `tenants` (1..8) on its GPU: 16 for a
  * process alone; for co-tenants one hardware queue per pool context + 1 (11 / 6 / 4 for 2 / 4 / 8 tenants).  The GPU's
  * hardware scheduler runs ~28 user queues at once across ALL processes; past that every process is time-sliced
  * (profiles/r4_c_queue_probe_pools_of_7.md), so co-tenants keep well below it.  Pure function, no device needed - a host whose runtime
@@ -113,11 +47,6 @@ unsigned hs_ed25519_hw_queue_budget(unsigned tenants);
  * or hs_ed25519_submit returns.  NULL on failure (hs_ed25519_last_error). */
 void *hs_ed25519_host_alloc(size_t bytes);
 void hs_ed25519_host_free(void *p);
-/* The batch size below which a call should stay on the CPU path of the shim (dalek): the GPU round
- * trip costs one wavefront's serial chain (~0.36-0.4 ms cold, ~0.09-0.12 ms with registered keys) whatever n
- * is.  keys_registered != 0: the caller would use a *_cached entry point.  bench.py measures the
- * crossover (`small_batch_crossover`); env HS_ED25519_MIN_GPU_BATCH overrides. */
-size_t hs_ed25519_min_gpu_batch(int keys_registered);
 /* HS_ED25519_BATCH_RLC draws its 127-bit coefficients from SHA-512 keyed with a 32-byte secret taken
  * from the OS at first use, mixed with a per-call sequence number (host side, at enqueue) and a per-execution
  * counter kept in the context's workspace on the device (so a round replayed from a captured hipGraph draws fresh
@@ -128,19 +57,6 @@ int hs_ed25519_set_rlc_key(const uint8_t key[32]);
  * only pays from a few thousand signatures up; profiles/r2_rlc_ab.md).  A context can override the
  * threshold (tests run the pipeline from n = 1); 0 restores the default. */
 size_t hs_ed25519_rlc_min_batch(void);
-/* Human-readable text of the last engine error seen by the calling thread. */
-const char *hs_ed25519_last_error(void);
-
-/* Signature::verify_batch / QC::verify shape: one digest shared by n pairs.
- * Replaces crypto/src/lib.rs:206-219 (called at consensus/src/messages.rs:197). */
-int hs_ed25519_verify_shared(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs,
-                             size_t n, uint32_t mode, uint8_t *bitmap);
-
-/* TC::verify shape: one digest per pair.  Replaces the loop of
- * Signature::verify calls at consensus/src/messages.rs:307-313 (mode STRICT),
- * and with n = 1 a single crypto/src/lib.rs:200-204 call. */
-int hs_ed25519_verify_multi(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs,
-                            size_t n, uint32_t mode, uint8_t *bitmap);
 
 /* ---- device-resident variant (streamed rounds, benchmarks, multi-GPU shards) ----
  * All data pointers are DEVICE pointers on the initialised GPU, 16-byte aligned.
@@ -197,26 +113,13 @@ typedef struct hs_ed25519_batch {
 } hs_ed25519_batch;
 int hs_ed25519_verify_device_batches(hs_ed25519_ctx *ctx, const hs_ed25519_batch *batches, size_t count, void *stream);
 
-/* ---- committee key cache -------------------------------------------------------------------
- * Every key the reference verifies belongs to the committee, which is static per epoch
- * (consensus/src/config.rs:39-43).  hs_ed25519_keyset_create decompresses the n_keys public
- * keys once and builds per-key window tables in HBM (528,420 bytes per key; see
- * hs_ed25519_keyset_bytes) so that a verification needs no doublings and no decompression of A:
- * 32 additions from the key's table + 16 from the base point's own 16-bit-window table (67 MB per
- * GPU, built inside hs_ed25519_init) + 1 square root or inversion for R.  The *_cached calls take key_idx[i] = position of
- * signature i's key in the set instead of the key bytes (the Rust shim resolves it with the
- * same map QC::verify / TC::verify already use for the stake lookup,
- * consensus/src/messages.rs:182-194); an index >= n_keys rejects that signature.  Accept set,
- * return values, bitmap format, modes and alignment rules are identical to the calls above.
- * A key set is immutable and may be used concurrently from any number of threads/streams. */
-typedef struct hs_ed25519_keyset hs_ed25519_keyset;
-int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys);   /* device slot 0 */
+/* ---- committee key cache: the extended forms (hs_ed25519_core.h declares keyset_create / _destroy and
+ * verify_shared_cached / verify_tc_cached and describes the cache) ---------------------------------------------
+ * A verification through a key set is 32 additions from the key's table + 16 from the base point's own
+ * 16-bit-window table (67 MB per GPU, built inside hs_ed25519_init) + 1 square root or a share of an inversion for R. */
 int hs_ed25519_keyset_create_on(hs_ed25519_keyset **out, const uint8_t *pks, size_t n_keys, int slot);
-void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks);
 size_t hs_ed25519_keyset_size(const hs_ed25519_keyset *ks);
 size_t hs_ed25519_keyset_bytes(size_t n_keys);   /* HBM footprint of a key set of that size */
-int hs_ed25519_verify_shared_cached(const hs_ed25519_keyset *ks, const uint8_t digest[32], const uint32_t *key_idx,
-                                    const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap);
 int hs_ed25519_verify_multi_cached(const hs_ed25519_keyset *ks, const uint8_t *digests, const uint32_t *key_idx,
                                    const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bitmap);
 int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,
@@ -227,16 +130,8 @@ int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset
 int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const hs_ed25519_batch *batches,
                                             size_t count, void *stream);
 
-/* ---- TC::verify with the per-vote digests built on the device ------------------------------
- * consensus/src/messages.rs:307-313 hashes SHA-512(round_le || high_qc_round_le)[..32] on the
- * host for every vote before each Signature::verify; these entry points take the certificate's
- * round and the n high_qc_round values (uint64, host order) and hash on the GPU, so a timeout
- * certificate costs one call and no host hashing.  Strict semantics; return values, bitmap and
- * alignment rules as above (high_qc_rounds: 8-byte aligned on the device form). */
-int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const uint8_t *pks, const uint8_t *sigs,
-                         size_t n, uint8_t *bitmap);
-int hs_ed25519_verify_tc_cached(const hs_ed25519_keyset *ks, uint64_t round, const uint64_t *high_qc_rounds,
-                                const uint32_t *key_idx, const uint8_t *sigs, size_t n, uint8_t *bitmap);
+/* ---- TC::verify with the per-vote digests built on the device: the device-pointer forms (host forms: core header) ----
+ * high_qc_rounds: 8-byte aligned. */
 int hs_ed25519_verify_device_tc(hs_ed25519_ctx *ctx, uint64_t round, const uint64_t *d_high_qc_rounds,
                                 const uint8_t *d_pks, const uint8_t *d_sigs, size_t n, uint8_t *d_bitmap,
                                 uint32_t *d_nreject, void *stream);
@@ -311,9 +206,17 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
  * two-lane + R-wavefront kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
  * the batch count (3 pins it to the one-signature-per-quad form, 1 to the one-lane pair over the
  * batch list), 5 = key cache: the two-launch form at any size, batch lists included (cold calls as 0, except that a cold batch
- * list stays on the quad kernels).  All have the same accept set.  Returns the previous choice or
- * HS_ED25519_E_ARG.  (Beaten variants - quad stage 2, four-lane cached forms - are only built
- * with -DHS_AB_VARIANTS and are not part of the shipped library.) */
+ * list stays on the quad kernels), 6 / 7 = cold single calls of up to 8 signatures per SIMD: the one-wavefront eight-lane form
+ * (k_verify_fused8) / the split form with a helper wavefront (k_verify_fused8h) whatever hs_ed25519_autotune chose (larger calls
+ * and batch lists as 0) - what bench.py uses to time BOTH forms on the box it runs on.  All have the same accept set.  Returns
+ * the previous choice or HS_ED25519_E_ARG. */
+#define HS_ED25519_K_AUTO 0
+#define HS_ED25519_K_LANE 1
+#define HS_ED25519_K_FUSED 3
+#define HS_ED25519_K_FUSED_PAIRS 4
+#define HS_ED25519_K_CACHED_C 5
+#define HS_ED25519_K_OCT 6
+#define HS_ED25519_K_OCT_SPLIT 7
 int hs_ed25519_ctx_set_kernel(hs_ed25519_ctx *ctx, int which);
 
 /* Latency form or throughput form.  By default a context assumes its call has the GPU to itself (the reference's
@@ -330,10 +233,26 @@ int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *ctx, int concurrent);
 const char *hs_ed25519_dominant_kernel(void);              /* for a 1,024-signature batch */
 const char *hs_ed25519_dominant_kernel_for(size_t n);      /* for an n-signature cold-path call */
 const char *hs_ed25519_cached_kernel_for(size_t n);        /* for a LONE n-signature key-cache call (k_verify_cached_lane2r up to 98,304
-                                                            * signatures; above, k_cached_chain2 followed by k_cached_finish - on a GPU the
-                                                            * init probe found slow-feeding from 196,608 only, k_verify_cached_lane in
-                                                            * between; on a context marked concurrent the two-launch form from 49,152) */
+                                                            * signatures; above, k_cached_chain2 followed by k_cached_finish; on a
+                                                            * context marked concurrent the two-launch form from 49,152) */
 const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t count);   /* hs_ed25519_verify_device_batches of `count` batches */
+
+/* ---- measured kernel choice, and what the library resolved ---------------------------------------------------
+ * Between 4,097 and 8,192 signatures (more than half a wavefront slot per SIMD) the faster of the two eight-lane cold forms
+ * depends on the GPU in a way no static property predicts (round 4: boxes of one SKU, VBIOS, firmware and clocks differ by
+ * 3 - 10 % in either direction; the driver's box contradicted the instruction-feed proxy that round used).  So the library
+ * measures the thing itself: hs_ed25519_init - and this call, on demand (after a power-cap or clock change, say) - times
+ * k_verify_fused8 and k_verify_fused8h on a canned, valid 6,667-signature batch (the QC of N = 10,000; signed on the
+ * device; three alternating runs each, minima of the dispatch timestamps; ~3 ms in all) on device slot `slot` and keeps the
+ * faster for that slot.  ms[0] = one-wavefront form, ms[1] = split form (ms may be NULL).  Returns the pick (0 / 1) or
+ * HS_ED25519_E_*; a form whose run did not accept the whole canned batch is an engine error, never a pick.
+ * HS_ED25519_OCT_SPLIT=0 / 1 in the environment pins the form instead; HS_ED25519_AUTOTUNE=0 skips the measurement at
+ * init (the split form is then used throughout - the choice of two boxes in three). */
+int hs_ed25519_autotune(int slot, double ms[2]);
+/* Every value the library resolved at init - pools, tenancy, thresholds, environment overrides seen, the hardware-queue
+ * budget against the GPU_MAX_HW_QUEUES it found, per device slot the autotune times and pick - as one JSON object.
+ * Writes at most cap bytes (NUL-terminated) and returns the length the full text needs (snprintf convention). */
+size_t hs_ed25519_config_dump(char *buf, size_t cap);
 
 /* ---- one call over several GPUs (BASELINE configs[3]: a 100,000-validator QC on 8 x MI355X) ----
  * After hs_ed25519_init_devices with k slots these cut the batch into k contiguous shards of
@@ -360,7 +279,10 @@ int hs_ed25519_shard_rccl_ranks(void);    /* ranks of the in-process RCCL exchan
  * HS_ED25519_BATCH's.  Runs from hs_ed25519_shard_msm_min() signatures up (default hs_ed25519_rlc_min_batch() x device slots:
  * below ~40,000 signatures per device the per-signature kernels answer sooner; env HS_ED25519_SHARD_MSM_MIN or
  * hs_ed25519_set_shard_msm_min override), below that as HS_ED25519_BATCH.  hs_ed25519_shard_msm_stats: calls that ran the
- * combination and how many of them it accepted outright. */
+ * combination and how many of them it accepted outright; its return value counts the combinations that were asked to
+ * travel by RCCL but went through pinned host memory because the collective could not be SET UP (no librccl, a device list
+ * ncclCommInitAll refuses, no memory for the gather buffers) - the records are still on their devices then, so the call
+ * verifies instead of failing; an error after the grouped call has started is returned as an error. */
 size_t hs_ed25519_shard_msm_min(void);
 int hs_ed25519_set_shard_msm_min(size_t n);
 int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts);

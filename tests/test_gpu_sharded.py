@@ -204,3 +204,28 @@ def test_one_combination_through_the_rccl_exchange_one_slot(oracle):
         lib.hs_ed25519_set_shard_msm_min(0)
         lib.hs_ed25519_set_shard_exchange(old)
         lib.hs_ed25519_shard_reset()
+
+
+def test_one_combination_falls_back_to_the_host_exchange_when_rccl_cannot_be_set_up(oracle, three_slots):
+    """three device slots on ONE GPU is a device list ncclCommInitAll cannot serve (rccl_ensure refuses it).  A sharded
+    BATCH_RLC call asked to exchange by RCCL used to fail outright there, although every device still held its 384-byte
+    record; now it joins them through pinned host memory, says so in the stats, and the verdicts are the oracle's."""
+    lib = _lib.lib()
+    old = lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_RCCL)
+    lib.hs_ed25519_set_shard_msm_min(1)
+    try:
+        n = 1500
+        dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+        f0 = lib.hs_ed25519_shard_msm_stats(None, None)
+        c0, a0 = _lib.shard_msm_stats()
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)
+        assert ok and all(bits(bm, n)) and _lib.shard_msm_stats() == (c0 + 1, a0 + 1)
+        assert lib.hs_ed25519_shard_msm_stats(None, None) == f0 + 1
+        dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=20)
+        expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)
+        ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)
+        assert not ok and bits(bm, n) == expect
+    finally:
+        lib.hs_ed25519_set_shard_msm_min(0)
+        lib.hs_ed25519_set_shard_exchange(old)
+        lib.hs_ed25519_shard_reset()
