@@ -50,6 +50,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+METRIC = "Ed25519 verifies/sec (whole node) + QC-verify p50 latency at N validators"     # BASELINE.json's metric, verbatim: `value` is
+# its first half; the second half is config.qc_verify_p50_ms_* at config.qc_validators (the driver's record keeps `config`)
 ALGO_BYTES_MULTI = 128      # 32 B digest + 32 B key + 64 B signature per verification
 ALGO_BYTES_SHARED = 96
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -250,6 +252,51 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     assert all((int(w) & ((1 << 64) - 1)) == (1 << 64) - 1 for w in full), "QC bitmap"
     kt = ctx.kernel_times()
     cold_kernel_ms = (kt[0] + kt[1]) / max(1, kt[2])
+    # (b') BOTH eight-lane cold forms on THIS box, in this run: the library chose one of them by timing both
+    # at init (hs_ed25519_autotune); here each runs in four alternating blocks of 30 calls through the per-context selectors,
+    # kernel time from the dispatch timestamps, call time from the host clock - so the line shows which form is faster here,
+    # by how much, and whether the library's pick agrees
+    forms = {}
+    try:
+        acc = {"k_verify_fused8": ([], [0.0, 0]), "k_verify_fused8h": ([], [0.0, 0])}
+        with torch.cuda.stream(st):
+            for block in range(4):
+                for name, sel in (("k_verify_fused8", _lib.KERNEL_OCT), ("k_verify_fused8h", _lib.KERNEL_OCT_SPLIT)):
+                    ctx.set_kernel(sel)
+                    ctx.set_profiling(30)
+                    for i in range(32):
+                        nr.zero_()
+                        st.synchronize()
+                        t0 = time.perf_counter()
+                        ctx.verify(d_dg.data_ptr(), 0, d_pk.data_ptr(), d_sg.data_ptr(), n, _lib.BATCH, bm.data_ptr(), nr.data_ptr(), ctx.stream)
+                        bad = int(nr.item())
+                        dt = time.perf_counter() - t0
+                        assert bad == 0, "device-resident QC (%s): %d rejects" % (name, bad)
+                        if i >= 2:
+                            acc[name][0].append(dt)
+                    k = ctx.kernel_times()
+                    acc[name][1][0] += k[0] + k[1]
+                    acc[name][1][1] += k[2]
+        ctx.set_kernel(_lib.KERNEL_AUTO)
+        for name, (lat, (ms, cnt)) in acc.items():
+            lat.sort()
+            forms[name] = {"kernel_ms": round(ms / max(1, cnt), 4), "call_p50_ms": round(lat[len(lat) // 2] * 1e3, 4)}
+        faster = min(forms, key=lambda k: forms[k]["kernel_ms"])
+        slower = max(forms, key=lambda k: forms[k]["kernel_ms"])
+        forms["faster_here"] = faster
+        forms["faster_by"] = round(forms[slower]["kernel_ms"] / forms[faster]["kernel_ms"] - 1.0, 4)
+    except Exception as e:      # noqa: BLE001
+        forms = {"error": "%s: %s" % (type(e).__name__, e)}
+        ctx.set_kernel(_lib.KERNEL_AUTO)
+    try:
+        cfg = _lib.config_dump()
+        d0 = cfg["devices"][0]
+        forms["library"] = {"chosen": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
+                            "chosen_by": ("environment HS_ED25519_OCT_SPLIT" if cfg["oct_split_forced"] >= 0 else
+                                          "hs_ed25519_autotune at init" if d0["oct_pick"] != "not measured" else "default (not measured)"),
+                            "autotune_ms": d0["oct_ms"]}
+    except Exception as e:      # noqa: BLE001
+        forms["library"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # (c) the same QC with the whole committee registered as a key set (static per epoch)
     t0 = time.perf_counter()
     keys = [pk[32 * i:32 * i + 32] for i in range(n)]
@@ -298,12 +345,15 @@ def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
     return {"n_validators": validators, "signatures": n, "calls": calls, "cpu": cpu, "env": env,
             "p10_p50_p99_ms_device_resident": [round(f(devt) * 1e3, 4) for f in (p10, med, p99)],
             "kernel_ms_device_resident": round(cold_kernel_ms, 4), "kernel": _lib.lib().hs_ed25519_dominant_kernel_for(n).decode(),
+            "cold_forms": forms,
             "p50_ms_host_api": round(med(host) * 1e3, 4), "p99_ms_host_api": round(p99(host) * 1e3, 4),
             "p50_ms_host_api_caller_pinned": round(med(pinned) * 1e3, 4) if pinned else None,
             "p50_ms_device_resident": round(med(devt) * 1e3, 4),
             "verifies_per_s_at_p50_host_api": round(n / med(host), 1),
             "committee_cached": {"keys": validators, "keyset_hbm_bytes": ks_bytes, "keyset_build_ms": round(build_ms, 1),
+                                 "kernel": _lib.lib().hs_ed25519_cached_kernel_for(n).decode(),
                                  "p50_ms_host_api": round(med(hostc) * 1e3, 4),
+                                 "verifies_per_s_at_p50_host_api": round(n / med(hostc), 1),
                                  "p50_ms_device_resident": round(med(devc) * 1e3, 4),
                                  "p10_p50_p99_ms_device_resident": [round(f(devc) * 1e3, 4) for f in (p10, med, p99)],
                                  "kernel_ms_device_resident": round(cached_kernel_ms, 4)}}
@@ -635,50 +685,172 @@ def sharded_c_abi(ngpus, ndev, validators=100000, timeout_s=150):
     return json.loads(lines[-1])
 
 
-def live_traffic(kernels=("k_verify_batches", "k_prepare_batches"), timeout_s=120):
-    """HBM-side bytes per launch of the headline pair, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE do not fit one pass; no trace domains beside the counters) over SOLO launches of the pair
-    (tools/pmc_solo.py headline: one launch at a time, the stream drained in between, so the chip-wide TCC counters of a
-    dispatch hold that dispatch's traffic only), summed over the counter's instances, the first two dispatches dropped,
-    corrected with the calibration in profiles/r3_pmc_calibration.json (FETCH_SIZE reports half of the 128-byte lines
-    fetched; WRITE_SIZE is exact for whole lines).  Returns None when rocprofv3 is not there."""
+PMC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+            ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"))
+CALIBRATION = os.path.join("profiles", "pmc_calibration.json")
+
+
+def pmc_passes(timeout_s=150):
+    """Counters of every kernel whose roofline this line quotes, measured IN THIS RUN: three rocprofv3 --pmc passes (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass; the SQ set is the third; no trace domains beside the counters) over SOLO launches
+    (tools/pmc_solo.py bench: one launch at a time, the stream drained in between, so the chip-wide counters of a dispatch hold
+    that dispatch only), summed over a counter's instances, the first two dispatches of each kernel@grid dropped.
+    FETCH_SIZE / WRITE_SIZE are corrected with the calibration in profiles/pmc_calibration.json (FETCH_SIZE reports half of the
+    128-byte lines fetched; WRITE_SIZE is exact for whole lines; tools/pmc_calibrate.py).  Returns
+    {"kernel@workgroups": {counter: per-dispatch average, "read_bytes", "write_bytes", "bytes"}, "calibration": {...}} or None
+    when rocprofv3 is not there."""
     import glob
     import shutil
     import sqlite3
     import tempfile
     if not shutil.which("rocprofv3"):
         return None
-    cal = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_calibration.json")))["factors"]
+    cal = json.load(open(os.path.join(ROOT, CALIBRATION)))["factors"]
     f_read, f_write = cal["fetch_line_gather_16B"], cal["write_wide_16B"]
     env = dict(os.environ, TMPDIR="/tmp")
-    res = {k: {} for k in kernels}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    res, errors = {}, []
+    for counters in PMC_SETS:
         d = tempfile.mkdtemp(prefix="hs_pmc_", dir="/tmp")
         try:
-            subprocess.run(["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_solo.py"), "headline"],
-                           capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            r = subprocess.run(["rocprofv3", "--pmc", *counters, "-d", d, "-o", "p", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_solo.py"), "bench"],
+                               capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
             dbs = glob.glob(os.path.join(d, "**", "p_results.db"), recursive=True)
             if not dbs:
-                return None
+                errors.append("%s: no results (rc %d): %s" % (counters[0], r.returncode, (r.stderr or "")[-200:]))
+                continue
             db = sqlite3.connect(dbs[0])
-            rows = db.execute("select name, dispatch_id, sum(counter_value) from pmc_events where counter_name = ? group by name, dispatch_id "
-                              "order by dispatch_id", (counter,)).fetchall()
-            for k in kernels:
-                v = [val for name, _, val in rows if name.split("(")[0] == k][2:]
-                if v:
-                    res[k][counter] = sum(v) / len(v) * 1024.0          # rocprofv3 reports KB
+            grid = {did: gx // max(1, wx) for did, gx, wx in
+                    db.execute("select dispatch_id, grid_size_x, workgroup_size_x from rocpd_kernel_dispatch")}
+            rows = db.execute("select name, dispatch_id, counter_name, sum(counter_value) from pmc_events "
+                              "group by name, dispatch_id, counter_name order by dispatch_id").fetchall()
+            per = {}
+            for name, did, counter, val in rows:
+                per.setdefault(("%s@%d" % (name.split("(")[0], grid.get(did, 0)), counter), []).append(val)
+            for (key, counter), vals in per.items():
+                vals = vals[2:] if len(vals) > 2 else vals
+                res.setdefault(key, {})[counter] = sum(vals) / len(vals)
+        except Exception as e:      # noqa: BLE001 - a pass that fails costs its counters, not the line
+            errors.append("%s: %s: %s" % (counters[0], type(e).__name__, e))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    out = {}
-    for k in kernels:
-        if "FETCH_SIZE" in res[k] and "WRITE_SIZE" in res[k]:
-            rd, wr = res[k]["FETCH_SIZE"] * f_read, res[k]["WRITE_SIZE"] * f_write
-            out[k] = {"read_bytes": int(rd), "write_bytes": int(wr), "bytes": int(rd + wr),
-                      "FETCH_SIZE_reported": int(res[k]["FETCH_SIZE"]), "WRITE_SIZE_reported": int(res[k]["WRITE_SIZE"])}
-    if not out:
+    for key, c in res.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rd, wr = c["FETCH_SIZE"] * 1024.0 * f_read, c["WRITE_SIZE"] * 1024.0 * f_write      # rocprofv3 reports KB
+            c.update({"read_bytes": int(rd), "write_bytes": int(wr), "bytes": int(rd + wr)})
+    if not res:
+        return {"error": "; ".join(errors) or "no counters"}
+    res["calibration"] = {"file": CALIBRATION, "fetch_factor": f_read, "write_factor": f_write}
+    if errors:
+        res["errors"] = errors
+    return res
+
+
+def pmc_pick(pmc, kernel, workgroups=None):
+    """the counters of `kernel` (at a launch of `workgroups` workgroups, when several sizes were launched) out of pmc_passes()"""
+    if not pmc or "error" in pmc:
         return None
-    out["calibration"] = {"file": "profiles/r3_pmc_calibration.json", "fetch_factor": f_read, "write_factor": f_write}
-    return out
+    keys = [k for k in pmc if "@" in k and k.split("@")[0] == kernel]
+    if workgroups is not None:
+        keys = [k for k in keys if int(k.split("@")[1]) == workgroups]
+    return pmc[keys[0]] if len(keys) == 1 else None
+
+
+def cached_rooflines(cached, pmc, n, stride):
+    """HBM rooflines of the key-cache kernels from THIS run's counter passes (round 4 read a round-3 file and
+    counted table lines as algorithmic bytes).  `frac` prices SURVEY 8d's algorithmic bytes - what the reference's call consumes
+    per verification: 96 B with one shared digest, 128 B with one per tuple - against the 8 TB/s peak; the 48 table lines of
+    128 B a verification gathers BY DESIGN (32 of the key's table, 16 of the base point's) are `design_traffic`, with its rate
+    and its ratio to the algorithmic bytes; `traffic` is what the counters saw."""
+    def roof(kernel_ms, sigs, per_verify, counters, kernels):
+        algo, design = per_verify * sigs, (32 + 16) * 128 * sigs
+        r = {"bound": "hbm", "kernel": kernels, "achieved": round(algo / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": algo,
+             "algorithmic_bytes_per_verification": per_verify, "avg_kernel_ms": round(kernel_ms, 4),
+             "design_traffic": design, "design_traffic_over_algorithmic": round(design / algo, 1),
+             "design_traffic_GBps": round(design / (kernel_ms * 1e-3) / 1e9, 1),
+             "design_traffic_note": "48 table lines x 128 B per verification (32 from the key set, 16 from the base point's 16-bit table): "
+                                    "the gather the key cache trades for the doublings - a rate worth knowing, not algorithmic bytes",
+             "traffic": None, "traffic_source": "unmeasured (no counter pass in this run)"}
+        got = [c for c in counters if c and "bytes" in c]
+        if got and len(got) == len(counters):
+            tr = sum(c["bytes"] for c in got)
+            r.update({"traffic": tr, "traffic_over_algorithmic": round(tr / algo, 1), "traffic_over_design": round(tr / design, 3),
+                      "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over solo launches (tools/pmc_solo.py bench), calibrated"})
+        return r
+    KC = cached["batches_per_launch"]
+    cached["roofline"] = roof(cached["avg_kernel_ms"], n * KC, ALGO_BYTES_MULTI if stride else ALGO_BYTES_SHARED,
+                              [pmc_pick(pmc, "k_verify_cached_lane2r_batches")], "k_verify_cached_lane2r_batches")
+    lc = cached.get("large_committee")
+    if isinstance(lc, dict) and "avg_kernel_ms" in lc:
+        nl = lc["signatures"]
+        wg = (nl + 63) // 64
+        if lc["kernel"] == "k_verify_cached_lane2r":
+            ctrs, names = [pmc_pick(pmc, "k_verify_cached_lane2r", wg)], "k_verify_cached_lane2r"
+        else:
+            ctrs, names = [pmc_pick(pmc, "k_cached_chain2", wg), pmc_pick(pmc, "k_cached_finish")], "k_cached_chain2 + k_cached_finish"
+        lc["roofline"] = roof(lc["avg_kernel_ms"], nl, ALGO_BYTES_SHARED, ctrs, names)
+        two = [pmc_pick(pmc, "k_cached_chain2", wg), pmc_pick(pmc, "k_cached_finish")]
+        if all(c and "bytes" in c for c in two):
+            lc["two_launch_form_traffic"] = {"k_cached_chain2": two[0]["bytes"], "k_cached_finish": two[1]["bytes"],
+                                             "over_algorithmic": round((two[0]["bytes"] + two[1]["bytes"]) / (ALGO_BYTES_SHARED * nl), 1),
+                                             "valu_wave_insts_per_verify": round((two[0].get("SQ_INSTS_VALU", 0) + two[1].get("SQ_INSTS_VALU", 0)) / nl, 1)}
+
+
+def summarise_extras(cfg, detail, pmc):
+    """The headline scalars of the extras, flat, into `config` - the part of the line the driver's record keeps: the second half of
+    BASELINE.json's metric (QC-verify p50 at N validators, cold and through the key cache, device-resident and host API), both cold
+    forms' kernel time on this box with the SQ counters of each, the one-synchronous-caller rates, tenants, streamed rounds."""
+    q = detail.get("qc_verify_latency", {})
+    if "error" in q:
+        cfg["qc_error"] = q["error"][:120]
+    elif q:
+        c = q["committee_cached"]
+        cfg.update({"qc_validators": q["n_validators"], "qc_signatures": q["signatures"],
+                    "qc_verify_p50_ms_cold": q["p50_ms_device_resident"], "qc_verify_p50_ms_key_cache": c["p50_ms_device_resident"],
+                    "qc_verify_p99_ms_cold": q["p10_p50_p99_ms_device_resident"][2], "qc_verify_p99_ms_key_cache": c["p10_p50_p99_ms_device_resident"][2],
+                    "qc_verify_p50_ms_cold_host_api": q["p50_ms_host_api"], "qc_verify_p50_ms_key_cache_host_api": c["p50_ms_host_api"],
+                    "qc_kernel_ms_cold": q["kernel_ms_device_resident"], "qc_kernel_ms_key_cache": c["kernel_ms_device_resident"],
+                    "qc_kernel_cold": q["kernel"], "qc_kernel_key_cache": c.get("kernel"),
+                    "one_sync_caller_verifies_per_s_qc_cold": q["verifies_per_s_at_p50_host_api"],
+                    "one_sync_caller_verifies_per_s_qc_key_cache": c.get("verifies_per_s_at_p50_host_api")})
+        f = q.get("cold_forms", {})
+        for name in ("k_verify_fused8", "k_verify_fused8h"):
+            if name in f:
+                cfg["qc_kernel_ms_%s" % name[2:]] = f[name]["kernel_ms"]
+                cfg["qc_call_p50_ms_%s" % name[2:]] = f[name]["call_p50_ms"]
+        if "faster_here" in f:
+            cfg["qc_cold_form_faster_here"], cfg["qc_cold_form_faster_by"] = f["faster_here"], f["faster_by"]
+        lib_ = f.get("library", {})
+        if "chosen" in lib_:
+            cfg["qc_cold_form_chosen"], cfg["qc_cold_form_chosen_by"] = lib_["chosen"], lib_["chosen_by"]
+            cfg["autotune_ms_verify_fused8"] = lib_["autotune_ms"].get("k_verify_fused8")
+            cfg["autotune_ms_verify_fused8h"] = lib_["autotune_ms"].get("k_verify_fused8h")
+        # one solo rocprofv3 SQ pass of the QC kernels (6,667 signatures): what would explain a kernel-time difference between boxes
+        n = q["signatures"]
+        for name, wg in (("k_verify_fused8", (n + 63) // 64 * 8), ("k_verify_fused8h", (n + 63) // 64 * 8), ("k_verify_cached_lane2r", (n + 63) // 64)):
+            c_ = pmc_pick(pmc, name, wg)
+            if c_:
+                for ctr, short in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_BUSY_CYCLES", "busy_cycles"),
+                                   ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_WAVES", "waves")):
+                    if ctr in c_:
+                        cfg["sq_%s_%s" % (name[2:], short)] = round(c_[ctr])
+    mp = detail.get("multi_process", {})
+    for r_ in mp.get("rows", []) if isinstance(mp, dict) else []:
+        if r_.get("processes") == 4 and r_.get("tenancy_hint") and "value" in r_:
+            cfg["four_tenants_verifies_per_s"] = r_["value"]
+            cfg["four_tenants_max_over_min"] = round(max(r_["per_process"]) / max(1.0, min(r_["per_process"])), 3)
+    sr = detail.get("streamed_rounds", {})
+    for key, short in (("cold_zero_copy", "streamed_rounds_cold_signatures_per_s"), ("key_cache_zero_copy", "streamed_rounds_key_cache_signatures_per_s")):
+        if isinstance(sr.get(key), dict):
+            cfg[short] = sr[key]["signatures_per_s"]
+    ab = detail.get("rlc_ab", {})
+    for nn in ("6667", "66667"):
+        if isinstance(ab.get(nn), dict) and "rlc_msm" in ab[nn]:
+            cfg["rlc_p50_ms_%s" % nn], cfg["per_signature_p50_ms_%s" % nn] = ab[nn]["rlc_msm"]["p50_ms"], ab[nn]["per_signature"]["p50_ms"]
+    sb = detail.get("small_batch_crossover", {})
+    if "measured_crossover_n" in sb:
+        cfg["small_batch_crossover_n_cold"], cfg["small_batch_crossover_n_key_cache"] = sb["measured_crossover_n"]["cold"], sb["measured_crossover_n"]["key_cache"]
 
 
 def launcher_command(ngpus, argv, port=None):
@@ -751,6 +923,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events (diagnostic)")
     ap.add_argument("--event-stride", type=int, default=16, help="record HIP events on every k-th call per context")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline + cpu_baseline only")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the three rocprofv3 counter passes (traffic, SQ counters)")
+    ap.add_argument("--detail-file", default=os.environ.get("HS_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
+                    help="where the verbose extras go (the line carries their headline scalars in `config` and this path)")
     ap.add_argument("--partitions", type=int, default=None,
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
                          "default 8 (one XCD each, two stream contexts per slice) for batches up to 4,096 signatures, 0 above)")
@@ -1013,29 +1188,35 @@ def main():
             l_el = time.perf_counter() - t0
             assert int(l_nr.item()) == 0
             lk_ms = (lctx.kernel_times()[0] + lctx.kernel_times()[1]) / max(1, lctx.kernel_times()[2])
-            # bytes of table lines read per launch: one 128-byte affine entry per 8-bit window of the key's table (32) and per
-            # 16-bit window of the base point's 67 MB table (16; larger than the L2s, so these come from MALL / HBM as well)
-            gather = (32 + 16) * 128 * nl
-            l_traffic = l_src = None
-            try:    # HBM-side bytes per launch from the committed SOLO rocprofv3 pass (same kernel, same launch size), calibrated
-                lk_name = _lib.lib().hs_ed25519_cached_kernel_for(nl).decode()
-                for key, row in json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["kernels"].items():
-                    if key.split("@")[0] == lk_name and row["signatures_per_launch"] == nl:
-                        l_traffic = row["hbm_bytes_per_launch"]
-                        l_src = ("profiles/r3_pmc_traffic.json: solo launch, FETCH_SIZE x %.3f (this project's calibration of one-line 16-byte "
-                                 "gathers, profiles/r3_pmc_calibration.json) + WRITE_SIZE" % row["fetch_factor"])
-            except Exception:
-                pass
+            # the same QC with four calls in flight on contexts marked concurrent: the two-launch form (chains + batched finish)
+            four = None
+            try:
+                cx = [_lib.DeviceContext(nl) for _ in range(4)]
+                cbm = [torch.zeros(8 * ((nl + 63) // 64), dtype=torch.uint8, device=dev) for _ in range(4)]
+                cst = [torch.cuda.ExternalStream(c.stream, device=dev) for c in cx]
+                for c in cx:
+                    c.set_concurrent(True)
+                torch.cuda.synchronize(dev)
+                for i in range(3 + 12):
+                    if i == 3:
+                        for s_ in cst:
+                            s_.synchronize()
+                        t0 = time.perf_counter()
+                    for j, c in enumerate(cx):
+                        c.verify_cached(lks, l_dg.data_ptr(), 0, l_ki.data_ptr(), l_sg.data_ptr(), nl, _lib.BATCH, cbm[j].data_ptr(), 0, c.stream)
+                for s_ in cst:
+                    s_.synchronize()
+                four = round(12 * 4 * nl / (time.perf_counter() - t0), 1)
+                assert all(bool((b_.view(torch.int64)[: nl // 64] == -1).all()) for b_ in cbm), "a concurrent key-cache QC was not all ones"
+                for c in cx:
+                    c.close()
+            except Exception as e:      # noqa: BLE001
+                four = {"error": "%s: %s" % (type(e).__name__, e)}
             cached["large_committee"] = {
                 "n_validators": Nv, "signatures": nl, "keyset_hbm_bytes": lks.hbm_bytes(),
                 "kernel": _lib.lib().hs_ed25519_cached_kernel_for(nl).decode(), "avg_kernel_ms": round(lk_ms, 4),
                 "value": round(nl * reps / l_el, 1), "unit": "verifies/s",
-                "roofline": {"bound": "hbm", "achieved": round(gather / (lk_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(gather / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                             "algorithmic_bytes_per_launch": gather, "traffic": l_traffic,
-                             "traffic_source": l_src,
-                             "note": "48 table entries x 128 B (one cache line each) per verification: 32 gathered from the key set, "
-                                     "16 from the base point's 16-bit table"}}
+                "four_in_flight_two_launch_form_signatures_per_s": four}
             lctx.close(); lks.close()
         except Exception as e:        # never let the extra break the headline
             cached["large_committee"] = {"error": str(e)}
@@ -1056,28 +1237,24 @@ def main():
                    else _lib.lib().hs_ed25519_dominant_kernel_for(n).decode())
     for c in ctxs:
         c.close()
-    # HBM-side traffic of the dominant kernel: measured in THIS run when the default workload is timed (rocprofv3 in a
-    # subprocess, solo launches, calibrated - live_traffic), else / on failure the committed solo pass of the same kernel
-    traffic = traffic_src = traffic_detail = None
-    if rank == 0 and world == 1 and not args.no_extras and kernel_name == "k_verify_batches" and n * K == 16384:
+    # Counters of the kernels this line quotes, measured in THIS run when the default workload is timed: three rocprofv3 passes
+    # over solo launches in a subprocess (pmc_passes).  No committed file of an earlier round stands in when it fails: the
+    # fields are then null and say why.
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_pmc and kernel_name == "k_verify_batches" and n * K == 16384:
         try:
-            traffic_detail = live_traffic()
-            if traffic_detail and kernel_name in traffic_detail:
-                traffic = traffic_detail[kernel_name]["bytes"]
-                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over solo launches of the pair "
-                               "(tools/pmc_solo.py headline), corrected with profiles/r3_pmc_calibration.json (fetch x %.3f, write x %.2f)"
-                               % (traffic_detail["calibration"]["fetch_factor"], traffic_detail["calibration"]["write_factor"]))
+            pmc = pmc_passes()
         except Exception as e:
-            traffic_detail = {"error": "%s: %s" % (type(e).__name__, e)}
-    if traffic is None:
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
-            for key, row in pmc["kernels"].items():
-                if key.split("@")[0] == kernel_name and row["signatures_per_launch"] == n * K:
-                    traffic = row["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r3_pmc_traffic.json (solo-launch rocprofv3 passes of an earlier run, calibrated with profiles/r3_pmc_calibration.json)"
-        except Exception:
-            pass
+            pmc = {"error": "%s: %s" % (type(e).__name__, e)}
+    traffic = traffic_src = None
+    head_pmc = pmc_pick(pmc, kernel_name)
+    prep_pmc = pmc_pick(pmc, "k_prepare_batches")
+    if head_pmc and "bytes" in head_pmc:
+        traffic = head_pmc["bytes"]
+        traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, solo launches, x %.3f / x %.2f (%s)" % (
+            pmc["calibration"]["fetch_factor"], pmc["calibration"]["write_factor"], CALIBRATION)
+    elif pmc and "error" in pmc:
+        traffic_src = "unmeasured: " + pmc["error"][:90]
     e2e = None
     if world == 1 and not args.no_extras:
         try:
@@ -1085,14 +1262,16 @@ def main():
         except Exception as e:
             e2e = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    out = None
+    out = detail = None
     if rank == 0:
         total = world * n * B * args.steps
         value = total / elapsed
-        algo = (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) * n * K       # one launch of the dominant kernel covers K batches
+        per_verify = ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI
+        algo = per_verify * n * K       # one launch of the dominant kernel covers K batches
         achieved = algo / (avg_verify_ms * 1e-3) / 1e9 if avg_verify_ms > 0 else 0.0
+        detail = {}                      # everything verbose goes to the side file; the line keeps scalars the driver's record holds
         out = {
-            "metric": "Ed25519 verifies/sec (whole node)",
+            "metric": METRIC,
             "value": round(value, 1), "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -1100,16 +1279,14 @@ def main():
             "dtype": "u32 limbs (radix 2^25.5), u64 accumulate",
             "data": "synthetic",
             "config": {
-                "workload": ("QC::verify shape: batches of %d signatures over one digest, batch semantics; " % n if shared else
-                             "BASELINE configs[1]: batches of %d distinct (digest, pk, sig) tuples, strict semantics, HBM-resident; " % n)
-                            + "one step = one pass over %d such batches per GPU (%d verifications), %d independent batches per "
-                              "launch (%s), launches round-robin over %d CU-partitioned stream contexts"
-                              % (B, B * n, K, "hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device", ns),
+                "workload": ("QC shape: %d-signature batches over one digest, batch semantics, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)
+                             if shared else
+                             "BASELINE configs[1]: %d-tuple (digest,pk,sig) batches, strict, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)),
                 "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
                 "distinct_tuples_per_gpu": ns * n, "streams": ns, "cu_partitions": args.partitions,
                 "timed_region_s": round(elapsed, 4), "batches_per_launch": K, "launches_in_timed_region_per_gpu": launches_per_step * args.steps,
-                "exchange": ("none on this workload: every rank verifies its own independent batches (SURVEY.md 8e); "
-                             "`sharded_committee` / `sharded_c_abi` are the workloads with the exchange step") if exchange else "none (1 GPU)",
+                "entry_point": "hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device",
+                "exchange": "none on this workload (independent batches per rank, SURVEY 8e); sharded_committee / sharded_c_abi have it" if exchange else "none (1 GPU)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name,
@@ -1117,54 +1294,92 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 8),
                 # `frac` is per launch of the dominant kernel (the contract's definition) while ~16 launches overlap on the
                 # chip; chip_frac = whole-GPU algorithmic bytes per second (value x 128 B) over the same peak
-                "chip_frac": round(value / world * (ALGO_BYTES_SHARED if shared else ALGO_BYTES_MULTI) / 1e9 / HBM_PEAK_GBS, 8),
+                "chip_frac": round(value / world * per_verify / 1e9 / HBM_PEAK_GBS, 8),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_detail": traffic_detail,
-                "algorithmic_bytes_per_launch": algo,
-                "avg_kernel_ms": round(avg_verify_ms, 4), "launches_timed": launches,
-                "event_sampling": "dispatch timestamps (hipExtLaunchKernel start/stop events, on the launch stream) of every "
-                                  "%d-th launch of each of the %d stream contexts, inside the timed region" % (args.event_stride, ns),
-                "note": "path is integer-VALU bound (SURVEY.md 8d); HBM fraction is tiny by construction",
+                "traffic_over_algorithmic": round(traffic / algo, 2) if traffic else None,
+                "traffic_k_prepare_batches": prep_pmc.get("bytes") if prep_pmc else None,
+                "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_verification": per_verify,
+                "avg_kernel_ms": round(avg_verify_ms, 4), "avg_k_prepare_ms": round(avg_prepare_ms, 4) if avg_prepare_ms > 0 else None,
+                "launches_timed": launches, "event_stride": args.event_stride,
+                "timing": "dispatch timestamps (hipExtLaunchKernel events on the launch stream) of sampled launches in the timed region",
+                "note": "integer-VALU bound (SURVEY 8d): HBM fraction tiny by construction; config.int_roofline_* are the bounds that bind",
             },
-            "int_roofline": None,
-            "kernels_ms": {"k_prepare": round(avg_prepare_ms, 4) if avg_prepare_ms > 0 else None,
-                           "k_verify": round(avg_verify_ms, 4)},
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
+        cfg = out["config"]
         kname = {"k_verify_fused_batches": "k_verify_fused3", "k_verify_fused_pairs_batches": "k_verify_fused_pairs"}.get(kernel_name, kernel_name)
         if kname in MAD_PER_VERIFY:
             mad_s = value / world * MAD_PER_VERIFY[kname]
-            out["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,
-                                   "unit": "v_mad_u64_u32 lane-ops/s (per GPU)", "frac": round(mad_s / MAD_PEAK_PER_S, 4),
-                                   "mad_per_verify": MAD_PER_VERIFY[kname]}
-            if kname in VALU_WAVE_INSTS_PER_VERIFY:
-                wi_s = value / world * VALU_WAVE_INSTS_PER_VERIFY[kname]
+            detail["int_roofline"] = {"bound": "valu-int-mul", "achieved": round(mad_s, 1), "peak": MAD_PEAK_PER_S,
+                                      "unit": "v_mad_u64_u32 lane-ops/s (per GPU)", "frac": round(mad_s / MAD_PEAK_PER_S, 4),
+                                      "mad_per_verify": MAD_PER_VERIFY[kname]}
+            cfg["int_roofline_mad_frac"] = round(mad_s / MAD_PEAK_PER_S, 4)
+            # total VALU wave-instructions per verification: measured in this run (SQ_INSTS_VALU of the solo pair) when the
+            # counter pass ran, else the committed round-4 figure for the same kernels
+            wi = wi_src = None
+            if head_pmc and prep_pmc and "SQ_INSTS_VALU" in head_pmc and "SQ_INSTS_VALU" in prep_pmc:
+                wi, wi_src = (head_pmc["SQ_INSTS_VALU"] + prep_pmc["SQ_INSTS_VALU"]) / (n * K), "SQ_INSTS_VALU of the solo launch pair, this run"
+            elif kname in VALU_WAVE_INSTS_PER_VERIFY:
+                wi, wi_src = VALU_WAVE_INSTS_PER_VERIFY[kname], "profiles/r4_p_pmc_sq_headline.json (this run's counter pass did not run)"
+            if wi:
+                wi_s = value / world * wi
                 cap = SIMDS * SCLK_HZ / CYCLES_PER_WAVE_INST_MIX
-                out["int_roofline"].update({
-                    "issue_frac": round(wi_s / cap, 4), "valu_wave_insts_per_verify": VALU_WAVE_INSTS_PER_VERIFY[kname],
+                cfg["int_roofline_issue_frac"] = round(wi_s / cap, 4)
+                cfg["valu_wave_insts_per_verify"] = round(wi, 1)
+                detail["int_roofline"].update({
+                    "issue_frac": round(wi_s / cap, 4), "valu_wave_insts_per_verify": round(wi, 1), "source": wi_src,
                     "valu_wave_insts_per_s": round(wi_s, 1), "simd_issue_capacity_per_s": round(cap, 1),
-                    "issue_note": "all VALU wave-instructions of the launch pair (SQ_INSTS_VALU, profiles/r4_p_pmc_sq_headline.json; %.1f %% are "
-                                  "v_mad_u64_u32) x value, over %d SIMDs x %.1f GHz / %.2f cycles per wave-instruction of that mix "
-                                  "(profiles/r1_ubench_valu.txt): the bound that binds this kernel" % (
+                    "issue_note": "all VALU wave-instructions of the launch pair (%.1f %% are v_mad_u64_u32) x value, over %d SIMDs x %.1f GHz / "
+                                  "%.2f cycles per wave-instruction of that mix (profiles/r1_ubench_valu.txt): the bound that binds this kernel" % (
                                       100 * MAD_SHARE_OF_VALU, SIMDS, SCLK_HZ / 1e9, CYCLES_PER_WAVE_INST_MIX)})
         if e2e is not None:
-            out["end_to_end"] = e2e
+            detail["end_to_end"] = e2e
+            for r_ in e2e.get("by_threads", []):
+                shape = (r_["host_threads"], r_["in_flight_per_thread"], r_["batches_per_launch"])
+                if shape == (16, 8, 8):
+                    cfg["end_to_end_verifies_per_s_16_threads_x_8_tickets"] = r_["value"]
+                if shape == (1, 1, 1):
+                    cfg["end_to_end_verifies_per_s_one_sync_caller_1024"] = r_["value"]
+                    cfg["end_to_end_call_p50_ms_one_sync_caller_1024"] = r_["call_p50_ms"]
+                if shape == (1, 256, 16):
+                    cfg["end_to_end_verifies_per_s_one_thread_256_tickets"] = r_["value"]
+            if "value" in e2e:
+                cfg["end_to_end_verifies_per_s_best"] = e2e["value"]
+            if "error" in e2e:
+                cfg["end_to_end_error"] = e2e["error"][:120]
         if world == 1 and not args.no_cached:
-            out["committee_cached"] = cached
+            if isinstance(cached, dict) and "value" in cached:
+                cached_rooflines(cached, pmc, n, stride)
+                cfg["committee_cached_verifies_per_s"] = cached["value"]
+                lc = cached.get("large_committee", {})
+                if "roofline" in lc:
+                    cfg["cached_qc_66667_kernel_ms"] = lc["avg_kernel_ms"]
+                    cfg["cached_qc_66667_hbm_frac"] = lc["roofline"]["frac"]
+                    cfg["cached_qc_66667_traffic_over_algorithmic"] = lc["roofline"].get("traffic_over_algorithmic")
+                    cfg["cached_qc_66667_table_gather_GBps"] = lc["roofline"].get("design_traffic_GBps")
+                if isinstance(lc.get("four_in_flight_two_launch_form_signatures_per_s"), float):
+                    cfg["cached_qc_66667_four_in_flight_signatures_per_s"] = lc["four_in_flight_two_launch_form_signatures_per_s"]
+            detail["committee_cached"] = cached
         if world == 1 and not args.no_qc:
             # streamed_rounds first: a ring (and its 5 GB key set) built while the process's first extra context of QC size is
-            # alive - the wide pool context qc_latency creates - runs ~25 % slower until that context goes (DESIGN.md 8.2,
-            # tools/streamed_probe.py, profiles/r3_streamed_probe.txt; the round-2 tree behaves identically): a coupling in the
-            # runtime, not the ring's steady state
+            # alive - the wide pool context qc_latency creates - runs ~25 % slower until that context goes (tools/streamed_probe.py,
+            # profiles/r3_streamed_probe.txt; the round-2 tree behaves identically): a coupling in the runtime, not the ring's steady state
             for key, fn in (("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
                             ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
                             ("multi_process", lambda: mp_early if mp_early is not None else multi_process(n))):
                 try:
-                    out[key] = fn()
+                    detail[key] = fn()
                 except Exception as e:        # extras never cost the headline line
-                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    detail[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            summarise_extras(cfg, detail, pmc)
+        if pmc is not None:
+            detail["pmc"] = pmc
+        try:
+            detail["library_config"] = _lib.config_dump()
+        except Exception as e:      # noqa: BLE001
+            detail["library_config"] = {"error": str(e)}
         if not args.no_cpu and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
@@ -1175,16 +1390,17 @@ def main():
     # a device hangs there, the finished headline is printed with the extra marked as timed out (line_watchdog).
     dog = line_watchdog(real_stdout)
     if rank == 0:
-        out["config"]["ranks"] = {"world": world, "gpus_visible": ndev, "control_plane": backend if exchange else "none",
-                                  "virtual_ranks": virtual,
-                                  "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}
+        out["config"].update({"ranks_world": world, "ranks_gpus_visible": ndev, "ranks_control_plane": backend if exchange else "none",
+                              "ranks_virtual": virtual,
+                              "ranks_launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"})
 
     def guarded(key, seconds, fn, every_rank):
         """run extra `key` (on every rank, or on rank 0 while the others wait at the next barrier) under rank 0's deadline"""
         if rank == 0:
             def late():
                 o = dict(out)
-                o[key] = {"error": "did not finish within %d s; the line was printed by the watchdog, the ranks were abandoned" % seconds}
+                o["config"] = dict(out["config"])
+                o["config"][key + "_error"] = "did not finish within %d s; the line was printed by the watchdog, the ranks were abandoned" % seconds
                 return json.dumps(o)
             dog.arm(late, seconds)
         res = None
@@ -1197,7 +1413,21 @@ def main():
             print("bench: rank %d: extra %s failed: %s" % (rank, key, res["error"]), file=sys.stderr, flush=True)
         if rank == 0:
             dog.disarm()
-            out[key] = res
+            detail[key] = res
+            out[key] = res                # the N > 1 line has no other extras (they are gated on one rank): these two stay in it, whole
+            cfgm = out["config"]
+            if isinstance(res, dict) and "error" in res:
+                cfgm[key + "_error"] = str(res["error"])[:120]
+            elif isinstance(res, dict):
+                for form in ("cold", "key_cache"):          # sharded_committee: the QC of the large committee cut over the ranks
+                    if isinstance(res.get(form), dict) and "p50_ms" in res[form]:
+                        cfgm["%s_p50_ms_%s" % (key, form)] = res[form]["p50_ms"]
+                        cfgm["%s_verifies_per_s_%s" % (key, form)] = res[form]["verifies_per_s"]
+                if "signatures" in res:
+                    cfgm[key + "_signatures"] = res["signatures"]
+                for k2, v2 in res.items():                   # sharded_c_abi: flat scalar rows of the one-process form
+                    if isinstance(v2, (int, float)) and k2 not in ("signatures",) and len(cfgm) < 120:
+                        cfgm["%s_%s" % (key, k2)] = v2
 
     # the workload that has an exchange step: one very large committee sharded over the GPUs, one process per GPU,
     # all-gather of the per-shard accept bitmaps (RCCL over xGMI; gloo when ranks share a device)
@@ -1210,6 +1440,16 @@ def main():
         if exchange:
             dist.barrier()
         guarded("sharded_c_abi", 170, lambda: sharded_c_abi(world, ndev, validators=args.large_committee), False)
+    if rank == 0:
+        # the verbose extras go to a side file (gpurun_out/ travels back from a gpurun box); the line says where
+        try:
+            os.makedirs(os.path.dirname(args.detail_file), exist_ok=True)
+            with open(args.detail_file, "w") as f:
+                json.dump({"line": out, "detail": detail}, f, indent=1)
+            out["detail_file"] = os.path.relpath(args.detail_file, ROOT)
+            out["detail_keys"] = sorted(detail)
+        except Exception as e:      # noqa: BLE001
+            out["detail_file"] = "not written: %s" % e
     line = json.dumps(out) if rank == 0 else None
     if exchange:
         if rank == 0:

@@ -20,7 +20,8 @@ def test_bench_gpus_2_runs_by_itself_and_its_exchange_extras_work():
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batches-per-step", "64", "--large-committee", "3000"],
+                        "--batches-per-step", "64", "--large-committee", "3000",
+                        "--detail-file", os.path.join(ROOT, "gpurun_out", "test_bench_gpus2_detail.json")],
                        capture_output=True, text=True, timeout=600, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     try:        # keep the ranks' stderr where a gpurun visit can pick it up
@@ -32,7 +33,9 @@ def test_bench_gpus_2_runs_by_itself_and_its_exchange_extras_work():
     tb = "\n".join(l for l in r.stderr.splitlines() if l.startswith(("[rank", "bench:")) or "Error" in l)
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, tb[-4000:])
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["ranks"]["world"] == 2
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["ranks_world"] == 2
+    assert j["metric"].startswith("Ed25519 verifies/sec (whole node) + QC-verify p50 latency")      # BASELINE.json's metric, whole
+    assert j["config"]["sharded_committee_p50_ms_cold"] > 0 and j["config"]["sharded_committee_p50_ms_key_cache"] > 0     # flat, where the driver's record keeps them
     sc = j["sharded_committee"]
     assert "error" not in sc and sc["ranks"] == 2 and sc["cold"]["p50_ms"] > 0 and sc["key_cache"]["p50_ms"] > 0, sc
     ca = j["sharded_c_abi"]

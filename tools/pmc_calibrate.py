@@ -1,7 +1,7 @@
 """Combine tools/ubench_gather's known volumes with rocprofv3's FETCH_SIZE / WRITE_SIZE for the same run into the
 calibration factors bench.py and the profiles use.
 
-    python tools/pmc_calibrate.py <ubench stdout json> <FETCH_SIZE results.db> <WRITE_SIZE results.db> > profiles/r3_pmc_calibration.json
+    python tools/pmc_calibrate.py <ubench stdout json> <FETCH_SIZE results.db> <WRITE_SIZE results.db> > profiles/pmc_calibration.json
 
 factor = true bytes / counter bytes (multiply a counter reading by it).  rocprofv3 reports the counters in KB."""
 import json

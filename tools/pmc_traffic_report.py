@@ -35,14 +35,14 @@ lines160 = cal["kernels"]["k_cal_gather_entry160"].get("fetch_factor_vs_touched_
 factor = dict(F, fetch_entry160_gather_lines=lines160)
 out = {"note": "SOLO launches (one dispatch at a time, the stream drained in between: tools/pmc_solo.py), rocprofv3 --pmc FETCH_SIZE and "
                "--pmc WRITE_SIZE in separate passes, no trace domains; counters summed over their instances, averaged over the dispatches of "
-               "a kernel at one grid size.  CORRECTED with this project's own calibration (profiles/r3_pmc_calibration.json, "
+               "a kernel at one grid size.  CORRECTED with this project's own calibration (profiles/pmc_calibration.json, "
                "tools/ubench_gather.hip): FETCH_SIZE reports HALF of the 128-byte lines fetched in EVERY read pattern measured (wide 16-byte "
                "streams 2.00, dword rows 2.00, one-line 16-byte gathers 1.91, dword gathers 2.00 against touched lines), so reads are "
                "multiplied by the factor of the kernel's dominant pattern; WRITE_SIZE is exact for full-line writes (1.00) and is taken as "
                "reported - for 16-byte pieces of a line it over-reports once the footprint exceeds the caches (factor 0.43 on a 4 GiB "
                "footprint), which none of these kernels' write sets does.  Infinity-Cache hits are counted by these counters "
                "(MI355X_MICROARCH.md), so 'HBM-side' means 'left the L2'.",
-       "calibration": "profiles/r3_pmc_calibration.json", "factors": factor, "kernels": {}}
+       "calibration": "profiles/pmc_calibration.json", "factors": factor, "kernels": {}}
 for k, (what, sigs, pat, algo) in KERNELS.items():
     if k not in fetch:
         continue
