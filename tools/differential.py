@@ -1,0 +1,224 @@
+"""Structured differential at scale (VERDICT r4 "Next round" #3): >= 10^7 crafted tuples through EVERY cold and key-cache kernel
+form of the engine, in STRICT and in BATCH, against the C oracle - mutations drawn from the edge classes (A / R + each 8-torsion
+point, pure-torsion keys, the alternative encodings dalek's lenient decompression admits, s in {L - 1, L, L + 1, 2^252, high
+bits, s + L}, ...), not byte flips.  tests/craft builds the tuples (a signer that hashes the crafted encodings, so the verdict
+depends on k mod 8 and on torsion surviving every scalar transformation); the labels are the oracle's.
+
+    python tools/differential.py [--total 10000000] [--chunk 1048576] [--out gpurun_out/r5_differential.json]
+
+A GPU job (the engine has no CPU path); `tests/test_gpu_differential.py` runs a 10^6 slice of the same code as a -m gpu test.
+The reference path this guards: /root/reference/crypto/src/lib.rs:200-219 (verify_strict / verify_batch of ed25519-dalek 1.0.1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import craft  # noqa: E402  (tests/craft)
+
+
+def forms(_lib):
+    """(name, kind, selector, signatures per call, batches per call, concurrent) - every production kernel form and how a call
+    reaches it.  kind: cold / cached single calls, cold_list / cached_list batch lists."""
+    K = _lib
+    return [
+        ("k_verify_fused8", "cold", K.KERNEL_OCT, 8192, 1, False),
+        ("k_verify_fused8h", "cold", K.KERNEL_OCT_SPLIT, 8192, 1, False),
+        ("k_verify_fused8h (1,000-signature calls)", "cold", K.KERNEL_OCT_SPLIT, 1000, 1, False),
+        ("k_verify_fused", "cold", K.KERNEL_FUSED, 16384, 1, False),
+        ("k_verify_fused3", "cold", K.KERNEL_FUSED, 32768, 1, False),
+        ("k_prepare + k_verify", "cold", K.KERNEL_LANE, 131072, 1, False),
+        ("k_prepare + k_verify_tail", "cold", K.KERNEL_AUTO, 81920, 1, False),
+        ("k_verify_fused_batches", "cold_list", K.KERNEL_AUTO, 4096, 2, False),
+        ("k_verify_fused_pairs_batches", "cold_list", K.KERNEL_AUTO, 4096, 4, False),
+        ("k_prepare_batches + k_verify_batches", "cold_list", K.KERNEL_AUTO, 4096, 16, False),
+        ("k_verify_cached_lane2r", "cached", K.KERNEL_AUTO, 65536, 1, False),
+        ("k_verify_cached_lane", "cached", K.KERNEL_LANE, 131072, 1, False),
+        ("k_cached_chain2 + k_cached_finish (4 per lane)", "cached", K.KERNEL_CACHED_C, 131072, 1, False),
+        ("k_cached_chain2 + k_cached_finish (8 per lane)", "cached", K.KERNEL_CACHED_C, 131072, 1, True),
+        ("k_verify_cached_lane2r_batches", "cached_list", K.KERNEL_AUTO, 4096, 4, False),
+        ("k_verify_cached_lane_batches", "cached_list", K.KERNEL_LANE, 4096, 4, False),
+        ("k_cached_chain2_batches + k_cached_finish_batches", "cached_list", K.KERNEL_CACHED_C, 4096, 4, False),
+    ]
+
+
+def run(total, chunk, seed=1, pool_seeds=1024, threads=None, shared_every=4, log=None, only=None):
+    """returns the report dict; raises nothing on mismatches (the caller asserts on report["mismatches"])"""
+    import torch
+    from hotstuff_amd import _lib
+    threads = threads or max(1, min(64, len(os.sched_getaffinity(0))))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(float(quota) / float(period) + 0.5)))
+    except Exception:      # noqa: BLE001
+        pass
+    l = craft.lib()
+    _lib.ensure_init()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(seed)
+    pool = craft.key_pool(pool_seeds)
+    fl = [f for f in forms(_lib) if only is None or any(o in f[0] for o in only)]
+    ctx = _lib.DeviceContext(131072)
+    st = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    rep = {"total": 0, "chunk": chunk, "seed": seed, "key_pool_seeds": pool_seeds, "host_threads": threads,
+           "modes": ["BATCH", "STRICT"], "forms": {f[0]: {"verifications": 0, "mismatches": 0} for f in fl},
+           "classes": {c: {"tuples": 0, "accept_batch": 0, "accept_strict": 0} for c in craft.CLASSES},
+           "label_check": {"sampled": 0, "mismatches": 0}, "mismatches": 0, "first_mismatches": [], "shared_digest_chunks": 0,
+           "seconds": {"craft_and_label": 0.0, "gpu": 0.0}}
+    done = 0
+    chunk_no = 0
+    while done < total:
+        n = min(chunk, total - done)
+        n = (n + 65535) // 65536 * 65536          # whole lists of sixteen 4,096-signature batches: a shorter last list would take another form
+        shared = shared_every and chunk_no % shared_every == shared_every - 1
+        t0 = time.perf_counter()
+        if shared:
+            # one digest for the whole chunk (the QC shape: stride 0 in every call)
+            one = rng.integers(0, 256, size=32, dtype=np.uint8)
+            crng = np.random.default_rng(seed * 1000 + chunk_no)
+            c = craft_chunk_shared(l, n, crng, pool, threads, one)
+            rep["shared_digest_chunks"] += 1
+        else:
+            c = craft.craft_chunk(l, n, rng, pool, threads)
+        bad_labels = craft.check_labels_against_the_oracle(l, c, rng, max(1000, n // 100), threads)
+        rep["label_check"]["sampled"] += max(1000, n // 100)
+        rep["label_check"]["mismatches"] += bad_labels
+        rep["seconds"]["craft_and_label"] += time.perf_counter() - t0
+        for ci, name in enumerate(craft.CLASSES):
+            m = c["cls"] == ci
+            rep["classes"][name]["tuples"] += int(m.sum())
+            rep["classes"][name]["accept_batch"] += int((c["expect"][m] & 1).sum())
+            rep["classes"][name]["accept_strict"] += int(((c["expect"][m] >> 1) & 1).sum())
+        t0 = time.perf_counter()
+        # the chunk's distinct keys become the committee of the key-cache forms
+        uniq, inv = np.unique(np.ascontiguousarray(c["pk"]).view(np.dtype((np.void, 32))).ravel(), return_inverse=True)
+        ks = _lib.KeySet([r.tobytes() for r in uniq])
+        d_ki = torch.from_numpy(inv.astype(np.int32)).to(dev)
+        d_dg = torch.from_numpy(c["msgs"][:1].copy() if shared else c["msgs"]).to(dev)
+        d_pk = torch.from_numpy(c["pk"]).to(dev)
+        d_sg = torch.from_numpy(c["sig"]).to(dev)
+        bm = torch.zeros(n // 8 + 8 * (n // 960 + 2), dtype=torch.uint8, device=dev)      # every call writes whole 64-bit ballots of its own
+        torch.cuda.synchronize(dev)
+        stride = 0 if shared else 32
+        for mode_name, mode, vbit in (("BATCH", _lib.BATCH, 0), ("STRICT", _lib.STRICT, 1)):
+            want = ((c["expect"] >> vbit) & 1).astype(np.uint8)
+            for name, kind, sel, per_call, per_list, conc in fl:
+                bm.zero_()
+                torch.cuda.synchronize(dev)
+                ctx.set_kernel(sel)
+                ctx.set_concurrent(conc)
+                pos = 0
+                bit = 0                          # where this call's ballots start in the bitmap buffer (a multiple of 64)
+                keep, spans = [], []
+                while pos < n:
+                    if kind in ("cold", "cached"):
+                        m_ = min(per_call, n - pos)
+                        dg = d_dg.data_ptr() + (0 if shared else 32 * pos)
+                        if kind == "cold":
+                            ctx.verify(dg, stride, d_pk.data_ptr() + 32 * pos, d_sg.data_ptr() + 64 * pos, m_, mode, bm.data_ptr() + bit // 8, 0, 0)
+                        else:
+                            ctx.verify_cached(ks, dg, stride, d_ki.data_ptr() + 4 * pos, d_sg.data_ptr() + 64 * pos, m_, mode, bm.data_ptr() + bit // 8, 0, 0)
+                        spans.append((bit, m_))
+                        pos += m_
+                        bit += (m_ + 63) // 64 * 64
+                    else:
+                        entries = []
+                        for _ in range(per_list):
+                            if pos >= n:
+                                break
+                            m_ = min(per_call, n - pos)
+                            keys = (d_ki.data_ptr() + 4 * pos) if kind == "cached_list" else (d_pk.data_ptr() + 32 * pos)
+                            entries.append((d_dg.data_ptr() + (0 if shared else 32 * pos), stride, keys, d_sg.data_ptr() + 64 * pos, m_, mode,
+                                            bm.data_ptr() + bit // 8, 0))
+                            spans.append((bit, m_))
+                            pos += m_
+                            bit += (m_ + 63) // 64 * 64
+                        lst = _lib.batch_array(entries)
+                        keep.append(lst)
+                        if kind == "cold_list":
+                            ctx.verify_batches(lst)
+                        else:
+                            ctx.verify_batches_cached(ks, lst)
+                st.synchronize()
+                bits = np.unpackbits(bm.cpu().numpy(), bitorder="little")
+                got = bits[:n] if bit == n else np.concatenate([bits[b:b + m_] for b, m_ in spans])
+                diff = np.nonzero(got != want)[0]
+                fr = rep["forms"][name]
+                fr["verifications"] += n
+                if len(diff):
+                    fr["mismatches"] += int(len(diff))
+                    rep["mismatches"] += int(len(diff))
+                    for i in diff[:3]:
+                        if len(rep["first_mismatches"]) < 24:
+                            rep["first_mismatches"].append({"form": name, "mode": mode_name, "chunk": chunk_no, "index": int(i),
+                                                            "class": craft.CLASSES[c["cls"][i]], "spec": int(c["spec"][i]), "gpu": int(got[i]), "oracle": int(want[i]),
+                                                            "msg": bytes(c["msgs"][0 if shared else i]).hex(), "pk": bytes(c["pk"][i]).hex(), "sig": bytes(c["sig"][i]).hex()})
+        ctx.set_kernel(_lib.KERNEL_AUTO)
+        ctx.set_concurrent(False)
+        ks.close()
+        rep["seconds"]["gpu"] += time.perf_counter() - t0
+        done += n
+        chunk_no += 1
+        rep["total"] = done
+        if log:
+            log("chunk %d: %d tuples done, %d mismatches, %d label mismatches" % (chunk_no, done, rep["mismatches"], rep["label_check"]["mismatches"]))
+    ctx.close()
+    rep["verifications_total"] = sum(f["verifications"] for f in rep["forms"].values())      # every form saw every tuple in both modes
+    rep["seconds"] = {k: round(v, 1) for k, v in rep["seconds"].items()}
+    return rep
+
+
+def craft_chunk_shared(l, n, rng, pool, threads, digest):
+    """craft.craft_chunk with ONE message for every tuple (byte-flips then only touch pk / sig)"""
+    spec, cls, key = craft.schedule(n, rng, len(pool))
+    seeds = np.ascontiguousarray(pool[key])
+    msgs = np.ascontiguousarray(np.broadcast_to(digest, (n, 32)))
+    pk = np.zeros((n, 32), dtype=np.uint8)
+    sig = np.zeros((n, 64), dtype=np.uint8)
+    l.hs_craft_many(seeds.ctypes.data, msgs.ctypes.data, spec.ctypes.data, n, pk.ctypes.data, sig.ctypes.data, threads)
+    m = np.nonzero(cls == craft.CLASSES.index("byte-flip"))[0]
+    where = rng.integers(0, 96 * 8, size=len(m))
+    for i, w in zip(m, where):
+        byte, bit = int(w) // 8, int(w) % 8
+        arr, off = (pk, byte) if byte < 32 else (sig, byte - 32)
+        arr[i, off] ^= 1 << bit
+    expect = np.zeros(n, dtype=np.uint8)
+    l.hs_craft_verify_both_many(msgs.ctypes.data, pk.ctypes.data, sig.ctypes.data, n, expect.ctypes.data, threads)
+    return {"msgs": msgs, "pk": pk, "sig": sig, "spec": spec, "cls": cls, "key": key, "expect": expect}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--total", type=int, default=10_000_000)
+    ap.add_argument("--chunk", type=int, default=1 << 20)
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r5_differential.json"))
+    args = ap.parse_args()
+    t0 = time.time()
+    rep = run(args.total, args.chunk, seed=args.seed, log=lambda s: print(s, file=sys.stderr, flush=True))
+    rep["wall_s"] = round(time.time() - t0, 1)
+    try:
+        from hotstuff_amd import _lib
+        rep["library_config"] = _lib.config_dump()
+    except Exception:      # noqa: BLE001
+        pass
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(rep, open(args.out, "w"), indent=1)
+    print(json.dumps({k: rep[k] for k in ("total", "mismatches", "label_check", "wall_s", "seconds")}))
+    print("forms:", file=sys.stderr)
+    for k, v in rep["forms"].items():
+        print("  %-55s %12d verifications  %d mismatches" % (k, v["verifications"], v["mismatches"]), file=sys.stderr)
+    sys.exit(1 if rep["mismatches"] or rep["label_check"]["mismatches"] else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,8 @@
 """What distinguishes one GPU box from another, recorded beside every latency number (VERDICT r3 "Next round" #1):
-clocks, power cap, performance level, partition modes, hardware-queue budget, and the MEASURED clock of a lone wavefront
-(tools/clock_probe: the thing a QC's latency is proportional to).  `python tools/gpu_env.py` prints one JSON object;
-bench.py embeds `snapshot()` as `qc_verify_latency.env`.  Everything is best-effort: a missing tool or field is recorded
+clocks, power cap, performance level, partition modes, hardware-queue budget, identity.  `python tools/gpu_env.py` prints one
+JSON object; bench.py stores `snapshot()` in its detail file as `qc_verify_latency.env`.  (Round 4's probe programs - lone-wavefront
+clock, dependent gathers, instruction feed - left the tree in round 5: the library now times the kernel forms themselves at
+init, hs_ed25519_autotune, and bench.py reports both forms on the box it runs on.)  Everything is best-effort: a missing tool or field is recorded
 as null, never an error."""
 import json
 import os
@@ -136,68 +137,7 @@ def identity():
     return out
 
 
-def clock_probe(idle_ms=100):
-    """tools/clock_probe: effective MHz of a lone wavefront cold / spaced / back-to-back / under load (None when not built)."""
-    exe = os.path.join(ROOT, "tools", "clock_probe")
-    if not os.path.exists(exe):
-        return None
-    txt = _run([exe, str(idle_ms)], timeout=60)
-    if not txt:
-        return None
-    res = {}
-    for line in txt.splitlines():
-        m = re.match(r"(\S+)\s+n=\d+\s+chain p50\s+([\d.]+) us.*effective\s+([\d.]+) MHz.*?([\d.]+) cycles/instruction", line)
-        if m:
-            res[m.group(1)] = {"chain_us": float(m.group(2)), "mhz": float(m.group(3)), "cycles_per_instruction": float(m.group(4))}
-        elif line.startswith("device 0"):
-            res["device"] = line.strip()
-        m = re.match(r"issue\s+(\S+)\s+independent x8, (\d+) wavefront.*?:\s+([\d.]+) cycles per instruction", line)
-        if m:
-            res.setdefault("issue_cycles_per_instruction", {})["%s_%s_wavefronts" % (m.group(1), m.group(2))] = float(m.group(3))
-    return res or None
-
-
-def mem_latency_probe(quick=True):
-    """tools/mem_latency_probe: ns per DEPENDENT 16-byte gather of one wavefront over 32 MB ... 6 GB (what the table lookups on a
-    QC's chain wait for; None when not built)."""
-    exe = os.path.join(ROOT, "tools", "mem_latency_probe")
-    if not os.path.exists(exe):
-        return None
-    txt = _run([exe] + (["quick"] if quick else []), timeout=120)
-    if not txt:
-        return None
-    res, cur = {}, None
-    for line in txt.splitlines():
-        m = re.match(r"\s*(\d+) MB.*?:\s+([\d.]+) ns per hop.*?([\d.]+) shader cycles per hop", line)
-        if m:
-            cur = res["%s_MB" % m.group(1)] = {"ns_per_hop": float(m.group(2)), "cycles_per_hop": float(m.group(3))}
-        m = re.match(r"\s*independent gathers,\s*(\d+) wavefronts:\s+([\d.]+) lines per us", line)
-        if m and cur is not None:
-            cur["lines_per_us_%s_wavefronts" % m.group(1)] = float(m.group(2))
-    return res or None
-
-
-def ifetch_probe():
-    """tools/ifetch_probe quick: ns per straight-line 8-byte instruction delivered to one wavefront - THE marker of the two classes
-    of box round 4 found (1.97 ns on some GPUs, 4.06 on others).  None when not built."""
-    exe = os.path.join(ROOT, "tools", "ifetch_probe")
-    if not os.path.exists(exe):
-        return None
-    txt = _run([exe, "quick"], timeout=60)
-    if not txt:
-        return None
-    res = {}
-    for line in txt.splitlines():
-        m = re.match(r"(\d+) KB\s+(\d+) workgroups:\s+([\d.]+) ns per instruction", line)
-        if m:
-            res["%sKB_%swg_ns_per_instruction" % (m.group(1), m.group(2))] = float(m.group(3))
-    if res:
-        v = res.get("24KB_1wg_ns_per_instruction")
-        res["class"] = None if v is None else ("fast-feed" if v < 3.0 else "slow-feed")
-    return res or None
-
-
-def snapshot(with_probe=True):
+def snapshot():
     s = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "HS_ED25519_TENANTS": os.environ.get("HS_ED25519_TENANTS"),
          "HSA_ENABLE_SDMA": os.environ.get("HSA_ENABLE_SDMA"), "host_cores": os.cpu_count()}
     s["rocm_smi"] = rocm_smi()
@@ -211,16 +151,10 @@ def snapshot(with_probe=True):
                            "hbm_gb": round(p.total_memory / 2**30, 1), "gcn_arch": getattr(p, "gcnArchName", None)}
     except Exception:      # noqa: BLE001
         pass
-    if with_probe:
-        s["lone_wavefront_clock"] = clock_probe()
-        s["dependent_gather"] = mem_latency_probe()
-        s["instruction_feed"] = ifetch_probe()
     return s
 
 
 if __name__ == "__main__":
-    snap = snapshot("--no-probe" not in sys.argv)
-    if "--full" in sys.argv:
-        snap["dependent_gather"] = mem_latency_probe(quick=False)
+    snap = snapshot()
     json.dump(snap, sys.stdout, indent=1)
     print()

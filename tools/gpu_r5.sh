@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round-5 gpurun visits.  gpurun --timeout 1500 -- 'bash tools/gpu_r5.sh <tag> <stage> [stage ...]'   (files land in gpurun_out/r5_<tag>_*)
+#   tests   the GPU suite + smoke()
+#   bench   the driver's command; the line, its detail file and a one-screen summary
+#   diff    the scale differential: 10^7 crafted tuples through every kernel form + 10^7 / 10^5 scalars through half_scalar
+#   prof    rocprofv3 --kernel-trace --stats of the headline workload (the kernel's average duration the roofline must agree with)
+tag=${1:-a}; shift
+mkdir -p gpurun_out
+export HS_SYNTH_CACHE=/tmp/hs_synth
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5_${tag}
+for stage in "$@"; do
+case $stage in
+tests)
+    timeout 1500 python -m pytest tests -x -q -m gpu > ${O}_pytest.txt 2>&1; echo "pytest rc=$?"
+    grep -E "passed|failed|error" ${O}_pytest.txt | tail -3
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+    ;;
+bench)
+    timeout 900 python bench.py --steps 20 --warmup 5 --detail-file ${O}_bench_detail.json > ${O}_bench.json.txt 2> ${O}_bench.err; echo "bench rc=$? line bytes $(wc -c < ${O}_bench.json.txt)"
+    python - ${O}_bench.json.txt <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    try: j = json.loads(l)
+    except Exception: continue
+    c, r = j["config"], j["roofline"]
+    g = lambda k: c.get(k)
+    print("headline %.2f M verifies/s  %s %.4f ms  traffic %s (x%s algorithmic)  mad %s issue %s" % (j["value"] / 1e6, r["kernel"], r["avg_kernel_ms"], r["traffic"], r.get("traffic_over_algorithmic"), g("int_roofline_mad_frac"), g("int_roofline_issue_frac")))
+    print("QC N=%s: cold p50 %s ms (kernel %s, %s by %s; fused8 %s / fused8h %s ms here, autotune %s / %s), key cache p50 %s ms (kernel %s); host API %s / %s ms" % (
+        g("qc_validators"), g("qc_verify_p50_ms_cold"), g("qc_kernel_ms_cold"), g("qc_cold_form_chosen"), g("qc_cold_form_chosen_by"), g("qc_kernel_ms_verify_fused8"), g("qc_kernel_ms_verify_fused8h"),
+        g("autotune_ms_verify_fused8"), g("autotune_ms_verify_fused8h"), g("qc_verify_p50_ms_key_cache"), g("qc_kernel_ms_key_cache"), g("qc_verify_p50_ms_cold_host_api"), g("qc_verify_p50_ms_key_cache_host_api")))
+    print("e2e 16x8 %s  one sync caller 1,024: %s (%s ms)  QC cold %s  QC cached %s | 4 tenants %s (spread %s) | streamed %s / %s | cached list %s, 66,667: %s ms frac %s" % (
+        g("end_to_end_verifies_per_s_16_threads_x_8_tickets"), g("end_to_end_verifies_per_s_one_sync_caller_1024"), g("end_to_end_call_p50_ms_one_sync_caller_1024"),
+        g("one_sync_caller_verifies_per_s_qc_cold"), g("one_sync_caller_verifies_per_s_qc_key_cache"), g("four_tenants_verifies_per_s"), g("four_tenants_max_over_min"),
+        g("streamed_rounds_cold_signatures_per_s"), g("streamed_rounds_key_cache_signatures_per_s"), g("committee_cached_verifies_per_s"), g("cached_qc_66667_kernel_ms"), g("cached_qc_66667_hbm_frac")))
+    print("cpu", j.get("cpu_baseline", {}).get("value"), "detail", j.get("detail_file"), "config keys", len(c))
+PY
+    tail -3 ${O}_bench.err | cut -c1-300
+    ;;
+diff)
+    timeout 1200 python tools/differential.py --total ${HS_DIFF_TOTAL:-10000000} --out ${O}_differential.json 2> ${O}_differential.err; echo "differential rc=$?"
+    tail -22 ${O}_differential.err | cut -c1-200
+    timeout 600 tools/half_differential ${HS_HALF_TOTAL:-10000000} 100000 > ${O}_half_differential.json 2> ${O}_half_differential.err; echo "half_differential rc=$?"
+    python -c "
+import json
+d = json.load(open('${O}_half_differential.json'))
+for k in ('random', 'adversarial'):
+    print(k, {x: v for x, v in d[k].items() if 'hist' not in x})
+"
+    ;;
+prof)
+    timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r5_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
+    python tools/rocpd_summary.py $(find /tmp/r5_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    ;;
+esac
+done
