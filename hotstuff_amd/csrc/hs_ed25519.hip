@@ -1097,7 +1097,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     g_devs.swap(devs);
     g_max_batch.store(max_batch ? max_batch : 1024);
     g_init.store(true);
-    const bool tune = g_autotune.load() && g_oct_split.load() < 0;
+    const bool tune = g_autotune.load() && g_oct_split.load() < 0 && kTenants == 1;      // a co-tenant does not tune (hs_tune.hip)
     const int queues = g_hw_queues_env;
     lk.unlock();
     // measured kernel choice (hs_tune.hip), outside the lock: it runs ordinary calls on a context of its own.  A failure

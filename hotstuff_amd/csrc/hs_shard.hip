@@ -176,8 +176,10 @@ struct shard_item {
 };
 
 // run all items concurrently; out_bm[s] (optional per slot) receives ceil(n_s/8) bytes.  Verdict = AND.
+std::atomic<unsigned long long> s_rccl_fallbacks{0};      // exchanges that went through pinned host memory because RCCL could not be set up
 int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32_t mode, std::vector<std::vector<uint8_t>> *out_bm,
-              bool want_rccl, size_t slice_bytes, std::vector<uint8_t> *gathered) {
+              bool want_rccl, size_t slice_bytes, std::vector<uint8_t> *gathered, bool *used_rccl) {
+    if (used_rccl) *used_rccl = false;
     const int k = (int)items.size();
     std::vector<host_job> jobs(k);
     int rc = 0;
@@ -216,7 +218,15 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
                 }
                 if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the slice", e);
             }
-            if (!rc) {
+            if (rc) {
+                // The collective could not be SET UP (no librccl, a device list ncclCommInitAll refuses, no memory for the gather
+                // buffers): every slot's bitmap slice still comes home through its context's pinned bitmap, so the call answers
+                // through the host exchange instead of failing.  Errors once the grouped call has started are returned.
+                (void)hipGetLastError();
+                s_rccl_fallbacks++;
+                want_rccl = false;
+                rc = 0;
+            } else {
                 ncclResult_t r = s_rccl.GroupStart();
                 for (int s = 0; s < k && r == ncclSuccess; s++)
                     r = s_rccl.AllGather(send[s], gs->buf[s], slice_bytes, ncclUint8, s_comms[s], st[s]);   // in place
@@ -224,7 +234,8 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
                 if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail("ncclAllGather", r != ncclSuccess ? r : r2);
             }
         }
-        if (!rc) {
+        if (!rc && want_rccl) {
+            if (used_rccl) *used_rccl = true;
             gathered->assign((size_t)k * slice_bytes, 0);
             if (hipSetDevice(dev_ordinal(0)) != hipSuccess ||
                 hipMemcpyAsync(gathered->data(), gs->buf[0], gathered->size(), hipMemcpyDeviceToHost, st[0]) != hipSuccess)
@@ -272,9 +283,10 @@ int verify_sharded_contiguous(const hs_ed25519_keyset *const *ks_per_slot, const
     const bool rccl = s_exchange.load() == HS_ED25519_EXCHANGE_RCCL;
     std::vector<std::vector<uint8_t>> bms(k);
     std::vector<uint8_t> gathered;
-    const int verdict = run_items(items, digest_stride, mode, bitmap && !rccl ? &bms : nullptr, rccl, slice, &gathered);
+    bool via_rccl = false;
+    const int verdict = run_items(items, digest_stride, mode, bitmap ? &bms : nullptr, rccl, slice, &gathered, &via_rccl);
     if (verdict < 0) return verdict;
-    if (rccl) {
+    if (via_rccl) {
         // slices are whole 64-bit words at offset s*slice bytes = s*S signatures: the concatenation IS the bitmap
         if (bitmap) memcpy(bitmap, gathered.data(), (n + 7) / 8);
         return bitmap_all_ones(gathered.data(), n) ? 1 : 0;
@@ -306,7 +318,6 @@ size_t msm_min() {
     if (const char *e = getenv("HS_ED25519_SHARD_MSM_MIN")) { const long long x = atoll(e); if (x > 0) return (size_t)x; }
     return hs_ed25519_rlc_min_batch() * (size_t)(dev_slots() > 0 ? dev_slots() : 1);
 }
-std::atomic<unsigned long long> s_msm_rccl_fallbacks{0};      // combinations that went through the host exchange because RCCL could not be set up
 // 1 = the combination over all shards accepted, 0 = it did not (localise), < 0 = engine error
 int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n) {
     const int k = dev_slots();
@@ -375,7 +386,7 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
             // buffers): every device still holds its 384-byte record, and the host exchange below needs nothing else - so the call
             // verifies through it instead of failing.  An error once the grouped call has started is returned as before.
             (void)hipGetLastError();
-            s_msm_rccl_fallbacks++;
+            s_rccl_fallbacks++;
             via_rccl = false;
             rc = 0;
         }
@@ -441,7 +452,7 @@ extern "C" int hs_ed25519_set_shard_msm_min(size_t n) { s_msm_override.store(n);
 extern "C" int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts) {
     if (calls) *calls = s_msm_calls.load();
     if (accepts) *accepts = s_msm_accepts.load();
-    const unsigned long long f = s_msm_rccl_fallbacks.load();
+    const unsigned long long f = s_rccl_fallbacks.load();
     return f > 0x7fffffffull ? 0x7fffffff : (int)f;
 }
 
@@ -547,7 +558,7 @@ static int verify_sharded_cached(const hs_ed25519_keyset_sharded *kss, const uin
     std::vector<std::vector<uint8_t>> bms(k);
     std::vector<uint8_t> unused;
     // routed shards are ragged (their sizes follow the votes), so the slices go through the host exchange
-    const int verdict = run_items(items, digest_stride, mode, bitmap ? &bms : nullptr, false, 0, &unused);
+    const int verdict = run_items(items, digest_stride, mode, bitmap ? &bms : nullptr, false, 0, &unused, nullptr);
     if (verdict < 0) return verdict;
     if (bitmap) {
         memset(bitmap, 0, (n + 7) / 8);

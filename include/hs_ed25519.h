@@ -243,8 +243,10 @@ const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t coun
  * 3 - 10 % in either direction; the driver's box contradicted the instruction-feed proxy that round used).  So the library
  * measures the thing itself: hs_ed25519_init - and this call, on demand (after a power-cap or clock change, say) - times
  * k_verify_fused8 and k_verify_fused8h on a canned, valid 6,667-signature batch (the QC of N = 10,000; signed on the
- * device; three alternating runs each, minima of the dispatch timestamps; ~3 ms in all) on device slot `slot` and keeps the
- * faster for that slot.  ms[0] = one-wavefront form, ms[1] = split form (ms may be NULL).  Returns the pick (0 / 1) or
+ * device; alternating runs until the minima of the dispatch timestamps have settled - a GPU idle a moment ago starts at
+ * idle clocks -, 5 - 10 ms in all, on a wide pool context: no stream of its own) on device slot `slot` and keeps the
+ * faster for that slot.  A process that is one of several tenants of its GPU does not tune (HS_ED25519_E_ARG here): its
+ * calls of that size run on its share of the CUs, where the eight-lane forms do not apply.  ms[0] = one-wavefront form, ms[1] = split form (ms may be NULL).  Returns the pick (0 / 1) or
  * HS_ED25519_E_*; a form whose run did not accept the whole canned batch is an engine error, never a pick.
  * HS_ED25519_OCT_SPLIT=0 / 1 in the environment pins the form instead; HS_ED25519_AUTOTUNE=0 skips the measurement at
  * init (the split form is then used throughout - the choice of two boxes in three). */
@@ -279,10 +281,10 @@ int hs_ed25519_shard_rccl_ranks(void);    /* ranks of the in-process RCCL exchan
  * HS_ED25519_BATCH's.  Runs from hs_ed25519_shard_msm_min() signatures up (default hs_ed25519_rlc_min_batch() x device slots:
  * below ~40,000 signatures per device the per-signature kernels answer sooner; env HS_ED25519_SHARD_MSM_MIN or
  * hs_ed25519_set_shard_msm_min override), below that as HS_ED25519_BATCH.  hs_ed25519_shard_msm_stats: calls that ran the
- * combination and how many of them it accepted outright; its return value counts the combinations that were asked to
- * travel by RCCL but went through pinned host memory because the collective could not be SET UP (no librccl, a device list
- * ncclCommInitAll refuses, no memory for the gather buffers) - the records are still on their devices then, so the call
- * verifies instead of failing; an error after the grouped call has started is returned as an error. */
+ * combination and how many of them it accepted outright; its return value counts the exchanges (bitmap slices or partial
+ * points) that were asked to travel by RCCL but went through pinned host memory because the collective could not be SET UP
+ * (no librccl, a device list ncclCommInitAll refuses, no memory for the gather buffers) - every device still holds its part
+ * then, so the call verifies instead of failing; an error after the grouped call has started is returned as an error. */
 size_t hs_ed25519_shard_msm_min(void);
 int hs_ed25519_set_shard_msm_min(size_t n);
 int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts);

@@ -1,6 +1,6 @@
 """One process with the eight-lane cold form pinned by the environment (HS_ED25519_OCT_SPLIT=0: k_verify_fused8, =1: k_verify_fused8h
-at every size up to 8,192 - the library's own choice between 4,097 and 8,192 signatures follows the GPU, so a single box exercises
-only one of them there): every edge and torsion-fuzz vector in both modes and a ~3 % corrupted 6,667-signature QC, device-resident
+at every size up to 8,192 - the library's own choice between 4,097 and 8,192 signatures is the form it measured faster on the GPU
+at init, so a single box exercises only one of them there): every edge and torsion-fuzz vector in both modes and a ~3 % corrupted 6,667-signature QC, device-resident
 through the C ABI.  Prints one JSON object {"kernel": ..., "strict": [...], "batch": [...], "qc": {mode: hex bitmap}}."""
 import json
 import os

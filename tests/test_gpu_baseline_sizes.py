@@ -43,7 +43,7 @@ def test_cold_and_cached_vs_oracle_at_baseline_size(oracle, n):
         assert not ok and bits(bm, n) == expect, "cold path, mode %d" % mode
         ok, bm = ks.verify_packed(dg, packed, sg, n, mode, shared=True, want_bitmap=True)
         assert not ok and bits(bm, n) == expect, "key-cache path, mode %d" % mode
-    # 4,097 ... 8,192 signatures: the split eight-lane form on a slow-feeding box, the one-wavefront form on a fast-feeding one (measured at init)
+    # 4,097 ... 8,192 signatures: whichever of the two eight-lane forms hs_ed25519_autotune measured faster on this GPU at init
     assert _lib.lib().hs_ed25519_dominant_kernel_for(n).decode() in (("k_verify_fused8h", "k_verify_fused8") if n <= 8192 else (("k_verify_fused" if n <= 16384 else ("k_verify_fused3" if n <= 32768 else "k_verify_tail")),))
     assert _lib.lib().hs_ed25519_cached_kernel_for(n).decode() == "k_verify_cached_lane2r"
     ks.close()
@@ -64,10 +64,10 @@ def test_pairs_form_vs_oracle_at_baseline_size(oracle, n):
     run.close()
 
 
-@pytest.mark.parametrize("reps,kernel", [(193, ("k_cached_chain2",)), (98, ("k_cached_chain2", "k_verify_cached_lane"))])      # 100,352: by box
+@pytest.mark.parametrize("reps,kernel", [(193, ("k_cached_chain2",)), (98, ("k_cached_chain2",))])      # 197,632 and 100,352
 def test_large_cached_call_takes_the_batched_finish_by_size(oracle, reps, kernel):
     """n = 197,632: hs_ed25519_verify_shared_cached dispatches the chains + batched-finish pair by size (a lone call: four
-    signatures per finish lane); 100,352: the same on a fast-feeding GPU, the one-lane kernel on a slow-feeding one.  1,024 distinct committee keys, their votes tiled, ~3 % corrupted
+    signatures per finish lane), from 98,305 signatures on every GPU (round 5 retired the per-box switch between 98,305 and 196,607).  1,024 distinct committee keys, their votes tiled, ~3 % corrupted
     individually."""
     base = 1024
     dg, pk, sg = synth.make_batch(base, shared=True, cache_dir=CACHE)

@@ -554,10 +554,10 @@ def test_mixed_concurrent_callers(oracle):
 
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_both_eight_lane_forms_on_any_box(oracle, edge_vectors, torsion_fuzz, split):
-    """Between 4,097 and 8,192 signatures the library picks the one-wavefront eight-lane kernel on a fast-feeding GPU and the
-    split one (main + helper wavefront) on a slow-feeding one (k_feed_probe at init), so one box exercises only one of them at
-    QC size.  Pin each through the environment in a process of its own: all labelled vectors in both modes, and a ~3 %
-    corrupted 6,667-signature QC bit-exact against the oracle."""
+    """Between 4,097 and 8,192 signatures the library picks whichever eight-lane kernel - one wavefront, or main + helper - it
+    measured faster on this GPU at init (hs_ed25519_autotune), so one box exercises only one of them at QC size.  Pin each
+    through the environment in a process of its own: all labelled vectors in both modes, and a ~3 % corrupted 6,667-signature
+    QC bit-exact against the oracle.  (The per-context selectors 6 / 7 reach both forms too: tests/test_gpu_differential.py.)"""
     import json
     import subprocess
     import sys
