@@ -243,8 +243,8 @@ const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, size_t coun
  * 3 - 10 % in either direction; the driver's box contradicted the instruction-feed proxy that round used).  So the library
  * measures the thing itself: hs_ed25519_init - and this call, on demand (after a power-cap or clock change, say) - times
  * k_verify_fused8 and k_verify_fused8h on a canned, valid 6,667-signature batch (the QC of N = 10,000; signed on the
- * device; alternating runs until the minima of the dispatch timestamps have settled - a GPU idle a moment ago starts at
- * idle clocks -, 5 - 10 ms in all, on a wide pool context: no stream of its own) on device slot `slot` and keeps the
+ * device; three rounds of a block of five runs per form, the first of a block untimed, minima of the dispatch timestamps;
+ * ~10 ms in all, on a wide pool context: no stream of its own) on device slot `slot` and keeps the
  * faster for that slot.  A process that is one of several tenants of its GPU does not tune (HS_ED25519_E_ARG here): its
  * calls of that size run on its share of the CUs, where the eight-lane forms do not apply.  ms[0] = one-wavefront form, ms[1] = split form (ms may be NULL).  Returns the pick (0 / 1) or
  * HS_ED25519_E_*; a form whose run did not accept the whole canned batch is an engine error, never a pick.

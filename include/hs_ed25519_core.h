@@ -88,7 +88,7 @@ uint32_t hs_ed25519_abi_version(void);
 #define HS_ED25519_E_BUSY (-5)     /* hs_ed25519_submit only: every pool context is in flight - wait on a ticket, retry */
 
 /* Select the GPU (HIP ordinal), build the base-point tables on it (67 MB, a few ms), time the two forms of the
- * eight-lane cold kernel on a canned 6,667-signature batch and keep the faster for this GPU (5 - 10 ms;
+ * eight-lane cold kernel on a canned 6,667-signature batch and keep the faster for this GPU (~10 ms;
  * hs_ed25519_autotune in hs_ed25519.h), and pre-size the context pool for batches of `max_batch` signatures
  * (contexts grow on demand).  Idempotent and thread-safe.  Returns 0 or HS_ED25519_E_*.
  * The environment is NOT modified (round 5; a library must not call setenv in a threaded host): the pools want
