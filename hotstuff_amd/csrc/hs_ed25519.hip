@@ -776,7 +776,7 @@ static const size_t kCachedLane1Min = 98304;
 // lone wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
 // four calls in flight 341 -> 414 M signatures/s at 49,152 - 66,667, 353 / 382 -> 436 - 441 at 131,072 (343 against 346 - 353
 // at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the one-lane kernel's 0.40 and the
-// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) on a fast-feeding box - above 98,304, where the one-lane
+// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) on one box - above 98,304, where the one-lane
 // kernel used to take over (on some boxes the one-lane kernel still wins there by 7 %, profiles/r4_t_cached_c_slow_box.md).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
 // the tail is as long as the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
 // A lone call takes the two-launch form above 98,304 signatures on every GPU (round 5: round 4 switched there by an init-time proxy
@@ -1664,6 +1664,14 @@ extern "C" int hs_ed25519_keyset_create_on(hs_ed25519_keyset **out, const uint8_
     hs_ed25519_keyset *ks = new (std::nothrow) hs_ed25519_keyset();
     if (!ks) return fail(HS_ED25519_E_NOMEM, "keyset_create: out of memory");
     ks->slot = slot;
+    // Registration runs on a wide pool context's stream, not on the legacy stream: a legacy-stream operation is an error
+    // (hipErrorStreamCaptureImplicit) while another thread captures a round ring's hipGraph, and a node registers the next epoch's
+    // committee while rounds stream (round 5: the thread-sanitizer run of tests/cpp/stress_host.cpp hit it twice in 48,000 calls).
+    hs_ed25519_ctx *pc = nullptr;
+    rc = pool_get(&pc, slot, (size_t)-1);
+    if (rc) { delete ks; return rc; }
+    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } pool_guard{pc};
+    hipStream_t st = pc->stream;
     u32 *d_in = nullptr, *d_axy = nullptr;
     hipError_t e = hipSuccess;
     do {
@@ -1673,12 +1681,12 @@ extern "C" int hs_ed25519_keyset_create_on(hs_ed25519_keyset **out, const uint8_
         if ((e = hipMalloc((void **)&ks->d_niels, nkeys * 128)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&d_in, nkeys * 32)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&d_axy, nkeys * 80)) != hipSuccess) break;
-        if ((e = hipMemcpy(d_in, pks, nkeys * 32, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_in, pks, nkeys * 32, hipMemcpyHostToDevice, st)) != hipSuccess) break;
         const u32 nk = (u32)nkeys;
         void *a[] = { &d_in, (void *)&nk, &d_axy, &ks->d_pk, &ks->d_flag, &ks->d_niels };
-        if ((e = hipLaunchKernel((const void *)k_keyset_decompress, dim3((nk + 63) / 64), dim3(64), a, 0, nullptr)) != hipSuccess) break;
-        if (build_tables(ks->d_tab, d_axy, nkeys, true, nullptr)) { e = hipErrorUnknown; break; }
-        e = hipDeviceSynchronize();
+        if ((e = hipLaunchKernel((const void *)k_keyset_decompress, dim3((nk + 63) / 64), dim3(64), a, 0, st)) != hipSuccess) break;
+        if (build_tables(ks->d_tab, d_axy, nkeys, true, st)) { e = hipErrorUnknown; break; }
+        e = hipStreamSynchronize(st);
     } while (0);
     if (d_in) (void)hipFree(d_in);
     if (d_axy) (void)hipFree(d_axy);

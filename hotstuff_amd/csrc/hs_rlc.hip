@@ -454,7 +454,10 @@ int hs::rlc_reserve(hs_ed25519_ctx *ctx, size_t n, void *stream) {
     HS_HIP(hipMalloc((void **)&w->wsum, (size_t)(HS_RLC_WINDOWS + 1) * HS_RLC_WSUM_WORDS * 4), "hipMalloc rlc window sums");
     HS_HIP(hipMalloc((void **)&w->tabs, (size_t)4 * kTabWords * 4), "hipMalloc rlc offsets");
     HS_HIP(hipMalloc((void **)&w->small, kSmallBytes + 64 + kPartBytes + 64), "hipMalloc rlc flags");      // ... | epoch | partial record | join flag
-    HS_HIP(hipMemset(w->small + kSmallBytes, 0, 64), "rlc clear epoch");       // the execution counter starts at 0 and only k_rlc_final writes it
+    // the execution counter starts at 0 and only k_rlc_final writes it.  On the context's own stream, not the legacy stream: a legacy-
+    // stream operation fails (hipErrorStreamCaptureImplicit) while another thread captures a round ring's graph (round 5, TSan run)
+    HS_HIP(hipMemsetAsync(w->small + kSmallBytes, 0, 64, ctx->stream), "rlc clear epoch");
+    HS_HIP(hipStreamSynchronize(ctx->stream), "rlc clear epoch");
     w->np = np;
     return 0;
 }
@@ -516,7 +519,8 @@ extern "C" int hs_ed25519_ctx_rlc_last(hs_ed25519_ctx *ctx, size_t *calls) {
     HS_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(ctx->stream), "stream sync");
     u32 flags[2] = {0, 0};
-    HS_HIP(hipMemcpy(flags, w->small, 8, hipMemcpyDeviceToHost), "read rlc flags");        // failed, ok
+    HS_HIP(hipMemcpyAsync(flags, w->small, 8, hipMemcpyDeviceToHost, ctx->stream), "read rlc flags");        // failed, ok (never the legacy stream)
+    HS_HIP(hipStreamSynchronize(ctx->stream), "read rlc flags");
     return flags[1] ? 1 : 0;
 }
 

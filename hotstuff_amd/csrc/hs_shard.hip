@@ -413,7 +413,8 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
         if (rccl) {      // a collective was asked for but a slot had no signatures: records fetched one by one instead
             for (int s : live) {
                 if (hipSetDevice(jobs[s].c->device) != hipSuccess ||
-                    hipMemcpy(jobs[s].c->h_out, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToHost) != hipSuccess)
+                    hipMemcpyAsync(jobs[s].c->h_out, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToHost, jobs[s].c->stream) != hipSuccess ||
+                    hipStreamSynchronize(jobs[s].c->stream) != hipSuccess)
                     return fail(HS_ED25519_E_DEVICE, "D2H partial point");
             }
         }

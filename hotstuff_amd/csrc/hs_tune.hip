@@ -107,8 +107,9 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
             }
             // a form that does not accept the canned valid batch is an engine error, never a pick
             uint32_t nrej = 1;
-            HS_HIP(hipMemcpy(&nrej, d + o_nr, 4, hipMemcpyDeviceToHost), "autotune: D2H reject counter");
-            HS_HIP(hipMemcpy(bm.data(), d + o_bm, bm.size(), hipMemcpyDeviceToHost), "autotune: D2H bitmap");
+            HS_HIP(hipMemcpyAsync(&nrej, d + o_nr, 4, hipMemcpyDeviceToHost, st), "autotune: D2H reject counter");      // never the legacy stream
+            HS_HIP(hipMemcpyAsync(bm.data(), d + o_bm, bm.size(), hipMemcpyDeviceToHost, st), "autotune: D2H bitmap");
+            HS_HIP(hipStreamSynchronize(st), "autotune: D2H verdicts");
             if (nrej != 0 || !bitmap_all_ones(bm.data(), n))
                 return fail(HS_ED25519_E_DEVICE, f ? "autotune: k_verify_fused8h did not accept the canned valid batch"
                                                    : "autotune: k_verify_fused8 did not accept the canned valid batch");

@@ -4,6 +4,8 @@
 #   bench   the driver's command; the line, its detail file and a one-screen summary
 #   diff    the scale differential: 10^7 crafted tuples through every kernel form + 10^7 / 10^5 scalars through half_scalar
 #   prof    rocprofv3 --kernel-trace --stats of the headline workload (the kernel's average duration the roofline must agree with)
+#   san     the host side under -fsanitize=thread and address,undefined (python -c "import __graft_entry__ as g; g.build_sanitized()"
+#           first, here: build/san/ travels with the snapshot): canary, the 15-thread stress client, the C++ mirror tests
 tag=${1:-a}; shift
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
@@ -51,6 +53,21 @@ for k in ('random', 'adversarial'):
 prof)
     timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r5_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
     python tools/rocpd_summary.py $(find /tmp/r5_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    ;;
+san)
+    for kind in tsan asan; do
+        d=build/san/$kind
+        [ -x $d/stress_host ] || { echo "no $kind build"; continue; }
+        if [ $kind = tsan ]; then export TSAN_OPTIONS="suppressions=$PWD/tests/cpp/tsan.supp history_size=4 second_deadlock_stack=1 exitcode=66 log_path=$PWD/${O}_tsan_report"
+        else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"; fi
+        timeout 60 $d/stress_host canary > ${O}_${kind}_canary.txt 2>&1; echo "$kind canary rc=$? (66 / 67 = the detector fired)"
+        rm -f ${O}_${kind}_report*
+        timeout 300 $d/stress_host 6 > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
+        PYTHONPATH=tools:tests python tests/test_gpu_cpp_mirror.py fixture /tmp/mirror_fixture.bin && timeout 200 $d/mirror_tests /tmp/mirror_fixture.bin > ${O}_${kind}_mirror.txt 2>&1; echo "$kind mirror_tests rc=$?"; grep -c "^ok" ${O}_${kind}_mirror.txt; grep "^FAIL" ${O}_${kind}_mirror.txt | head
+        unset TSAN_OPTIONS ASAN_OPTIONS UBSAN_OPTIONS
+        ls ${O}_${kind}_report* 2>/dev/null | head -5
+        grep -h "SUMMARY" ${O}_${kind}_report* 2>/dev/null | sort | uniq -c | sort -rn | head -10
+    done
     ;;
 esac
 done
