@@ -225,3 +225,58 @@ def test_streamed_rounds_single_thread_sustained_rate(cached):
     assert all(v > 1e6 for v in results.values())
     if ks:
         ks.close()
+
+
+def test_key_sets_are_registered_while_a_ring_captures_its_graphs(oracle):
+    """A node registers the next epoch's committee while rounds stream.  A legacy-stream operation is an error
+    (hipErrorStreamCaptureImplicit) while ANOTHER thread captures a hipGraph; until round 5 key-set registration ran on the legacy
+    stream, and the thread-sanitizer run of the stress client caught it failing twice in 48,000 calls
+    (profiles/r5_t_sanitizer_runs.txt).  One thread drives a graph-mode ring whose every round has another size (a capture or an
+    update each time), another registers and drops key sets and reads an RLC stage's flags; nothing may fail and every verdict
+    equals the oracle's."""
+    import threading
+    n = 4096
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    dgc, pkc, sgc, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=16)
+    expect = oracle_verify_many(oracle, dgc, 0, pkc, sgc, n, 0)
+    errors, done = [], threading.Event()
+
+    def rounds():
+        try:
+            ring = _lib.RoundRing(n, slots=2, kind="graph")
+            r = 0
+            while not done.is_set() or r < 40:
+                m = 64 * (1 + (r * 7) % 63)          # 64 ... 4,032 signatures: a different grid almost every round
+                fill(ring, r % 2, dgc, pkc[: 32 * m], sgc[: 64 * m], m, True)
+                ring.submit(r % 2, _lib.BATCH)
+                ok, bm = ring.wait(r % 2)
+                if bits(bm, m) != expect[:m]:
+                    errors.append("round %d of %d signatures: bitmap differs from the oracle" % (r, m))
+                r += 1
+            ring.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append("ring: %s: %s" % (type(e).__name__, e))
+
+    def registrations():
+        try:
+            keys = [pk[32 * i:32 * i + 32] for i in range(512)]
+            for i in range(25):
+                ks = _lib.KeySet(keys[i:i + 256])
+                packed, idx = ks.indices(keys[i:i + 200])
+                ok, bm = ks.verify_packed(dg, packed, b"".join(sg[64 * (i + j):64 * (i + j) + 64] for j in range(200)), 200, _lib.BATCH,
+                                          shared=True, want_bitmap=True)
+                if not ok:
+                    errors.append("key set %d rejected valid signatures" % i)
+                ks.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append("registration: %s: %s" % (type(e).__name__, e))
+        finally:
+            done.set()
+
+    ts = [threading.Thread(target=rounds), threading.Thread(target=registrations)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not any(t.is_alive() for t in ts), "a thread is stuck"
+    assert not errors, errors[:4]
