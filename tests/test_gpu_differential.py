@@ -22,8 +22,11 @@ def test_a_million_crafted_tuples_through_every_kernel_form():
     assert rep["total"] == 1 << 20 and rep["shared_digest_chunks"] == 1
     assert rep["label_check"]["mismatches"] == 0, rep["label_check"]
     assert rep["mismatches"] == 0, rep["first_mismatches"][:4]
-    assert all(f["verifications"] == 2 << 20 for f in rep["forms"].values()), rep["forms"]
-    assert len(rep["forms"]) >= 17
+    rlc = {k: f for k, f in rep["forms"].items() if k.startswith("k_rlc_")}
+    assert all(f["verifications"] == 2 << 20 for k, f in rep["forms"].items() if k not in rlc), rep["forms"]
+    assert len(rep["forms"]) >= 19 and len(rlc) == 2
+    for f in rlc.values():       # mixed calls localised to BATCH's labels; honest-only calls accepted by the combination itself
+        assert f["mismatches"] == 0 and f["honest_calls"] >= 8 and f["calls_accepted_by_the_combination"] == f["honest_calls"], f
     # the classes the differential exists for were there, with both verdicts
     for name in ("A+T", "A+T,R+T", "torsion-A,R+T"):
         c = rep["classes"][name]

@@ -164,6 +164,62 @@ def run(total, chunk, seed=1, pool_seeds=1024, threads=None, shared_every=4, log
                                                             "msg": bytes(c["msgs"][0 if shared else i]).hex(), "pk": bytes(c["pk"][i]).hex(), "sig": bytes(c["sig"][i]).hex()})
         ctx.set_kernel(_lib.KERNEL_AUTO)
         ctx.set_concurrent(False)
+        # dalek's verify_batch AS COMPUTED (HS_ED25519_BATCH_RLC: one random linear combination per call, Pippenger MSM), cold and through
+        # the key set.  (a) calls of 16,384 tuples of every class: each call holds hundreds of invalid torsion-free tuples, so the
+        # combination rejects (all but 2^-127 of the time) and the per-signature kernels localise - the bitmap must be BATCH's labels
+        # bit for bit, which runs the five RLC stages over off-curve points, non-canonical scalars and torsion at scale; (b) the
+        # chunk's honest tuples alone: every call must be accepted BY THE COMBINATION (rlc_last == 1), bitmap all ones.
+        if only is None or any("rlc" in o for o in only):
+            want = (c["expect"] & 1).astype(np.uint8)
+            honest = np.nonzero(c["cls"] == craft.CLASSES.index("honest"))[0]
+            honest = honest[: len(honest) // 64 * 64]
+            h_pk = torch.from_numpy(np.ascontiguousarray(c["pk"][honest])).to(dev)
+            h_sg = torch.from_numpy(np.ascontiguousarray(c["sig"][honest])).to(dev)
+            h_dg = d_dg if shared else torch.from_numpy(np.ascontiguousarray(c["msgs"][honest])).to(dev)
+            h_ki = torch.from_numpy(inv[honest].astype(np.int32)).to(dev)
+            ctx.set_rlc_min(1)
+            per = 16384
+            for name, cached in (("k_rlc_* (BATCH_RLC, cold)", False), ("k_rlc_* (BATCH_RLC, key cache)", True)):
+                fr = rep["forms"].setdefault(name, {"verifications": 0, "mismatches": 0, "calls_accepted_by_the_combination": 0, "honest_calls": 0})
+                bm.zero_()
+                torch.cuda.synchronize(dev)
+                for pos in range(0, n, per):
+                    m_ = min(per, n - pos)
+                    dg = d_dg.data_ptr() + (0 if shared else 32 * pos)
+                    if cached:
+                        ctx.verify_cached(ks, dg, stride, d_ki.data_ptr() + 4 * pos, d_sg.data_ptr() + 64 * pos, m_, _lib.BATCH_RLC, bm.data_ptr() + pos // 8, 0, 0)
+                    else:
+                        ctx.verify(dg, stride, d_pk.data_ptr() + 32 * pos, d_sg.data_ptr() + 64 * pos, m_, _lib.BATCH_RLC, bm.data_ptr() + pos // 8, 0, 0)
+                st.synchronize()
+                got = np.unpackbits(bm.cpu().numpy(), bitorder="little")[:n]
+                diff = np.nonzero(got != want)[0]
+                fr["verifications"] += n
+                fr["mismatches"] += int(len(diff))
+                rep["mismatches"] += int(len(diff))
+                for i in diff[:3]:
+                    if len(rep["first_mismatches"]) < 24:
+                        rep["first_mismatches"].append({"form": name, "mode": "BATCH_RLC", "chunk": chunk_no, "index": int(i), "class": craft.CLASSES[c["cls"][i]],
+                                                        "gpu": int(got[i]), "oracle": int(want[i]), "pk": bytes(c["pk"][i]).hex(), "sig": bytes(c["sig"][i]).hex()})
+                for pos in range(0, len(honest), per):
+                    m_ = min(per, len(honest) - pos)
+                    bm.zero_()
+                    torch.cuda.synchronize(dev)
+                    dg = h_dg.data_ptr() + (0 if shared else 32 * pos)
+                    if cached:
+                        ctx.verify_cached(ks, dg, stride, h_ki.data_ptr() + 4 * pos, h_sg.data_ptr() + 64 * pos, m_, _lib.BATCH_RLC, bm.data_ptr(), 0, 0)
+                    else:
+                        ctx.verify(dg, stride, h_pk.data_ptr() + 32 * pos, h_sg.data_ptr() + 64 * pos, m_, _lib.BATCH_RLC, bm.data_ptr(), 0, 0)
+                    stage, _ = ctx.rlc_last()
+                    ones = bool((np.unpackbits(bm[: (m_ + 7) // 8].cpu().numpy(), bitorder="little")[:m_] == 1).all())
+                    fr["honest_calls"] += 1
+                    fr["calls_accepted_by_the_combination"] += 1 if (stage == 1 and ones) else 0
+                    fr["verifications"] += m_
+                    if not (stage == 1 and ones):
+                        fr["mismatches"] += 1
+                        rep["mismatches"] += 1
+                        if len(rep["first_mismatches"]) < 24:
+                            rep["first_mismatches"].append({"form": name, "mode": "BATCH_RLC honest-only", "chunk": chunk_no, "call_at": int(pos), "rlc_stage": int(stage), "all_ones": ones})
+            ctx.set_rlc_min(0)
         ks.close()
         rep["seconds"]["gpu"] += time.perf_counter() - t0
         done += n
