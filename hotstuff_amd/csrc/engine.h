@@ -98,14 +98,16 @@ struct dev_state {
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
     // hs_ed25519_autotune: kernel time of the two eight-lane cold forms on a canned 6,667-signature batch on THIS device
     // ([0] k_verify_fused8, [1] k_verify_fused8h; 0 = not measured) and the faster one (-1 = not measured: the split form)
-    float oct_ms[2] = {0.f, 0.f};
-    int oct_pick = -1;
+    float oct_ms[2] = {0.f, 0.f};            // (written and read under g_mu: hs_ed25519_autotune, hs_ed25519_config_dump)
 };
 extern std::mutex g_mu;
 extern std::condition_variable g_cv;
 extern std::atomic<bool> g_init;
 extern std::vector<dev_state> g_devs;
 extern std::atomic<size_t> g_max_batch;
+constexpr int kMaxSlots = 64;                // hs_ed25519_init_devices takes at most this many device slots
+extern std::atomic<int> g_oct_pick[kMaxSlots];   // per slot: the faster eight-lane cold form as measured (0 one wavefront, 1 split, -1 not measured); read by
+                                             // every cold call without a lock, written by hs_ed25519_autotune - hence atomics beside g_devs, not inside it
 extern int kMaxPool[2];                      // contexts per pool: [0] wide, [1] narrow
 extern unsigned kPoolPartitions;             // CU slices the narrow pool's streams are spread over
 extern unsigned kTenants, kTenantIndex;      // this process is tenant kTenantIndex of kTenants on its GPU (hs_ed25519_set_tenancy)

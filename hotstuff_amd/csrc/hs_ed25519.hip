@@ -762,6 +762,7 @@ std::condition_variable hs::g_cv;
 std::atomic<bool> hs::g_init{false};
 std::vector<dev_state> hs::g_devs;           // written under g_mu by init / shutdown only
 std::atomic<size_t> hs::g_max_batch{0};
+std::atomic<int> hs::g_oct_pick[hs::kMaxSlots];      // set to -1 by init
 // Pool sizes per device slot.  Every context owns a stream and HIP multiplexes streams onto 16 hardware queues
 // (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
 // narrow contexts - two per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
@@ -1021,7 +1022,7 @@ static const char *env_knob(const char *name) {
 }
 extern "C" uint32_t hs_ed25519_abi_version(void) { return HS_ED25519_ABI_VERSION; }
 extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t max_batch) {
-    if (!ordinals || count == 0 || count > 64) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
+    if (!ordinals || count == 0 || count > (size_t)kMaxSlots) return fail(HS_ED25519_E_ARG, "hs_ed25519_init_devices: bad device list");
     std::unique_lock<std::mutex> lk(g_mu);
     if (g_init.load()) {
         // idempotent for the same device list; a different one would silently run on the wrong GPUs
@@ -1094,6 +1095,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
         devs[i].cus = (unsigned)prop.multiProcessorCount;
     }
     HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
+    for (int i = 0; i < kMaxSlots; i++) g_oct_pick[i].store(-1, std::memory_order_relaxed);
     g_devs.swap(devs);
     g_max_batch.store(max_batch ? max_batch : 1024);
     g_init.store(true);
@@ -1156,10 +1158,11 @@ extern "C" size_t hs_ed25519_config_dump(char *buf, size_t cap) {
     o += "\"devices\": [";
     for (size_t i = 0; i < g_devs.size(); i++) {
         const dev_state &d = g_devs[i];
+        const int pick = g_oct_pick[i].load(std::memory_order_relaxed);
         snprintf(t, sizeof t, "%s{\"slot\": %zu, \"ordinal\": %d, \"cus\": %u, \"oct_ms\": {\"k_verify_fused8\": %.4f, \"k_verify_fused8h\": %.4f}, "
                  "\"oct_pick\": \"%s\", \"oct_form_4097_8192\": \"%s\"}", i ? ", " : "", i, d.ordinal, d.cus, d.oct_ms[0], d.oct_ms[1],
-                 d.oct_pick < 0 ? "not measured" : (d.oct_pick ? "k_verify_fused8h" : "k_verify_fused8"),
-                 oct_split_for(6667, (size_t)d.cus * 4, d.oct_pick) ? "k_verify_fused8h" : "k_verify_fused8");
+                 pick < 0 ? "not measured" : (pick ? "k_verify_fused8h" : "k_verify_fused8"),
+                 oct_split_for(6667, (size_t)d.cus * 4, pick) ? "k_verify_fused8h" : "k_verify_fused8");
         o += t;
     }
     o += "], \"env_seen\": {";
@@ -1192,7 +1195,7 @@ static int kernel_for(const hs_ed25519_ctx *ctx, size_t n) {
 extern "C" const char *hs_ed25519_dominant_kernel_for(size_t n) {
     const size_t simds = g_init.load() && !g_devs.empty() && g_devs[0].cus ? (size_t)g_devs[0].cus * 4 : 1024;
     if (n <= simds * 8 && n <= g_oct_max_batch.load())
-        return oct_split_for(n, simds, g_init.load() && !g_devs.empty() ? g_devs[0].oct_pick : -1) ? "k_verify_fused8h" : "k_verify_fused8";
+        return oct_split_for(n, simds, g_init.load() ? g_oct_pick[0].load(std::memory_order_relaxed) : -1) ? "k_verify_fused8h" : "k_verify_fused8";
     if (n <= g_quad_max_batch.load()) return n <= simds * 16 ? "k_verify_fused" : "k_verify_fused3";
     const size_t tail = n % (simds * 64);       // a sliver past whole rounds of wavefronts rides in the stage-2 launch (enqueue_cold)
     return n > simds * 64 && tail && tail <= g_tail_max.load() ? "k_verify_tail" : "k_verify";
@@ -1272,7 +1275,7 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         const int ksel = ctx->kernel == HS_K_CACHED_C ? HS_K_AUTO : ctx->kernel;      // a key-cache selector leaves cold calls alone
         const bool oct_forced = ksel == HS_K_OCT || ksel == HS_K_OCT_SPLIT;
         if (n <= simds * 8 && (oct_forced || (ksel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n))) {
-            const bool split = oct_forced ? ksel == HS_K_OCT_SPLIT : oct_split_for(n, simds, g_devs[ctx->slot].oct_pick);
+            const bool split = oct_forced ? ksel == HS_K_OCT_SPLIT : oct_split_for(n, simds, g_oct_pick[ctx->slot].load(std::memory_order_relaxed));
             if (split)
                 HS_HIP(launch1((const void *)k_verify_fused8h, dim3(np / 8), dim3(128), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                        "launch k_verify_fused8h");

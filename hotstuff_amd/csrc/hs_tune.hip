@@ -40,6 +40,10 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
     if (slot < 0 || slot >= dev_slots()) return fail(HS_ED25519_E_ARG, "autotune: no such device slot");
     const size_t n = kTuneSigs, np = round_up(n, 64);
     if (kTenants > 1) return fail(HS_ED25519_E_ARG, "autotune: a co-tenant's calls of this size run on its share of the CUs, where the eight-lane forms do not apply");
+    // device buffer: [seeds K x 32][keys K x 32][secrets n x 64][digest 64][pks n x 32][sigs n x 64][bitmap][reject counter]
+    const size_t o_seed = 0, o_key = o_seed + 32 * kTuneKeys, o_sec = o_key + 32 * kTuneKeys, o_dg = o_sec + 64 * np, o_pk = o_dg + 64,
+                 o_sig = o_pk + 32 * np, o_bm = o_sig + 64 * np, o_nr = o_bm + bitmap_bytes(np), total = o_nr + 16;
+    std::vector<uint8_t> h(o_pk + 32 * np, 0), bm(bitmap_bytes(np));      // host mirrors: declared before the guard, whose destructor drains the stream that may still read them
     hs_ed25519_ctx *c = nullptr;
     int rc = pool_get(&c, slot, n);              // a wide pool context: no stream of our own (see above)
     if (rc) return rc;
@@ -55,13 +59,9 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     rc = ctx_reserve(c, n, c->staging);
     if (rc) return rc;
-    // device buffer: [seeds K x 32][keys K x 32][secrets n x 64][digest 64][pks n x 32][sigs n x 64][bitmap][reject counter]
-    const size_t o_seed = 0, o_key = o_seed + 32 * kTuneKeys, o_sec = o_key + 32 * kTuneKeys, o_dg = o_sec + 64 * np, o_pk = o_dg + 64,
-                 o_sig = o_pk + 32 * np, o_bm = o_sig + 64 * np, o_nr = o_bm + bitmap_bytes(np), total = o_nr + 16;
     if (hipMalloc((void **)&guard.d, total) != hipSuccess) { (void)hipGetLastError(); return fail(HS_ED25519_E_NOMEM, "autotune: hipMalloc"); }
     uint8_t *d = guard.d;
     hipStream_t st = (hipStream_t)hs_ed25519_ctx_stream(c);
-    std::vector<uint8_t> h(o_pk + 32 * np, 0);
     uint64_t s = 0x6873747565643235ull;      // fixed: the batch is the same on every box
     for (size_t i = 0; i < 32 * kTuneKeys + 0; i += 8) { const uint64_t v = mix64(s); memcpy(&h[o_seed + i], &v, 8); }
     for (size_t i = 0; i < 32; i += 8) { const uint64_t v = mix64(s); memcpy(&h[o_dg + i], &v, 8); }
@@ -84,7 +84,6 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
     if (rc) return rc;
     double best[2] = {1e30, 1e30};
     const int form[2] = {HS_K_OCT, HS_K_OCT_SPLIT};
-    std::vector<uint8_t> bm(bitmap_bytes(np));
     // Blocks of kTuneBlock consecutive runs of ONE form, the forms' blocks alternating, the first run of a block untimed: what the
     // metric times is a QC kernel whose code and tables are warm (bench.py's p50 is over 200 calls of one form back to back).
     // Strictly alternating single runs measured 0.39 / 0.42 ms where the same kernels back to back run 0.25 / 0.30 ms
@@ -121,7 +120,7 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_init.load() && slot < (int)g_devs.size()) {
             g_devs[slot].oct_ms[0] = (float)best[0]; g_devs[slot].oct_ms[1] = (float)best[1];
-            g_devs[slot].oct_pick = pick;
+            g_oct_pick[slot].store(pick, std::memory_order_relaxed);
         }
     }
     if (ms_out) { ms_out[0] = best[0]; ms_out[1] = best[1]; }

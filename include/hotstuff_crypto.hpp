@@ -76,6 +76,10 @@ inline CryptoResult to_result(int rc) { return CryptoResult{rc == 1}; }
 // process); unset = the GPU named by HS_ED25519_DEVICE (default 0).  Idempotent and thread-safe in the library.
 inline bool ensure_init() {
     static const int rc = [] {
+        // the library must have been built from the header this mirror was compiled against (same ABI major): what the Rust
+        // shim's engine_start does.  A mismatch fails every call, loudly, instead of calling through
+        // argument lists that may have changed.
+        if ((hs_ed25519_abi_version() >> 16) != (HS_ED25519_ABI_VERSION >> 16)) return HS_ED25519_E_ARG;
         std::vector<int> devs;
         if (const char *e = std::getenv("HS_ED25519_DEVICES")) {
             int v = 0; bool have = false;
