@@ -83,6 +83,10 @@ struct hs_ed25519_keyset {
     size_t nkeys = 0;
     hs::u32 *d_tab = nullptr, *d_pk = nullptr, *d_flag = nullptr;
     hs::u32 *d_niels = nullptr;   // [key][32 words]: affine Niels form of +A (y+x, y-x, 2dxy, pad) for the RLC path
+    // host-API work that names this set and has not been collected yet: jobs and groups (synchronous calls, tickets), round
+    // rings (for their whole life).  hs_ed25519_keyset_destroy waits for it to drain instead of synchronising the device -
+    // a device-wide synchronisation from one thread breaks a hipGraph capture in progress on another (round 5).
+    mutable std::atomic<int> users{0};
 };
 
 namespace hs {
@@ -128,7 +132,9 @@ int enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src msg
                    const uint8_t *d_sigs, size_t n, uint32_t mode, uint8_t *d_bitmap, uint32_t *d_nreject, void *stream,
                    const u32 *d_skip = nullptr);
 // one host-pointer verification on one device slot, split so that several devices can be in flight from one thread
-struct host_job { hs_ed25519_ctx *c = nullptr; size_t n = 0; bool zc = false; };
+struct host_job { hs_ed25519_ctx *c = nullptr; size_t n = 0; bool zc = false; const hs_ed25519_keyset *ks = nullptr; /* held from submit to finish / abandon */ };
+inline void ks_hold(const hs_ed25519_keyset *ks) { if (ks) ks->users.fetch_add(1, std::memory_order_acq_rel); }
+inline void ks_release(const hs_ed25519_keyset *ks) { if (ks) ks->users.fetch_sub(1, std::memory_order_acq_rel); }
 // gather (optional): element p of the call is signature gather[p] of `sigs` (and digest gather[p] of `digests` when they are
 // per tuple) - a routed shard is packed straight into the pinned staging, one copy instead of two; `keys` stay contiguous
 int host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const uint8_t *digests, size_t digest_stride,

@@ -26,6 +26,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <new>
 #include <mutex>
 #include <condition_variable>
@@ -1710,8 +1712,20 @@ extern "C" int hs_ed25519_keyset_create(hs_ed25519_keyset **out, const uint8_t *
 }
 extern "C" void hs_ed25519_keyset_destroy(hs_ed25519_keyset *ks) {
     if (!ks) return;
+    // No hipDeviceSynchronize here (until round 5 there was one, return value ignored): a device-wide synchronisation marks
+    // every stream that is capturing on ANY thread invalidated, and a node drops the last epoch's committee while its rounds
+    // stream through a graph-mode ring (tests/test_gpu_ring.py, registration while capturing: one run in two failed).  What
+    // must hold is that nothing still reads the tables: the host API counts its uncollected work on the set (engine.h, `users`).
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+    while (ks->users.load(std::memory_order_acquire) > 0 && std::chrono::steady_clock::now() < deadline)
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (ks->users.load(std::memory_order_acquire) > 0) {      // leak rather than free under a running kernel; the struct stays too (late releases touch it)
+        (void)fail(HS_ED25519_E_ARG, "keyset_destroy: work is still in flight on the key set after 10 s (tickets not collected, a round ring "
+                                     "not destroyed?) - its tables are leaked, not freed");
+        return;
+    }
     const int ord = hs::dev_ordinal(ks->slot);
-    if (ord >= 0) { (void)hipSetDevice(ord); (void)hipDeviceSynchronize(); }
+    if (ord >= 0) (void)hipSetDevice(ord);
     if (ks->d_tab) (void)hipFree(ks->d_tab);
     if (ks->d_pk) (void)hipFree(ks->d_pk);
     if (ks->d_flag) (void)hipFree(ks->d_flag);

@@ -213,6 +213,7 @@ int hs::host_submit(host_job &job, int slot, const hs_ed25519_keyset *ks, const 
     int rc = pool_get(&job.c, slot, n, nowait);
     if (rc) return rc;
     hs_ed25519_ctx *c = job.c;
+    job.ks = ks; ks_hold(ks);                      // released with the context: host_finish / host_abandon
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
     rc = ctx_reserve(c, n > hint ? n : hint, true);
@@ -257,7 +258,8 @@ int hs::host_finish(host_job &job, uint8_t *bitmap) {
     hs_ed25519_ctx *c = job.c;
     if (!c) return fail(HS_ED25519_E_ARG, "host_finish: nothing submitted");
     job.c = nullptr;
-    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    struct putter { hs_ed25519_ctx *c; const hs_ed25519_keyset *ks; ~putter() { hs::pool_put(c); hs::ks_release(ks); } } guard{c, job.ks};
+    job.ks = nullptr;
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
     if (bitmap) memcpy(bitmap, c->h_out, (job.n + 7) / 8);
@@ -268,7 +270,8 @@ void hs::host_abandon(host_job &job) {
     (void)hipSetDevice(job.c->device);
     (void)hipStreamSynchronize(job.c->stream);
     pool_put(job.c);
-    job.c = nullptr;
+    ks_release(job.ks);
+    job.c = nullptr; job.ks = nullptr;
 }
 const uint8_t *hs::host_job_bitmap(const host_job &job) { return job.c ? job.c->h_out : nullptr; }
 
@@ -320,7 +323,7 @@ static int group_close_and_launch(host_group *g) {
 static void group_unref(host_group *g) {
     bool last;
     { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
-    if (last) { pool_put(g->c); delete g; }
+    if (last) { pool_put(g->c); ks_release(g->ks); delete g; }
 }
 // this thread's open group (it holds a reference); a thread that exits launches what it left open
 struct open_group_slot {
@@ -366,7 +369,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
             rc = fail(HS_ED25519_E_DEVICE, "hipEventCreate");
         if (!rc && !(g = new (std::nothrow) host_group())) rc = fail(HS_ED25519_E_NOMEM, "out of memory");
         if (rc) { pool_put(c); return rc; }
-        g->c = c; g->ks = ks; g->slot = slot;
+        g->c = c; g->ks = ks; g->slot = slot; ks_hold(ks);      // released when the last member's reference goes (group_unref)
         g->members = 1; g->refs = 1; idx = 0;
         if (more) { g->refs++; t_open.g = g; }                  // the thread's reference to its open group
         else { g->closed = true; closer = true; }
@@ -519,7 +522,10 @@ static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uin
     hs_ed25519_ctx *c = nullptr;
     int rc = pool_get(&c, ks ? ks->slot : 0, n);
     if (rc) return rc;
-    struct putter { hs_ed25519_ctx *c; ~putter() { hs::pool_put(c); } } guard{c};
+    // (an early return below may leave work on the stream: the guard drains it before the context and the key set are let go)
+    struct putter { hs_ed25519_ctx *c; const hs_ed25519_keyset *ks; bool done;
+                    ~putter() { if (!done) (void)hipStreamSynchronize(c->stream); hs::pool_put(c); hs::ks_release(ks); } } guard{c, ks, false};
+    ks_hold(ks);
     HS_HIP(hipSetDevice(c->device), "hipSetDevice");
     const size_t hint = c->narrow ? kPartitionMaxBatch : g_max_batch.load();
     rc = ctx_reserve(c, n > hint ? n : hint, true);
@@ -545,6 +551,7 @@ static int verify_host_tc(const hs_ed25519_keyset *ks, uint64_t round, const uin
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     if (!zc) HS_HIP(hipMemcpyAsync(c->h_out, c->d_out, bitmap_bytes(n), hipMemcpyDeviceToHost, c->stream), "D2H");
     HS_HIP(hipStreamSynchronize(c->stream), "stream sync");
+    guard.done = true;
     if (bitmap) memcpy(bitmap, c->h_out, (n + 7) / 8);
     return bitmap_all_ones(c->h_out, n) ? 1 : 0;
 }
@@ -580,6 +587,7 @@ struct hs_ed25519_ring {
     bool use_graph = false;
     bool zero_copy = false;      // kernels read the pinned slot / write the pinned bitmap directly over PCIe
     size_t captures = 0, launches = 0;
+    size_t recaptures = 0, uncaptured = 0;      // captures another thread's runtime call invalidated: taken again / given up (that round ran as stream operations)
 };
 
 extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
@@ -589,6 +597,7 @@ extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
         if (s.exec) (void)hipGraphExecDestroy(s.exec);
         if (s.ctx) hs_ed25519_ctx_destroy(s.ctx);
     }
+    ks_release(r->ks);
     delete r;
 }
 
@@ -599,7 +608,7 @@ extern "C" int hs_ed25519_ring_create(hs_ed25519_ring **out, size_t slot_batch, 
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     hs_ed25519_ring *r = new (std::nothrow) hs_ed25519_ring();
     if (!r) return fail(HS_ED25519_E_NOMEM, "ring_create: out of memory");
-    r->cap = round_up(slot_batch, 64); r->ks = ks;
+    r->cap = round_up(slot_batch, 64); r->ks = ks; ks_hold(ks);      // for the ring's life: its rounds read the set's tables
     // AUTO follows the measurements (profiles/r1_ring_sweep.md): zero-copy wins or ties up to QC-sized rounds of a
     // 10,000-validator committee; above that the copy engines' bulk transfers are as good and plain stream
     // operations overlap best.  The graph form never won on gfx950 / ROCm 7 and is kept selectable.
@@ -635,6 +644,7 @@ extern "C" int hs_ed25519_ring_begin(hs_ed25519_ring *r, unsigned slot, size_t n
     return 0;
 }
 
+static const int kCaptureTries = 4;
 static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
     hs_ed25519_ctx *c = s.ctx;
     // zero-copy: hipHostMalloc memory is mapped into the device's address space, so the kernels can
@@ -675,30 +685,58 @@ extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_
         int rc = ring_enqueue(r, s, mode);
         if (rc) return rc;
     } else {
+        bool as_stream_ops = false;
         if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode) {
+            // Thread-local capture: this thread's own calls are recorded, other threads' are not.  It does not make the capture
+            // immune to them: on ROCm 7 a device-wide synchronisation issued by ANY thread (hipDeviceSynchronize; the engine has
+            // none after init, the host program may) marks every capturing stream invalidated, and each recorded call after that
+            // - or hipStreamEndCapture - fails with hipErrorStreamCaptureInvalidated (tools/capture_probe.hip measures which
+            // calls do it).  An invalidated capture recorded nothing and left the stream idle, so it is simply taken again; after
+            // kCaptureTries the round runs as plain stream operations - same kernels, same verdict - and the next round tries anew.
             hipGraph_t g = nullptr;
-            HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-            int rc = ring_enqueue(r, s, mode);
-            hipError_t e = hipStreamEndCapture(st, &g);
-            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipStreamEndCapture", e);
-            if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
-                hipGraphNode_t bad = nullptr;
-                hipGraphExecUpdateResult res;
-                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
-                    (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
-                    (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
+            int rc = 0;
+            hipError_t e = hipSuccess;
+            for (int attempt = 0;; attempt++) {
+                g = nullptr;
+                HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+                rc = ring_enqueue(r, s, mode);
+                e = hipStreamEndCapture(st, &g);
+                if (!rc && e == hipSuccess) break;
+                if (g) { (void)hipGraphDestroy(g); g = nullptr; }
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const bool idle = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+                (void)hipGetLastError();
+                // a refusal that is not the capture's (bad arguments, out of memory) is the caller's to see, at once
+                if (rc && rc != HS_ED25519_E_DEVICE) return rc;
+                if (!idle) return fail(HS_ED25519_E_DEVICE, "ring_submit: the slot's stream did not leave capture mode", e);
+                if (attempt + 1 < kCaptureTries) { r->recaptures++; continue; }
+                r->uncaptured++;
+                as_stream_ops = true;
+                break;
+            }
+            if (as_stream_ops) {
+                rc = ring_enqueue(r, s, mode);
+                if (rc) return rc;
+            } else {
+                if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
+                    hipGraphNode_t bad = nullptr;
+                    hipGraphExecUpdateResult res;
+                    if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
+                        (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
+                        (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
+                    }
                 }
+                if (!s.exec) {
+                    e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
+                    if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
+                }
+                (void)hipGraphDestroy(g);
+                s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
+                r->captures++;
             }
-            if (!s.exec) {
-                e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
-                if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
-            }
-            (void)hipGraphDestroy(g);
-            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
-            r->captures++;
         }
-        HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
+        if (!as_stream_ops)
+            HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
     }
     r->launches++;
     s.inflight = true; s.begun = false;
@@ -735,5 +773,10 @@ extern "C" hs_ed25519_ctx *hs_ed25519_ring_slot_ctx(hs_ed25519_ring *r, unsigned
 extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {
     if (!r || !graph_captures || !launches) return fail(HS_ED25519_E_ARG, "ring_stats: null");
     *graph_captures = r->captures; *launches = r->launches;
+    return 0;
+}
+extern "C" int hs_ed25519_ring_capture_stats(const hs_ed25519_ring *r, size_t *recaptures, size_t *uncaptured) {
+    if (!r || !recaptures || !uncaptured) return fail(HS_ED25519_E_ARG, "ring_capture_stats: null");
+    *recaptures = r->recaptures; *uncaptured = r->uncaptured;
     return 0;
 }

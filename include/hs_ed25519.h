@@ -179,6 +179,12 @@ int hs_ed25519_ring_poll(hs_ed25519_ring *ring, unsigned slot);
 int hs_ed25519_ring_wait(hs_ed25519_ring *ring, unsigned slot, uint8_t *bitmap);
 /* Number of graph captures / updates and of rounds submitted so far. */
 int hs_ed25519_ring_stats(const hs_ed25519_ring *ring, size_t *graph_captures, size_t *launches);
+/* HS_ED25519_RING_GRAPH only (ABI 5.1).  A capture is thread-local, yet on ROCm 7 a device-wide synchronisation issued by
+ * any OTHER thread of the process (hipDeviceSynchronize; the engine issues none after init, the host program may)
+ * invalidates it.  The ring takes an invalidated capture again (`recaptures`) and after four attempts runs that round
+ * as plain stream operations (`uncaptured`) - same kernels, same verdict; the next round captures anew.  Both stay 0
+ * in a host that never synchronises the whole device.  tools/capture_probe.hip lists the calls that do it. */
+int hs_ed25519_ring_capture_stats(const hs_ed25519_ring *ring, size_t *recaptures, size_t *uncaptured);
 /* The context a slot runs on - BORROWED: it dies with the ring, never destroy it, and use it only while the slot
  * has nothing in flight.  For the per-context knobs and read-outs (hs_ed25519_ctx_set_rlc_min,
  * hs_ed25519_ctx_rlc_last, hs_ed25519_ctx_set_concurrent, hs_ed25519_ctx_set_kernel).  NULL on bad arguments. */

@@ -283,3 +283,38 @@ def test_heavy_random_corruption_8192_cold_and_cached(oracle):
         assert cached_bits(ks, dg, keys, sg, n, mode, False) == expect
         assert 3000 < sum(expect) < 5200
     ks.close()
+
+
+def test_destroy_waits_for_tickets_in_flight_on_the_key_set(oracle):
+    """hs_ed25519_keyset_destroy does not synchronise the device (it would break a graph capture on another thread); it waits
+    for the host API's uncollected work on the set instead.  A thread destroys the set while tickets on it are out: it returns
+    only after the last one is collected, and their verdicts are the oracle's - the tables were not freed under the kernels."""
+    import threading
+    n = 20000
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    dgc, pkc, sgc, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=30)
+    expect = oracle_verify_many(oracle, dgc, 0, pkc, sgc, n, 0)
+    keys = [pkc[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    packed, idx = ks.indices(keys)
+    tickets = [_lib.Ticket(dgc, packed, sgc, n, _lib.BATCH, shared=True, keyset=ks) for _ in range(3)]
+    small = _lib.Ticket(dgc, packed[:4 * 500], sgc[:64 * 500], 500, _lib.BATCH, shared=True, keyset=ks)      # a group member holds it too
+    done = threading.Event()
+
+    def destroy():
+        ks.close()
+        done.set()
+
+    t = threading.Thread(target=destroy)
+    t.start()
+    assert not done.wait(0.3), "destroy returned with four tickets out on the key set"
+    for tk in tickets[:2]:
+        ok, bm = tk.wait()
+        assert bits(bm, n) == expect
+    assert not done.wait(0.1), "destroy returned with two tickets out on the key set"
+    ok, bm = small.wait()
+    assert bits(bm, 500) == expect[:500]
+    ok, bm = tickets[2].wait()
+    assert bits(bm, n) == expect
+    assert done.wait(5), "destroy did not return after the last ticket was collected"
+    t.join()

@@ -4,6 +4,8 @@
 #   bench   the driver's command; the line, its detail file and a one-screen summary
 #   diff    the scale differential: 10^7 crafted tuples through every kernel form + 10^7 / 10^5 scalars through half_scalar
 #   prof    rocprofv3 --kernel-trace --stats of the headline workload (the kernel's average duration the roofline must agree with)
+#   cap     tools/capture_probe (which runtime calls of another thread break a thread-local capture) + the ring / key-set
+#           thread tests ten times over
 #   san     the host side under -fsanitize=thread and address,undefined (python -c "import __graft_entry__ as g; g.build_sanitized()"
 #           first, here: build/san/ travels with the snapshot): canary, the 15-thread stress client, the C++ mirror tests
 tag=${1:-a}; shift
@@ -53,6 +55,21 @@ for k in ('random', 'adversarial'):
 prof)
     timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r5_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
     python tools/rocpd_summary.py $(find /tmp/r5_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    ;;
+cap)
+    [ -x tools/capture_probe ] || hipcc --offload-arch=gfx950 -O2 -o tools/capture_probe tools/capture_probe.hip -lpthread
+    timeout 120 tools/capture_probe 1500 > ${O}_capture_probe.json 2> ${O}_capture_probe.err; echo "capture_probe rc=$?"
+    python - ${O}_capture_probe.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("HIP runtime", d["hip_runtime_version"])
+for c in d["candidates"]:
+    print("%-48s calls %8d errs %-40s captures ok %6d failed %5d %s" % (c["other_thread"], c["its_calls"], c["its_errors"], c["captures_ok"], c["captures_failed"], c["failures"]))
+PY
+    for i in 1 2 3 4 5 6 7 8 9 10; do
+        timeout 300 python -m pytest tests/test_gpu_ring.py tests/test_gpu_keyset.py -x -q -m gpu -s -k "captures or synchronises or destroy_waits" > ${O}_cap_pytest_$i.txt 2>&1
+        echo "run $i rc=$? $(grep -E 'passed|failed' ${O}_cap_pytest_$i.txt | tail -1) $(grep -h 'device synchronisations' ${O}_cap_pytest_$i.txt)"
+    done
     ;;
 san)
     for kind in tsan asan; do
