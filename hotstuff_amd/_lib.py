@@ -215,8 +215,6 @@ def lib():
                 l.hs_ed25519_ring_wait.restype = ctypes.c_int
                 l.hs_ed25519_ring_stats.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
                 l.hs_ed25519_ring_stats.restype = ctypes.c_int
-                l.hs_ed25519_ring_capture_stats.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
-                l.hs_ed25519_ring_capture_stats.restype = ctypes.c_int
                 l.hs_ed25519_shard_msm_min.restype = sz
                 l.hs_ed25519_set_shard_msm_min.argtypes = [sz]
                 l.hs_ed25519_shard_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
@@ -428,7 +426,7 @@ def ensure_init():
 KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED, KERNEL_FUSED_PAIRS = 0, 1, 3, 4
 KERNEL_CACHED_C = 5          # key cache: chains + batched finish by compression at any size (cold calls: as KERNEL_AUTO)
 KERNEL_OCT, KERNEL_OCT_SPLIT = 6, 7   # cold single calls of <= 8 signatures per SIMD: k_verify_fused8 / k_verify_fused8h whatever the autotune chose
-ABI_VERSION = 0x00050001     # HS_ED25519_ABI_VERSION of include/hs_ed25519_core.h this binding was written against (test: == the header's)
+ABI_VERSION = 0x00050000     # HS_ED25519_ABI_VERSION of include/hs_ed25519_core.h this binding was written against (test: == the header's)
 
 
 def abi_version():
@@ -828,13 +826,6 @@ class RoundRing:
         """(graph captures / updates, rounds submitted)"""
         a, b = ctypes.c_size_t(), ctypes.c_size_t()
         check(lib().hs_ed25519_ring_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "hs_ed25519_ring_stats")
-        return a.value, b.value
-
-    def capture_stats(self):
-        """hs_ed25519_ring_capture_stats (graph form): (captures another thread's device-wide synchronisation invalidated and
-        the ring took again, rounds that ran as plain stream operations after four such attempts)"""
-        a, b = ctypes.c_size_t(), ctypes.c_size_t()
-        check(lib().hs_ed25519_ring_capture_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "hs_ed25519_ring_capture_stats")
         return a.value, b.value
 
     def close(self):

@@ -587,7 +587,6 @@ struct hs_ed25519_ring {
     bool use_graph = false;
     bool zero_copy = false;      // kernels read the pinned slot / write the pinned bitmap directly over PCIe
     size_t captures = 0, launches = 0;
-    size_t recaptures = 0, uncaptured = 0;      // captures another thread's runtime call invalidated: taken again / given up (that round ran as stream operations)
 };
 
 extern "C" void hs_ed25519_ring_destroy(hs_ed25519_ring *r) {
@@ -644,7 +643,6 @@ extern "C" int hs_ed25519_ring_begin(hs_ed25519_ring *r, unsigned slot, size_t n
     return 0;
 }
 
-static const int kCaptureTries = 4;
 static int ring_enqueue(hs_ed25519_ring *r, ring_slot &s, uint32_t mode) {
     hs_ed25519_ctx *c = s.ctx;
     // zero-copy: hipHostMalloc memory is mapped into the device's address space, so the kernels can
@@ -685,58 +683,37 @@ extern "C" int hs_ed25519_ring_submit(hs_ed25519_ring *r, unsigned slot, uint32_
         int rc = ring_enqueue(r, s, mode);
         if (rc) return rc;
     } else {
-        bool as_stream_ops = false;
         if (!s.exec || s.g_n != s.n || s.g_stride != s.stride || s.g_mode != mode) {
-            // Thread-local capture: this thread's own calls are recorded, other threads' are not.  It does not make the capture
-            // immune to them: on ROCm 7 a device-wide synchronisation issued by ANY thread (hipDeviceSynchronize; the engine has
-            // none after init, the host program may) marks every capturing stream invalidated, and each recorded call after that
-            // - or hipStreamEndCapture - fails with hipErrorStreamCaptureInvalidated (tools/capture_probe.hip measures which
-            // calls do it).  An invalidated capture recorded nothing and left the stream idle, so it is simply taken again; after
-            // kCaptureTries the round runs as plain stream operations - same kernels, same verdict - and the next round tries anew.
+            // Thread-local capture: calls of other threads are not recorded and the "unsafe" ones (allocation, stream and event
+            // creation, work on their own streams) leave it alone.  NOT every call does, on ROCm 7.0: a hipDeviceSynchronize or a
+            // legacy-stream hipMemcpy / hipMemset issued by any thread while this capture is open invalidates it ("operation
+            // failed due to a previous error during capture") or crashes inside the runtime - tools/capture_probe.hip,
+            // profiles/r5_h_capture_probe.json.  The engine issues neither after hs_ed25519_init (round 5: key-set registration
+            // left the legacy stream, hs_ed25519_keyset_destroy lost its device-wide synchronisation); a host that does must not
+            // select the graph form (include/hs_ed25519.h; AUTO never does).
             hipGraph_t g = nullptr;
-            int rc = 0;
-            hipError_t e = hipSuccess;
-            for (int attempt = 0;; attempt++) {
-                g = nullptr;
-                HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-                rc = ring_enqueue(r, s, mode);
-                e = hipStreamEndCapture(st, &g);
-                if (!rc && e == hipSuccess) break;
-                if (g) { (void)hipGraphDestroy(g); g = nullptr; }
-                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                const bool idle = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-                (void)hipGetLastError();
-                // a refusal that is not the capture's (bad arguments, out of memory) is the caller's to see, at once
-                if (rc && rc != HS_ED25519_E_DEVICE) return rc;
-                if (!idle) return fail(HS_ED25519_E_DEVICE, "ring_submit: the slot's stream did not leave capture mode", e);
-                if (attempt + 1 < kCaptureTries) { r->recaptures++; continue; }
-                r->uncaptured++;
-                as_stream_ops = true;
-                break;
-            }
-            if (as_stream_ops) {
-                rc = ring_enqueue(r, s, mode);
-                if (rc) return rc;
-            } else {
-                if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
-                    hipGraphNode_t bad = nullptr;
-                    hipGraphExecUpdateResult res;
-                    if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
-                        (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
-                        (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
-                    }
+            HS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            int rc = ring_enqueue(r, s, mode);
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(HS_ED25519_E_DEVICE, "hipStreamEndCapture", e);
+            if (s.exec) {                       // same topology unless the kernel choice changed: try the in-place update
+                hipGraphNode_t bad = nullptr;
+                hipGraphExecUpdateResult res;
+                if (hipGraphExecUpdate(s.exec, g, &bad, &res) != hipSuccess) {
+                    (void)hipGetLastError();      // a refused update is handled here: do not leave it as the thread's sticky error
+                    (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
                 }
-                if (!s.exec) {
-                    e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
-                    if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
-                }
-                (void)hipGraphDestroy(g);
-                s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
-                r->captures++;
             }
+            if (!s.exec) {
+                e = hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0);
+                if (e != hipSuccess) { (void)hipGraphDestroy(g); s.exec = nullptr; return fail(HS_ED25519_E_DEVICE, "hipGraphInstantiate", e); }
+            }
+            (void)hipGraphDestroy(g);
+            s.g_n = s.n; s.g_stride = s.stride; s.g_mode = mode;
+            r->captures++;
         }
-        if (!as_stream_ops)
-            HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
+        HS_HIP(hipGraphLaunch(s.exec, st), "hipGraphLaunch");
     }
     r->launches++;
     s.inflight = true; s.begun = false;
@@ -773,10 +750,5 @@ extern "C" hs_ed25519_ctx *hs_ed25519_ring_slot_ctx(hs_ed25519_ring *r, unsigned
 extern "C" int hs_ed25519_ring_stats(const hs_ed25519_ring *r, size_t *graph_captures, size_t *launches) {
     if (!r || !graph_captures || !launches) return fail(HS_ED25519_E_ARG, "ring_stats: null");
     *graph_captures = r->captures; *launches = r->launches;
-    return 0;
-}
-extern "C" int hs_ed25519_ring_capture_stats(const hs_ed25519_ring *r, size_t *recaptures, size_t *uncaptured) {
-    if (!r || !recaptures || !uncaptured) return fail(HS_ED25519_E_ARG, "ring_capture_stats: null");
-    *recaptures = r->recaptures; *uncaptured = r->uncaptured;
     return 0;
 }

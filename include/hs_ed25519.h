@@ -152,7 +152,13 @@ int hs_ed25519_verify_device_tc_cached(hs_ed25519_ctx *ctx, const hs_ed25519_key
  *   digest_stride 0: `digests` holds one shared 32-byte digest; 32: one per signature.
  *   flags: how a round travels (all four have the same results):
  *     HS_ED25519_RING_GRAPH       H2D copy -> kernel(s) -> D2H copy as ONE hipGraph launch, captured
- *                                 once per slot and re-launched / updated in place
+ *                                 once per slot and re-launched / updated in place.  HOST RULE for this form
+ *                                 only (ROCm 7.0, tools/capture_probe.hip): while a round is being captured
+ *                                 no thread of the process may call hipDeviceSynchronize or a legacy-stream
+ *                                 hipMemcpy / hipMemset - the runtime invalidates the capture (submit then
+ *                                 returns HS_ED25519_E_DEVICE) or crashes.  The engine calls neither after
+ *                                 hs_ed25519_init; allocation, stream / event creation and work on other
+ *                                 streams are harmless.  It never won on gfx950 (profiles/r1_ring_sweep.md).
  *     HS_ED25519_RING_STREAM_OPS  the same three operations issued to the slot's stream one by one
  *     HS_ED25519_RING_ZERO_COPY   no copies: the kernels read the pinned slot and write the pinned
  *                                 bitmap directly over PCIe (every input byte is read exactly once)
@@ -179,12 +185,6 @@ int hs_ed25519_ring_poll(hs_ed25519_ring *ring, unsigned slot);
 int hs_ed25519_ring_wait(hs_ed25519_ring *ring, unsigned slot, uint8_t *bitmap);
 /* Number of graph captures / updates and of rounds submitted so far. */
 int hs_ed25519_ring_stats(const hs_ed25519_ring *ring, size_t *graph_captures, size_t *launches);
-/* HS_ED25519_RING_GRAPH only (ABI 5.1).  A capture is thread-local, yet on ROCm 7 a device-wide synchronisation issued by
- * any OTHER thread of the process (hipDeviceSynchronize; the engine issues none after init, the host program may)
- * invalidates it.  The ring takes an invalidated capture again (`recaptures`) and after four attempts runs that round
- * as plain stream operations (`uncaptured`) - same kernels, same verdict; the next round captures anew.  Both stay 0
- * in a host that never synchronises the whole device.  tools/capture_probe.hip lists the calls that do it. */
-int hs_ed25519_ring_capture_stats(const hs_ed25519_ring *ring, size_t *recaptures, size_t *uncaptured);
 /* The context a slot runs on - BORROWED: it dies with the ring, never destroy it, and use it only while the slot
  * has nothing in flight.  For the per-context knobs and read-outs (hs_ed25519_ctx_set_rlc_min,
  * hs_ed25519_ctx_rlc_last, hs_ed25519_ctx_set_concurrent, hs_ed25519_ctx_set_kernel).  NULL on bad arguments. */

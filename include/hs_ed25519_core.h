@@ -74,7 +74,7 @@ extern "C" {
  * verdict semantics bumps the major; additions bump the minor.  The shim compares hs_ed25519_abi_version() - what the
  * loaded libhs_ed25519.so was BUILT from - with this constant at load time and refuses a library whose major differs
  * (INTEGRATION.md section 2); tests/test_abi_and_host_logic.py holds the two equal. */
-#define HS_ED25519_ABI_VERSION 0x00050001u
+#define HS_ED25519_ABI_VERSION 0x00050000u
 uint32_t hs_ed25519_abi_version(void);
 
 #define HS_ED25519_BATCH 0u
@@ -133,7 +133,7 @@ int hs_ed25519_verify_tc(uint64_t round, const uint64_t *high_qc_rounds, const u
  * host-API work still in flight on it (tickets not collected, synchronous calls of other threads that have not returned,
  * round rings not destroyed) is counted, and destroy waits up to ten seconds for the count to drain before it frees the
  * tables; if it does not drain, the tables are LEAKED (never freed under a running kernel) and hs_ed25519_last_error says
- * so.  It does not synchronise the device (until ABI 5.0 it did: a device-wide synchronisation breaks a hipGraph capture
+ * so.  It does not synchronise the device (rounds 1-4 did: a device-wide synchronisation breaks a hipGraph capture
  * in progress on any other thread).  Calls through the device-pointer entry points on the caller's own streams
  * (hs_ed25519.h) are not counted: drain those streams first. */
 typedef struct hs_ed25519_keyset hs_ed25519_keyset;

@@ -325,3 +325,31 @@ int main(void) {
     assert int(lines["min"]) >= 1
     if not torch.cuda.is_available():
         assert int(lines["verify"]) < 0 and lines["error"].strip(), lines       # not initialised / no device: an error, with a message
+
+
+def test_nothing_after_init_synchronises_the_device_or_uses_the_legacy_stream():
+    """On ROCm 7.0 a hipDeviceSynchronize or a legacy-stream hipMemcpy / hipMemset from ANY thread invalidates a hipGraph capture
+    in progress on another thread - or crashes inside the runtime (tools/capture_probe.hip, profiles/r5_h_capture_probe.json) -
+    and a node registers and drops committees while its rounds stream through a graph-mode ring (tests/test_gpu_ring.py).  Round 5
+    found two such calls by running into them (key-set registration on the legacy stream; a device-wide synchronisation in
+    hs_ed25519_keyset_destroy); this pins the rule on the sources: the only such calls of the product are in hs_ed25519.hip
+    between build_base_tables and the end of hs_ed25519_init_devices."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hotstuff_amd", "csrc")
+    pat = re.compile(r"\b(hipDeviceSynchronize|hipMemcpy|hipMemset|hipMemcpyToSymbol|hipMemcpyFromSymbol|hipMemcpyDtoH|hipMemcpyHtoD|hipMemcpyDtoD)\s*\(")
+    found = []
+    for name in sorted(os.listdir(root)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(root, name)).read()
+        lo = hi = -1
+        if name == "hs_ed25519.hip":
+            lo = text.index("static int build_base_tables(dev_state &d) {")
+            hi = text.index("g_init.store(true);", lo)
+        for m in pat.finditer(text):
+            line_start = text.rfind("\n", 0, m.start()) + 1
+            if text[line_start:m.start()].lstrip().startswith("//") or "//" in text[line_start:m.start()]:
+                continue        # prose
+            if lo <= m.start() < hi:
+                continue        # initialisation: no ring exists yet
+            found.append("%s:%d %s" % (name, text.count("\n", 0, m.start()) + 1, m.group(1)))
+    assert not found, found

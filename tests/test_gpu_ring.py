@@ -231,7 +231,9 @@ def test_key_sets_are_registered_while_a_ring_captures_its_graphs(oracle):
     """A node registers the next epoch's committee while rounds stream.  A legacy-stream operation is an error
     (hipErrorStreamCaptureImplicit) while ANOTHER thread captures a hipGraph; until round 5 key-set registration ran on the legacy
     stream, and the thread-sanitizer run of the stress client caught it failing twice in 48,000 calls
-    (profiles/r5_t_sanitizer_runs.txt).  One thread drives a graph-mode ring whose every round has another size (a capture or an
+    (profiles/r5_t_sanitizer_runs.txt).  A second such call survived that fix - hs_ed25519_keyset_destroy synchronised the whole device,
+    which invalidates a capture in progress (or crashes the runtime: tools/capture_probe.hip) - and failed this test in one run of two
+    until it went (the set now waits for its own uncollected work instead).  One thread drives a graph-mode ring whose every round has another size (a capture or an
     update each time), another registers and drops key sets and reads an RLC stage's flags; nothing may fail and every verdict
     equals the oracle's."""
     import threading
@@ -281,44 +283,3 @@ def test_key_sets_are_registered_while_a_ring_captures_its_graphs(oracle):
     assert not any(t.is_alive() for t in ts), "a thread is stuck"
     assert not errors, errors[:4]
 
-
-def test_a_host_thread_that_synchronises_the_device_does_not_fail_a_graph_ring(oracle):
-    """The engine issues no device-wide synchronisation after init (round 5: hs_ed25519_keyset_destroy had one, and the test above
-    failed in one run of two with hipErrorStreamCaptureInvalidated) - but the HOST program is free to, and on ROCm 7 a
-    hipDeviceSynchronize from any thread invalidates every capture in progress, thread-local or not (tools/capture_probe.hip,
-    profiles/r5_g_capture_probe.json).  The ring takes such a capture again and, after four attempts, runs the round as stream
-    operations; here another thread synchronises the device in a tight loop: every round still returns the oracle's bitmap."""
-    import ctypes
-    import threading
-    hip = ctypes.CDLL("libamdhip64.so")
-    n = 4096
-    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
-    dgc, pkc, sgc, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=16)
-    expect = oracle_verify_many(oracle, dgc, 0, pkc, sgc, n, 0)
-    stop = threading.Event()
-    syncs = [0]
-
-    def host_syncs():
-        while not stop.is_set():
-            hip.hipDeviceSynchronize()      # fails with hipErrorStreamCaptureUnsupported when it lands in a capture: the host's to handle
-            syncs[0] += 1
-
-    t = threading.Thread(target=host_syncs)
-    t.start()
-    try:
-        ring = _lib.RoundRing(n, slots=2, kind="graph")
-        for r in range(120):
-            m = 64 * (1 + (r * 7) % 63)
-            fill(ring, r % 2, dgc, pkc[: 32 * m], sgc[: 64 * m], m, True)
-            ring.submit(r % 2, _lib.BATCH)
-            ok, bm = ring.wait(r % 2)
-            assert bits(bm, m) == expect[:m], "round %d of %d signatures" % (r, m)
-        recaptures, uncaptured = ring.capture_stats()
-        captures, launches = ring.stats()
-        assert launches == 120 and captures + uncaptured == 120
-        print("device synchronisations by the host thread: %d; captures taken again: %d; rounds as stream operations: %d"
-              % (syncs[0], recaptures, uncaptured))
-        ring.close()
-    finally:
-        stop.set()
-        t.join(30)

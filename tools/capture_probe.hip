@@ -10,6 +10,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -o tools/capture_probe tools/capture_probe.hip -lpthread ; tools/capture_probe [ms]
 #include <hip/hip_runtime.h>
+#include <sys/wait.h>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -46,7 +47,24 @@ struct capture_side {
         e = hipStreamEndCapture(st, &g);
         if (first != hipSuccess || e != hipSuccess) {
             if (first != hipSuccess) note(where, first); else note("end", e);
+            if (first != hipSuccess) note("end after a failed step", e);
             if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            // what state is the stream left in, and what brings it back?
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            hipError_t q = hipStreamIsCapturing(st, &cs);
+            why[std::string("after: hipStreamIsCapturing -> ") + hipGetErrorName(q) + " status " + std::to_string((int)cs)]++;
+            (void)hipGetLastError();
+            if (q != hipSuccess || cs != hipStreamCaptureStatusNone) {
+                hipGraph_t g2 = nullptr;
+                q = hipStreamEndCapture(st, &g2);
+                if (g2) (void)hipGraphDestroy(g2);
+                hipError_t q2 = hipStreamIsCapturing(st, &cs);
+                why[std::string("second hipStreamEndCapture -> ") + hipGetErrorName(q) + ", then status " + hipGetErrorName(q2) + " " + std::to_string((int)cs)]++;
+                (void)hipGetLastError();
+            }
+            q = hipStreamSynchronize(st);
+            why[std::string("hipStreamSynchronize after the failure -> ") + hipGetErrorName(q)]++;
             (void)hipGetLastError();
             return false;
         }
@@ -66,6 +84,7 @@ struct other_side { hipStream_t st; void *d; void *h; };
 
 static hipError_t op_none(void *) { std::this_thread::yield(); return hipSuccess; }
 static hipError_t op_device_sync(void *) { return hipDeviceSynchronize(); }
+static hipError_t op_device_sync_slow(void *) { std::this_thread::sleep_for(std::chrono::milliseconds(2)); return hipDeviceSynchronize(); }
 static hipError_t op_malloc_free(void *) { void *p = nullptr; hipError_t e = hipMalloc(&p, 1 << 20); if (e == hipSuccess) e = hipFree(p); return e; }
 static hipError_t op_host_malloc_free(void *) { void *p = nullptr; hipError_t e = hipHostMalloc(&p, 1 << 16, hipHostMallocPortable | hipHostMallocMapped); if (e == hipSuccess) e = hipHostFree(p); return e; }
 static hipError_t op_stream_create_destroy(void *) { hipStream_t s; hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e == hipSuccess) e = hipStreamDestroy(s); return e; }
@@ -93,8 +112,7 @@ static hipError_t op_memcpy_to_symbol_async(void *p) {
     return e;
 }
 
-int main(int argc, char **argv) {
-    const int ms = argc > 1 ? atoi(argv[1]) : 1500;
+static int run_candidate(const candidate &c, int ms, bool firstc) {
     if (hipSetDevice(0) != hipSuccess) { fprintf(stderr, "no device\n"); return 2; }
     capture_side A; other_side B;
     const unsigned n = 1 << 16;
@@ -103,43 +121,58 @@ int main(int argc, char **argv) {
     memset(A.h, 1, 4 * n);
     if (hipStreamCreateWithFlags(&B.st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&B.d, 1 << 16) != hipSuccess ||
         hipHostMalloc(&B.h, 1 << 16, hipHostMallocPortable) != hipSuccess) return 2;
+    std::atomic<bool> stop{false};
+    size_t calls = 0; std::map<std::string, size_t> berr;
+    std::thread tb([&] {
+        (void)hipSetDevice(0);
+        while (!stop.load(std::memory_order_relaxed)) {
+            const hipError_t e = c.op(&B);
+            calls++;
+            if (e != hipSuccess) { berr[hipGetErrorName(e)]++; (void)hipGetLastError(); }
+        }
+    });
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned r = 0;
+    while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < ms) {
+        if (A.round(64 * (1 + (r * 7) % 1023))) A.ok++; else A.failed++;
+        r++;
+    }
+    stop.store(true); tb.join();
+    printf("%s {\"other_thread\": \"%s\", \"its_calls\": %zu, \"its_errors\": {", firstc ? " " : ",", c.name, calls);
+    bool f = true; for (auto &kv : berr) { printf("%s\"%s\": %zu", f ? "" : ", ", kv.first.c_str(), kv.second); f = false; }
+    printf("}, \"captures_ok\": %zu, \"captures_failed\": %zu, \"failures\": {", A.ok, A.failed);
+    f = true; for (auto &kv : A.why) { printf("%s\"%s\": %zu", f ? "" : ", ", kv.first.c_str(), kv.second); f = false; }
+    printf("}}\n"); fflush(stdout);
+    return 0;
+}
+
+// capture_probe [ms]            every candidate, each in a process of its own (a call that crashes the runtime is a result)
+// capture_probe ms index first  one candidate (what the parent runs)
+int main(int argc, char **argv) {
+    const int ms = argc > 1 ? atoi(argv[1]) : 1500;
     const candidate cands[] = {
-        {"nothing (control)", op_none}, {"hipDeviceSynchronize", op_device_sync}, {"hipMalloc + hipFree", op_malloc_free},
+        {"nothing (control)", op_none}, {"hipMalloc + hipFree", op_malloc_free},
         {"hipHostMalloc + hipHostFree", op_host_malloc_free}, {"hipStreamCreate + Destroy", op_stream_create_destroy},
         {"hipEventCreate + Destroy", op_event_create_destroy}, {"hipMemcpy (legacy stream)", op_memcpy_legacy},
         {"hipMemset (legacy stream)", op_memset_legacy}, {"hipStreamSynchronize(NULL)", op_stream_sync_legacy},
         {"async copy + kernel + sync on its own stream", op_async_own_stream}, {"hipStreamQuery (own stream)", op_stream_query_own},
         {"hipSetDevice", op_set_device}, {"hipMemGetInfo", op_mem_get_info}, {"hipMemcpyToSymbolAsync (own stream)", op_memcpy_to_symbol_async},
+        {"hipDeviceSynchronize every 2 ms", op_device_sync_slow}, {"hipDeviceSynchronize", op_device_sync},
     };
+    const int ncand = (int)(sizeof cands / sizeof cands[0]);
+    if (argc > 3) { const int i = atoi(argv[2]); return i >= 0 && i < ncand ? run_candidate(cands[i], ms, atoi(argv[3]) != 0) : 2; }
     int version = 0; (void)hipRuntimeGetVersion(&version);
     printf("{\"hip_runtime_version\": %d, \"ms_per_candidate\": %d, \"capture_mode\": \"hipStreamCaptureModeThreadLocal\", \"candidates\": [\n", version, ms);
-    bool firstc = true;
-    for (const candidate &c : cands) {
-        A.ok = A.failed = 0; A.why.clear();
-        std::atomic<bool> stop{false};
-        size_t calls = 0; std::map<std::string, size_t> berr;
-        std::thread tb([&] {
-            (void)hipSetDevice(0);
-            while (!stop.load(std::memory_order_relaxed)) {
-                const hipError_t e = c.op(&B);
-                calls++;
-                if (e != hipSuccess) { berr[hipGetErrorName(e)]++; (void)hipGetLastError(); }
-            }
-        });
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned r = 0;
-        while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < ms) {
-            if (A.round(64 * (1 + (r * 7) % 1023))) A.ok++; else A.failed++;
-            r++;
+    fflush(stdout);
+    for (int i = 0; i < ncand; i++) {
+        char cmd[512];
+        snprintf(cmd, sizeof cmd, "%s %d %d %d", argv[0], ms, i, i == 0);
+        const int rc = system(cmd);
+        if (rc != 0) {
+            printf("%s {\"other_thread\": \"%s\", \"process\": \"died: wait status %d (a crash inside the HIP runtime)\", \"its_calls\": 0, \"its_errors\": {}, "
+                   "\"captures_ok\": 0, \"captures_failed\": 0, \"failures\": {}}\n", i ? "," : " ", cands[i].name, rc);
+            fflush(stdout);
         }
-        stop.store(true); tb.join();
-        (void)hipDeviceSynchronize(); (void)hipGetLastError();
-        printf("%s {\"other_thread\": \"%s\", \"its_calls\": %zu, \"its_errors\": {", firstc ? " " : ",", c.name, calls);
-        bool f = true; for (auto &kv : berr) { printf("%s\"%s\": %zu", f ? "" : ", ", kv.first.c_str(), kv.second); f = false; }
-        printf("}, \"captures_ok\": %zu, \"captures_failed\": %zu, \"failures\": {", A.ok, A.failed);
-        f = true; for (auto &kv : A.why) { printf("%s\"%s\": %zu", f ? "" : ", ", kv.first.c_str(), kv.second); f = false; }
-        printf("}}\n"); fflush(stdout);
-        firstc = false;
     }
     printf("]}\n");
     return 0;
