@@ -90,3 +90,25 @@ def test_one_pass_labeller_equals_the_oracles_two_entry_points(chunk):
     l, c, _ = chunk
     rng = np.random.default_rng(3)
     assert craft.check_labels_against_the_oracle(l, c, rng, 520, 4) == 0
+
+
+def test_labels_equal_libsodium_group_arithmetic(chunk):
+    """The same labels against arithmetic this project did not write (tests/referees.py: dalek's point laws over libsodium's
+    crypto_core_ed25519_add, lenient decoding included): the 10^7-tuple differential's ground truth is then pinned by the
+    big-integer reference AND by an independent implementation, class by class - torsion on A / R, pure-torsion keys,
+    alternative encodings, every s mutation, byte flips."""
+    import referees
+    if referees._sodium_group() is None:
+        pytest.skip("no libsodium with the ed25519 core API in this image")
+    _, c, _ = chunk
+    bad, per_class = [], {}
+    for i in range(len(c["cls"])):
+        msg, pk, sig = bytes(c["msgs"][i]), bytes(c["pk"][i]), bytes(c["sig"][i])
+        laws = referees.sodium_point_laws(msg, pk, sig)
+        want = (1 if laws["cofactorless"] else 0) | (2 if laws["strict"] else 0)
+        name = craft.CLASSES[c["cls"][i]]
+        per_class[name] = per_class.get(name, 0) + 1
+        if want != int(c["expect"][i]):
+            bad.append((i, name, want, int(c["expect"][i])))
+    assert not bad, bad[:5]
+    assert len(per_class) == len(craft.CLASSES) and min(per_class.values()) >= 2, per_class
