@@ -44,6 +44,7 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
     const size_t o_seed = 0, o_key = o_seed + 32 * kTuneKeys, o_sec = o_key + 32 * kTuneKeys, o_dg = o_sec + 64 * np, o_pk = o_dg + 64,
                  o_sig = o_pk + 32 * np, o_bm = o_sig + 64 * np, o_nr = o_bm + bitmap_bytes(np), total = o_nr + 16;
     std::vector<uint8_t> h(o_pk + 32 * np, 0), bm(bitmap_bytes(np));      // host mirrors: declared before the guard, whose destructor drains the stream that may still read them
+    uint32_t nrej = 1;                                                      // (the reject counter's mirror too: an asynchronous copy targets it)
     hs_ed25519_ctx *c = nullptr;
     int rc = pool_get(&c, slot, n);              // a wide pool context: no stream of our own (see above)
     if (rc) return rc;
@@ -105,7 +106,7 @@ int hs::autotune_slot(int slot, double ms_out[2]) {
                 if (run > 0 && vm > 0 && vm < best[f]) best[f] = vm;
             }
             // a form that does not accept the canned valid batch is an engine error, never a pick
-            uint32_t nrej = 1;
+            nrej = 1;
             HS_HIP(hipMemcpyAsync(&nrej, d + o_nr, 4, hipMemcpyDeviceToHost, st), "autotune: D2H reject counter");      // never the legacy stream
             HS_HIP(hipMemcpyAsync(bm.data(), d + o_bm, bm.size(), hipMemcpyDeviceToHost, st), "autotune: D2H bitmap");
             HS_HIP(hipStreamSynchronize(st), "autotune: D2H verdicts");
