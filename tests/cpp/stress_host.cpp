@@ -198,7 +198,24 @@ static void keyset_worker(const dataset &d) {
         };
         std::thread a(user, 0u), b(user, 1u);
         a.join(); b.join();
+        // epoch change: the set is destroyed while a ticket on it is still out; another thread collects it a little later.
+        // Destroy waits for the host API's uncollected work on the set (no device-wide synchronisation - that would break
+        // the ring worker's graph captures), so the late verdict is still the right one.
+        const size_t n = 1 + splitmix(s) % 1200, l = splitmix(s) % (nk - n);
+        std::vector<uint32_t> idx(n);
+        for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)(l + i);
+        hs_ed25519_ticket *t = nullptr;
+        const int rc = hs_ed25519_submit(&t, ks, d.shared_dg, 0, idx.data(), &d.sg_shared[64 * (base + l)], n, HS_ED25519_BATCH, 0);
+        if (rc != 0 && rc != HS_ED25519_E_BUSY) REQUIRE(false, "cached submit before destroy");
+        std::thread late([&, t] {
+            if (!t) return;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            std::vector<uint8_t> bm(256, 0);
+            const int v = hs_ed25519_ticket_wait(t, bm.data());
+            check(d, base + l, n, v, bm.data(), "ticket collected during keyset_destroy");
+        });
         hs_ed25519_keyset_destroy(ks);
+        late.join();
     }
 }
 static void sharded_worker(const dataset &d) {
