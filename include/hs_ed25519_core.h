@@ -59,6 +59,12 @@
  * Thread safety: every function may be called concurrently from any thread
  * (the reference's tests call verify from several threads of one process,
  * SURVEY.md 8b); calls are served from an internal pool of stream contexts.
+ *
+ * HIP state a call touches: it makes the engine's GPU the calling thread's CURRENT HIP device (hipSetDevice) and leaves
+ * it so - a host that drives other GPUs through HIP itself calls hipSetDevice again afterwards; the reference does not
+ * use HIP at all.  Nothing else of the thread's or the process's HIP state is changed: no device-wide synchronisation
+ * and no legacy-stream operation after hs_ed25519_init (both break stream captures of other threads on ROCm 7.0,
+ * include/hs_ed25519.h, rings), no environment variable written, no device flags set.
  */
 #ifndef HS_ED25519_CORE_H
 #define HS_ED25519_CORE_H
