@@ -1085,18 +1085,28 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     std::vector<dev_state> devs(count);
     for (size_t i = 0; i < count; i++) {
         devs[i].ordinal = ordinals[i];
-        HS_HIP(hipSetDevice(ordinals[i]), "hipSetDevice");
+        // a failure on any device gives back what the earlier ones had built (67 MB each): init either succeeds as a whole or leaves nothing
+        hipError_t e = hipSetDevice(ordinals[i]);
+        const char *what = "hipSetDevice";
+        int rc = 0;
         // the base point's window tables (8-bit: key-cache layout, also the RLC path's; 16-bit: every verify kernel's [s]B)
-        int rc = build_base_tables(devs[i]);
+        if (e == hipSuccess) rc = build_base_tables(devs[i]);
+        if (e == hipSuccess && !rc) {
+            const u32 *b16 = devs[i].base_tab16;
+            what = "set the base-point table pointer";
+            e = hipMemcpyToSymbol(HIP_SYMBOL(g_b16), &b16, sizeof b16);
+            if (e == hipSuccess) { what = "hipDeviceSynchronize"; e = hipDeviceSynchronize(); }
+            hipDeviceProp_t prop;
+            if (e == hipSuccess) { what = "hipGetDeviceProperties"; e = hipGetDeviceProperties(&prop, ordinals[i]); }
+            if (e == hipSuccess) devs[i].cus = (unsigned)prop.multiProcessorCount;
+        }
+        if (e != hipSuccess && !rc) rc = fail(HS_ED25519_E_DEVICE, what, e);
         if (rc) { for (size_t k = 0; k <= i; k++) free_base_tables(devs[k]); return rc; }
-        const u32 *b16 = devs[i].base_tab16;
-        HS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_b16), &b16, sizeof b16), "set the base-point table pointer");
-        HS_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
-        hipDeviceProp_t prop;
-        HS_HIP(hipGetDeviceProperties(&prop, ordinals[i]), "hipGetDeviceProperties");
-        devs[i].cus = (unsigned)prop.multiProcessorCount;
     }
-    HS_HIP(hipSetDevice(ordinals[0]), "hipSetDevice");
+    if (const hipError_t e = hipSetDevice(ordinals[0]); e != hipSuccess) {
+        for (dev_state &d : devs) free_base_tables(d);
+        return fail(HS_ED25519_E_DEVICE, "hipSetDevice", e);
+    }
     for (int i = 0; i < kMaxSlots; i++) g_oct_pick[i].store(-1, std::memory_order_relaxed);
     g_devs.swap(devs);
     g_max_batch.store(max_batch ? max_batch : 1024);
