@@ -375,3 +375,21 @@ def test_the_plain_makefile_builds_what_build_engine_builds():
     assert r.returncode == 0, r.stderr
     for u in units:
         assert "-c %s.hip" % u in r.stdout
+
+
+def test_tools_only_use_what_the_binding_and_the_library_have():
+    """tools/*.py are the scripts profiles/ names as its sources; one that names a binding attribute or an entry point that no
+    longer exists cannot reproduce its file (round 5 found one such script, from round 1).  Static: every `_lib.X` is an
+    attribute of hotstuff_amd/_lib.py, every `hs_ed25519_*` word a symbol of the library (or a prose prefix ending in `_`)."""
+    tools = os.path.join(ROOT, "tools")
+    nm = {l.split()[-1] for l in __import__("subprocess").run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                                                                 text=True, check=True).stdout.splitlines() if l.strip()}
+    bad = []
+    for f in sorted(os.listdir(tools)):
+        if not f.endswith(".py"):
+            continue
+        s = open(os.path.join(tools, f)).read()
+        bad += ["%s: _lib.%s" % (f, m.group(1)) for m in re.finditer(r"\b_lib\.([A-Za-z_][A-Za-z0-9_]*)", s) if not hasattr(_lib, m.group(1))]
+        bad += ["%s: %s" % (f, m.group(1)) for m in re.finditer(r"\b(hs_ed25519_[a-z0-9_]*[a-z0-9])\b(?!_)", s)
+                if m.group(1) not in nm and not m.group(1).startswith(("hs_ed25519_core", "hs_ed25519_h"))]
+    assert not bad, sorted(set(bad))
