@@ -6,13 +6,13 @@
 Workload = BASELINE.json configs[1]: batches of 1,024 distinct (digest, pk, sig) tuples, one digest per
 tuple, strict semantics (the TC::verify / Signature::verify predicate, consensus/src/messages.rs:307-313),
 inputs resident in HBM.  A "step" is one pass of the hot path over a synthetic input set of
-`--batches-per-step` (default 1,024) such batches = 1,048,576 verifications: 1,024 independent
-hs_ed25519_verify_device calls (k_verify_fused at this batch size) issued round-robin over 16 stream
-contexts, each context restricted to its own slice of the CUs and holding its own distinct batch -
-the way a node under load issues independent certificates.  With the driver's `--steps 20 --warmup 5`
-the timed region is 20,480 launches / ~0.6 s, i.e. steady state whatever `steps` is (round 1 timed
-single launches, so 20 steps were 1.2 ms and the number depended on steps mod streams).  The timed
-region is bracketed by a barrier and a device synchronize on both sides; the maximum over ranks is taken.
+`--batches-per-step` (default 1,024) such batches = 1,048,576 verifications, EVERY TUPLE OF THE STEP DISTINCT
+(`--distinct-batches`; rounds 1 - 4 re-verified sixteen batches - the rate is the same, profiles/r5_n_distinct_batches.txt):
+64 hs_ed25519_verify_device_batches calls of sixteen batches each (k_prepare_batches + k_verify_batches) issued
+round-robin over 16 stream contexts, each context restricted to its own slice of the CUs - the way a node under load
+issues independent certificates.  With the driver's `--steps 20 --warmup 5` the timed region is 1,280 launch pairs /
+~0.2 s, steady state whatever `steps` is.  The timed region is bracketed by a barrier and a device synchronize on both
+sides; the maximum over ranks is taken.
 
 `value` is the HBM-resident rate the contract asks for.  `end_to_end` (same JSON line) is SURVEY.md
 8d's metric proper - host buffers in, host verdict out through the host-pointer C ABI
@@ -941,6 +941,11 @@ def main():
                          "several times the latency; wants --batches-per-launch 16 --partitions 0)")
     ap.add_argument("--shared", action="store_true", help="QC::verify shape (one digest, batch semantics)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HS_BENCH_STREAMS", "16")))
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="distinct synthetic batches per GPU.  Default (0): as many as a step has batches - every tuple of a step is "
+                         "distinct (1,048,576 per GPU), so no launch meets inputs or table lines a recent launch left in the caches.  "
+                         "16 = rounds 1 - 4's set (one batch per stream context, re-verified); the rate is the same either way "
+                         "(profiles/r5_n_distinct_batches.txt)")
     ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "4")),
                     help="batches per hs_ed25519_verify_device_batches_cached launch in the committee_cached extra")
     ap.add_argument("--no-cpu", action="store_true")
@@ -1032,8 +1037,8 @@ def main():
     stride = 0 if shared else 32
     B = max(1, args.batches_per_step)
     ns = max(1, min(args.streams, B))
-    # one distinct synthetic batch per stream context (ns x 1,024 distinct tuples per GPU).  Rank 0's are OpenSSL-signed
-    # fixtures (cached on disk, independent of the engine under test); the other ranks sign theirs on their GPU
+    # D distinct synthetic batches per GPU (default: a whole step's worth).  Rank 0's first ns - one per stream context, also what
+    # the extras use - are OpenSSL-signed fixtures (cached on disk, independent of the engine under test); every other batch is signed on the GPU
     # (hs_ed25519_sign_batch, bit-identical to OpenSSL by tests/test_gpu_wire_and_sign.py) - milliseconds instead of the
     # ~10 s of host signing per rank, which would otherwise stagger the ranks' arrival at the first barrier
     def gpu_signed_batch(first):
@@ -1042,13 +1047,15 @@ def main():
         dgs = synth.shared_digest(1) if shared else b"".join(synth.msg_digest(first + i) for i in range(n))
         sgs = _lib.sign_batch(b"".join(seeds[32 * i:32 * i + 32] + pks[32 * i:32 * i + 32] for i in range(n)), dgs, n, shared=shared)
         return dgs, pks, sgs
+    D = max(ns, args.distinct_batches if args.distinct_batches > 0 else min(B, 4096))       # distinct batches per GPU; the first ns are the stream contexts' own
     if rank == 0:
         batches = [synth.make_batch(n, shared=shared, first=j * n, cache_dir="/tmp/hs_synth") for j in range(ns)]
     else:
         batches = [gpu_signed_batch((rank * ns + j) * n) for j in range(ns)]
+    more = [gpu_signed_batch((world * ns + rank * (D - ns) + j) * n) for j in range(D - ns)]      # `batches` stays the contexts' own (the extras below use it)
     dg, pk, sg = batches[0]
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    d_in = [tuple(t(x) for x in bt) for bt in batches]
+    d_in = [tuple(t(x) for x in bt) for bt in batches + more]
     ctxs = None
     if args.partitions:
         try:
@@ -1076,20 +1083,28 @@ def main():
     p_st = [s.cuda_stream for s in streams]
     # context j verifies K independent batches per launch: its own tuples and its neighbours' (K distinct batches,
     # each with its own bitmap and reject counter)
-    lists = [_lib.batch_array([(p_in[(j + k) % ns][0], stride, p_in[(j + k) % ns][1], p_in[(j + k) % ns][2], n, mode,
-                                p_bm[j * K + k], p_nr[j * K + k]) for k in range(K)]) for j in range(ns)]
+    # (with --distinct-batches D > streams: context j's v-th launch takes batches v*K + j ... v*K + j + K - 1 of the D, so a batch
+    # comes round again only after D / K launches of that context)
+    V = max(1, D // K) if D > ns else 1
+    lists = [[_lib.batch_array([(p_in[(v * K + j + k) % D][0], stride, p_in[(v * K + j + k) % D][1], p_in[(v * K + j + k) % D][2], n, mode,
+                                 p_bm[j * K + k], p_nr[j * K + k]) for k in range(K)]) for v in range(V)] for j in range(ns)]
     if K == 1:
         fn = _lib.lib().hs_ed25519_verify_device
         calls = [(ctxs[j]._h, p_in[j][0], stride, p_in[j][1], p_in[j][2], n, mode, p_bm[j], p_nr[j], p_st[j]) for j in range(ns)]
     else:
         fn = _lib.lib().hs_ed25519_verify_device_batches
-        calls = [(ctxs[j]._h, ctypes.cast(lists[j], ctypes.c_void_p), K, p_st[j]) for j in range(ns)]
+        calls = [[(ctxs[j]._h, ctypes.cast(lists[j][v], ctypes.c_void_p), K, p_st[j]) for v in range(V)] for j in range(ns)]
     launches_per_step = B // K
+    seq = [0]
 
     def step(i):
         """one pass over the step's input set: B independent 1,024-tuple batches, K per launch, round-robin over the contexts"""
         for b in range(launches_per_step):
-            if fn(*calls[b % ns]) != 0:
+            c = calls[b % ns]
+            if K > 1:
+                c = c[(seq[0] // ns) % V]
+                seq[0] += 1
+            if fn(*c) != 0:
                 raise RuntimeError("verify launch failed: " + _lib.last_error())
 
     def fence():
@@ -1311,7 +1326,7 @@ def main():
                              if shared else
                              "BASELINE configs[1]: %d-tuple (digest,pk,sig) batches, strict, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)),
                 "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
-                "distinct_tuples_per_gpu": ns * n, "streams": ns, "cu_partitions": args.partitions,
+                "distinct_tuples_per_gpu": (D if K > 1 else ns) * n, "streams": ns, "cu_partitions": args.partitions,
                 "timed_region_s": round(elapsed, 4), "batches_per_launch": K, "launches_in_timed_region_per_gpu": launches_per_step * args.steps,
                 "entry_point": "hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device",
                 "exchange": "none on this workload (independent batches per rank, SURVEY 8e); sharded_committee / sharded_c_abi have it" if exchange else "none (1 GPU)",
