@@ -948,6 +948,8 @@ def main():
                          "(profiles/r5_n_distinct_batches.txt)")
     ap.add_argument("--cached-batches-per-launch", type=int, default=int(os.environ.get("HS_BENCH_CBPL", "4")),
                     help="batches per hs_ed25519_verify_device_batches_cached launch in the committee_cached extra")
+    ap.add_argument("--cached-variants", type=int, default=16,
+                    help="committee_cached extra: distinct message sets per batch of signers (1 = the same certificates re-verified)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
     ap.add_argument("--no-cached", action="store_true", help="skip the committee-key-cache extra")
@@ -1166,18 +1168,36 @@ def main():
         # context j verifies KC independent batches per launch (its own and its neighbours'), each with its own bitmap
         c_bm = [torch.zeros(bm_bytes, dtype=torch.uint8, device=dev) for _ in range(ns * KC)]
         c_nr = torch.zeros(ns * KC, dtype=torch.int32, device=dev)
-        clists = [_lib.batch_array([(p_in[(j + k) % ns][0], stride, d_ki[((j + k) % ns) * n:].data_ptr(), p_in[(j + k) % ns][2], n, mode,
-                                     c_bm[j * KC + k].data_ptr(), c_nr[j * KC + k:].data_ptr()) for k in range(KC)]) for j in range(ns)]
+        # The committee's keys are fixed, its certificates are not: variant v of batch j = the same n signers over OTHER messages,
+        # re-signed on the GPU - other hashes, other windows, other lines of the 8.7 GB of key tables in every launch (a repeated
+        # batch would find its 25 MB of lines per launch in the last-level cache: VC = 1 is that regime, for comparison)
+        VC = max(1, args.cached_variants)
+        first_of = lambda j: ((0 if rank == 0 else rank * ns) + j) * n          # key_seed index of batch j's first signer (as `batches` was built)
+        var = [[(p_in[j][0], p_in[j][2])] for j in range(ns)]                   # [batch][variant] -> (digests ptr, sigs ptr); variant 0 = the fixture
+        keep = []
+        for j in range(ns):
+            seeds = b"".join(synth.key_seed(first_of(j) + i) for i in range(n))
+            secrets = b"".join(seeds[32 * i:32 * i + 32] + batches[j][1][32 * i:32 * i + 32] for i in range(n))
+            for v in range(1, VC):
+                dgs = synth.shared_digest(1000 + v) if shared else b"".join(synth.msg_digest(900_000_000 + (v * ns + j) * n + i) for i in range(n))
+                sgs = _lib.sign_batch(secrets, dgs, n, shared=shared)
+                t_d, t_s = t(dgs), t(sgs)
+                keep.append((t_d, t_s))
+                var[j].append((t_d.data_ptr(), t_s.data_ptr()))
+        clists = [[_lib.batch_array([(var[(j + k) % ns][v][0], stride, d_ki[((j + k) % ns) * n:].data_ptr(), var[(j + k) % ns][v][1], n, mode,
+                                      c_bm[j * KC + k].data_ptr(), c_nr[j * KC + k:].data_ptr()) for k in range(KC)]) for v in range(VC)] for j in range(ns)]
         cfn = _lib.lib().hs_ed25519_verify_device_batches_cached
-        ccalls = [(ctxs[j]._h, ks.handle, ctypes.cast(clists[j], ctypes.c_void_p), KC, p_st[j]) for j in range(ns)]
+        ccalls = [[(ctxs[j]._h, ks.handle, ctypes.cast(clists[j][v], ctypes.c_void_p), KC, p_st[j]) for v in range(VC)] for j in range(ns)]
+        cseq = [0]
         claunches = (B + KC - 1) // KC
         for c in ctxs:
             c.set_profiling(max(1, (args.steps * claunches + ns - 1) // ns // args.event_stride + 1), every=args.event_stride)
 
         def cstep(i):
             for b in range(claunches):
-                if cfn(*ccalls[b % ns]) != 0:
+                if cfn(*ccalls[b % ns][(cseq[0] // ns) % VC]) != 0:
                     raise RuntimeError("hs_ed25519_verify_device_batches_cached failed: " + _lib.last_error())
+                cseq[0] += 1
 
         for i in range(args.warmup):
             cstep(i)
@@ -1199,7 +1219,7 @@ def main():
         cached = {"value": round(n * claunches * KC * args.steps / c_elapsed, 1), "unit": "verifies/s", "batches_per_launch": KC,
                   "ms_per_step": round(c_elapsed / args.steps * 1e3, 4), "kernel": "k_verify_cached_lane2r_batches",
                   "avg_kernel_ms": round(k_ms, 4), "avg_chain_kernel_ms": round(k_chain_ms, 4), "keys": n * ns, "keyset_hbm_bytes": ks.hbm_bytes(),
-                  "keyset_build_ms": round(build_ms, 2),
+                  "keyset_build_ms": round(build_ms, 2), "message_variants_per_batch": VC,
                   "table_bytes_read_per_verify": (32 + 16) * 128,      # 32 lines of the key's table + 16 of the base point's 16-bit table
                   "note": "keys pre-registered (static committee); not comparable with `value`, which is the cold path"}
         ks.close()
