@@ -4,6 +4,7 @@
 #   bench   the driver's command; the line, its detail file and a one-screen summary
 #   diff    the scale differential: 10^7 crafted tuples through every kernel form + 10^7 / 10^5 scalars through half_scalar
 #   prof    rocprofv3 --kernel-trace --stats of the headline workload (the kernel's average duration the roofline must agree with)
+#   stream  BASELINE configs[4]: 10 s of back-to-back 6,667-signature rounds from one host thread through the ring
 #   cap     tools/capture_probe (which runtime calls of another thread break a thread-local capture) + the ring / key-set
 #           thread tests ten times over
 #   san     the host side under -fsanitize=thread and address,undefined (python -c "import __graft_entry__ as g; g.build_sanitized()"
@@ -55,6 +56,9 @@ for k in ('random', 'adversarial'):
 prof)
     timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r5_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
     python tools/rocpd_summary.py $(find /tmp/r5_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    ;;
+stream)
+    timeout 120 python tools/streamed_10s.py 10 > ${O}_streamed_10s.md 2> ${O}_streamed_10s.err; echo "streamed_10s rc=$?"; cat ${O}_streamed_10s.md
     ;;
 cap)
     [ -x tools/capture_probe ] || hipcc --offload-arch=gfx950 -O2 -o tools/capture_probe tools/capture_probe.hip -lpthread
