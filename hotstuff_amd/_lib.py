@@ -572,6 +572,7 @@ class Ticket:
             import struct
             keys = struct.pack("<%dI" % n, *keys)
         self.n = n
+        self._keyset = keyset           # keeps the key set alive as long as the ticket (hs_ed25519_keyset_destroy waits for uncollected tickets)
         self._h = ctypes.c_void_p()
         rc = lib().hs_ed25519_submit(ctypes.byref(self._h), keyset.handle if keyset is not None else None, bytes(digests),
                                      0 if shared else 32, bytes(keys), bytes(sigs), n, mode, SUBMIT_MORE if more else 0)
