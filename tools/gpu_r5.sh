@@ -83,7 +83,7 @@ san)
         else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"; fi
         timeout 60 $d/stress_host canary > ${O}_${kind}_canary.txt 2>&1; echo "$kind canary rc=$? (66 / 67 = the detector fired)"
         rm -f ${O}_${kind}_report*
-        timeout 300 $d/stress_host 6 > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
+        timeout 600 $d/stress_host ${HS_STRESS_SECONDS:-6} > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
         PYTHONPATH=tools:tests python tests/test_gpu_cpp_mirror.py fixture /tmp/mirror_fixture.bin && timeout 200 $d/mirror_tests /tmp/mirror_fixture.bin > ${O}_${kind}_mirror.txt 2>&1; echo "$kind mirror_tests rc=$?"; grep -c "^ok" ${O}_${kind}_mirror.txt; grep "^FAIL" ${O}_${kind}_mirror.txt | head
         unset TSAN_OPTIONS ASAN_OPTIONS UBSAN_OPTIONS
         ls ${O}_${kind}_report* 2>/dev/null | head -5
