@@ -1344,7 +1344,7 @@ def main():
             "config": {
                 "workload": ("QC shape: %d-signature batches over one digest, batch semantics, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)
                              if shared else
-                             "BASELINE configs[1]: %d-tuple (digest,pk,sig) batches, strict, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)),
+                             "BASELINE configs[1]: %d-tuple (digest,pk,sig) batches, strict, HBM-resident, %d distinct batches per GPU; %d batches/launch on %d CU-masked streams" % (n, D if K > 1 else ns, K, ns)),
                 "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
                 "distinct_tuples_per_gpu": (D if K > 1 else ns) * n, "streams": ns, "cu_partitions": args.partitions,
                 "timed_region_s": round(elapsed, 4), "batches_per_launch": K, "launches_in_timed_region_per_gpu": launches_per_step * args.steps,
