@@ -420,8 +420,8 @@ def ensure_init():
         init()
 
 
-# DeviceContext.set_kernel: 0 = by batch size; 1 = one lane per signature (cold: k_prepare + k_verify,
-# key cache: k_verify_cached_lane); 3 = fused / two-lane kernels at any size; 4 = the pairs form of the fused kernel
+# DeviceContext.set_kernel: 0 = by batch size; 1 = one lane per signature (cold: k_prepare + k_verify;
+# key-cache calls: as 3); 3 = fused / two-lane kernels at any size; 4 = the pairs form of the fused kernel
 # in verify_batches (two signatures per quad; elsewhere it behaves as 3).
 KERNEL_AUTO, KERNEL_LANE, KERNEL_FUSED, KERNEL_FUSED_PAIRS = 0, 1, 3, 4
 KERNEL_CACHED_C = 5          # key cache: chains + batched finish by compression at any size (cold calls: as KERNEL_AUTO)

@@ -7,11 +7,12 @@
 //               k_verify_fused_batches    the same for up to 16 independent small batches per grid
 //               k_prepare + k_verify      above: one lane per point / signature, SoA workspace
 //   key cache   k_keyset_decompress, k_keyset_build   registration (tables in HBM)
-//               k_verify_cached_lane2r    default up to 196,608: two lanes per signature + a
+//               k_verify_cached_lane2r    up to 98,304 signatures and for batch lists: two lanes per signature + a
 //                                         wavefront decompressing the R's beside the chains
-//               k_verify_cached_lane      above: one lane per signature
+//               k_cached_chain2 + k_cached_finish   above: two-lane chains, then a batched finish by compression
 //   k_tc_digests                          timeout-certificate digests ahead of any of the above
-//   (the beaten forms k_verify_cached, _5w, _lane2 of rounds 1-3 left the tree in round 5: `git show cd3b106:hotstuff_amd/csrc/hs_ed25519.hip`,
+//   (the beaten forms k_verify_cached, _5w, _lane2 of rounds 1-3 and the one-lane k_verify_cached_lane[_batches] - by selector
+//    only since it lost its size range - left the tree in round 5: `git show cd3b106:hotstuff_amd/csrc/hs_ed25519.hip`,
 //    numbers in profiles/HISTORY.md section 9)
 // Every verify kernel takes an optional `skip` word: when the batch random-linear-combination
 // check (hs_rlc.hip) has already accepted the whole batch it writes an all-ones bitmap and leaves.
@@ -695,59 +696,6 @@ k_cached_finish_batches(cachedc_batch_list L) {
     cached_finish_block(blockIdx.x - B.first_f, B.fin, B.np, B.nl, L.m, B.n, B.sigs, B.mode, B.bitmap, B.nreject, nullptr);
 }
 
-// the throughput form: one lane per signature (verify_cached_lane), for the largest batches and for long batch lists
-// `block` = this wavefront's index within its batch (64 signatures per wavefront)
-__device__ __forceinline__ void cached_lane_block(u32 block, const keyset_view &ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
-                                                  const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                                                  unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    if (skip && *skip) {
-        const u32 lanes = min(64u, n - block * 64);
-        if (threadIdx.x == 0) bitmap[block] = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
-        return;
-    }
-    const u32 i = block * 64 + threadIdx.x;
-    const bool active = i < n;
-    const u32 j = active ? i : n - 1;
-    const u32 ki_raw = key_idx[j];
-    const bool known = ki_raw < nkeys;
-    const u32 ki = known ? ki_raw : 0;
-    const u32 *sig = sigs + (size_t)16 * j;
-    u32 kw[8], sw[8], renc[8], msg[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) renc[t] = sig[t];
-    load_msg(msg, msgs, j);
-    bool ok = prepare_scalars(kw, sw, ks.pk + (size_t)8 * ki, sig, msg, true, true);
-    const u32 fl = ks.flag[ki];
-    ok = ok && known && (fl & HS_F_ONCURVE);
-    if (mode & HS_MODE_STRICT) ok = ok && !(fl & HS_F_SMALL);
-    const bool curve = verify_cached_lane(ks.tab + (size_t)ki * HS_KS_KEY_WORDS, b16, kw, sw, renc, (mode & HS_MODE_STRICT) != 0);
-    const unsigned long long mask = __ballot(ok && curve && active);
-    if (threadIdx.x == 0) {
-        bitmap[block] = mask;
-        if (nreject) {
-            const u32 lanes = min(64u, n - block * 64);
-            const u32 bad = lanes - (u32)__popcll(mask);
-            if (bad) atomicAdd(nreject, bad);
-        }
-    }
-}
-__global__ void __launch_bounds__(64)
-k_verify_cached_lane(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, msg_src msgs,
-                     const u32 *__restrict__ key_idx, const u32 *__restrict__ sigs, u32 n, u32 mode,
-                     unsigned long long *__restrict__ bitmap, u32 *__restrict__ nreject, const u32 *__restrict__ skip) {
-    cached_lane_block(blockIdx.x, ks, nkeys, b16, msgs, key_idx, sigs, n, mode, bitmap, nreject, skip);
-}
-// the same over a list of batches (hs_ed25519_verify_device_batches_cached with HS_K_LANE on the context)
-__global__ void __launch_bounds__(64)
-k_verify_cached_lane_batches(keyset_view ks, u32 nkeys, const u32 *__restrict__ b16, cached_batch_list L) {
-    u32 k = 0;
-#pragma unroll
-    for (u32 t = 1; t < HS_MAX_BATCHES_PER_LAUNCH; t++) if (t < L.count && blockIdx.x >= L.b[t].first_block) k = t;
-    const cached_batch &B = L.b[k];
-    cached_lane_block(blockIdx.x - B.first_block, ks, nkeys, b16, B.msgs, B.key_idx, B.sigs, B.n, B.mode,
-                      (unsigned long long *)B.bitmap32, B.nreject, nullptr);
-}
-
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
@@ -769,18 +717,13 @@ std::atomic<int> hs::g_oct_pick[hs::kMaxSlots];      // set to -1 by init
 // (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
 // narrow contexts - two per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
 int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrides the second (read at init; measurement aid)
-// cached path: two lanes per signature plus an R-decompression wavefront (k_verify_cached_lane2r) up to here,
-// one lane per signature above.  Round 1 switched at 196,608; with the affine 128-byte table entries the one-lane
-// kernel fits two wavefronts per SIMD (243 VGPRs instead of 256 + 6 AGPRs) and wins from ~100,000 signatures
-// (profiles/r2_sweeps.md section 3: 0.518 vs 0.680 ms at 131,072; 0.485 vs 0.435 ms at 66,667).
-static const size_t kCachedLane1Min = 98304;
 // key cache, single calls: where the two-launch form - chains, then the batched finish by compression - takes over.  Its
 // second launch is a tail of 0.07 - 0.11 ms (four to sixteen signatures per lane and one 254-squaring inversion on a handful of
 // lone wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
 // four calls in flight 341 -> 414 M signatures/s at 49,152 - 66,667, 353 / 382 -> 436 - 441 at 131,072 (343 against 346 - 353
-// at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the one-lane kernel's 0.40 and the
-// R-wavefront kernel's 0.44 (0.290 against 0.262 at 66,667: not yet) on one box - above 98,304, where the one-lane
-// kernel used to take over (on some boxes the one-lane kernel still wins there by 7 %, profiles/r4_t_cached_c_slow_box.md).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
+// at 32,768: not yet); a LONE call with four signatures per lane 0.369 ms at 131,072 against the R-wavefront kernel's 0.44
+// (0.290 against 0.262 at 66,667: not yet) - above 98,304 (a one-lane kernel, k_verify_cached_lane, used to take over there: 0.40 ms at
+// 131,072, ahead by 7 % on some GPUs and behind by 8 % on others, profiles/r4_t_cached_c_slow_box.md; retired in round 5).  Batch lists of small batches lose outright (185 against 269 M verifies/s at four 1,024-signature batches per launch:
 // the tail is as long as the chains) and keep the R-wavefront kernel.  HS_ED25519_CACHED_C_MIN / _CACHED_C_MIN_LONE override.
 // A lone call takes the two-launch form above 98,304 signatures on every GPU (round 5: round 4 switched there by an init-time proxy
 // for "the box's class", worth +8 % / -7 % in a range past every BASELINE config; a size switch that needs a per-box oracle and
@@ -937,8 +880,8 @@ extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     delete c;
 }
 // Per-context kernel choice (tests and A/B measurements; the default is by batch size):
-// HS_K_AUTO 0, HS_K_LANE 1 (cold: k_prepare + k_verify; cached: k_verify_cached_lane),
-// HS_K_FUSED 3 (cold: k_verify_fused; cached: k_verify_cached_lane2r).  Returns the previous choice.
+// HS_K_AUTO 0, HS_K_LANE 1 (cold: k_prepare + k_verify; key-cache calls: as HS_K_FUSED),
+// HS_K_FUSED 3 (cold: k_verify_fused; cached: k_verify_cached_lane2r at any size).  Returns the previous choice.
 extern "C" int hs_ed25519_ctx_set_concurrent(hs_ed25519_ctx *c, int concurrent) {
     if (!c) return fail(HS_ED25519_E_ARG, "ctx_set_concurrent: null context");
     const int was = c->several_in_flight ? 1 : 0;
@@ -1160,11 +1103,11 @@ extern "C" size_t hs_ed25519_config_dump(char *buf, size_t cap) {
     o += t;
     snprintf(t, sizeof t, "\"max_batch_hint\": %zu, \"narrow_pool_max_batch\": %zu, \"zero_copy_max\": %zu, \"oct_max_batch\": %zu, \"oct_split_forced\": %d, "
              "\"autotune\": %d, \"quad_max_batch\": %zu, \"tail_max\": %zu, \"pairs_min_batches\": %lld, \"lane_min_batches\": %lld, \"lane_min_total\": %zu, "
-             "\"cached_lane1_min\": %zu, \"cached_c_min_concurrent\": %zu, \"cached_c_min_lone\": %zu, \"rlc_min_batch\": %zu, "
+             "\"cached_c_min_concurrent\": %zu, \"cached_c_min_lone\": %zu, \"rlc_min_batch\": %zu, "
              "\"min_gpu_batch\": {\"cold\": %zu, \"key_cache\": %zu}, ",
              g_max_batch.load(), (size_t)kPartitionMaxBatch, (size_t)kZeroCopyMax, g_oct_max_batch.load(), g_oct_split.load(), g_autotune.load(),
              g_quad_max_batch.load(), g_tail_max.load(), pm == (size_t)-1 ? -1ll : (long long)pm, lm == (size_t)-1 ? -1ll : (long long)lm, kLaneMinTotal,
-             kCachedLane1Min, g_cached_c_min.load(), g_cached_c_min_lone.load(), hs_ed25519_rlc_min_batch(),
+             g_cached_c_min.load(), g_cached_c_min_lone.load(), hs_ed25519_rlc_min_batch(),
              hs_ed25519_min_gpu_batch(0), hs_ed25519_min_gpu_batch(1));
     o += t;
     o += "\"devices\": [";
@@ -1222,7 +1165,7 @@ extern "C" const char *hs_ed25519_batches_kernel_for(const hs_ed25519_ctx *ctx, 
 }
 // what a LONE call of n signatures through the key cache runs (a context marked concurrent switches to k_cached_chain2 earlier)
 extern "C" const char *hs_ed25519_cached_kernel_for(size_t n) {
-    return n >= cached_c_min_lone() ? "k_cached_chain2" : (n > kCachedLane1Min ? "k_verify_cached_lane" : "k_verify_cached_lane2r");
+    return n >= cached_c_min_lone() ? "k_cached_chain2" : "k_verify_cached_lane2r";
 }
 static bool cached_c_form(const hs_ed25519_ctx *ctx, size_t n) {
     if (ctx->kernel == HS_K_CACHED_C) return true;
@@ -1566,10 +1509,6 @@ extern "C" int hs_ed25519_verify_device_batches_cached(hs_ed25519_ctx *ctx, cons
         hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
         if (ev) ctx->ev_mid[slot] = 0;
         void *a[] = { &kv, &nkeys, &p_bt, &L };
-        if (ctx->kernel == HS_K_LANE)
-            HS_HIP(launch1((const void *)k_verify_cached_lane_batches, dim3(blocks), dim3(64), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
-                   "launch k_verify_cached_lane_batches");
-        else
         HS_HIP(launch1((const void *)k_verify_cached_lane2r_batches, dim3(blocks), dim3(192), a, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                "launch k_verify_cached_lane2r_batches");
     }
@@ -1767,7 +1706,6 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
     hipEvent_t *ev = rec ? &ctx->ev[3 * slot] : nullptr;
     if (ev) ctx->ev_mid[slot] = 0;
     hipEvent_t e0 = ev ? ev[0] : nullptr, e2 = ev ? ev[2] : nullptr;
-    const int forced = ctx->kernel;
     if (cached_c_form(ctx, n)) {
         // chains, then HS_CFIN_M signatures per finish lane (verify_cached.h): R' and the flags pass through the context's workspace
         int rc = ctx_reserve(ctx, n, ctx->staging);
@@ -1786,10 +1724,7 @@ int hs::enqueue_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, msg_src
         HS_HIP(launch1((const void *)k_cached_finish, dim3(nl / 64), dim3(64), af, st, nullptr, e2), "launch k_cached_finish");
         return 0;
     }
-    if (forced == HS_K_LANE || (hs_k_auto_like(forced) && n > kCachedLane1Min))
-        HS_HIP(launch1((const void *)k_verify_cached_lane, dim3(np / 64), dim3(64), a, st, e0, e2), "launch k_verify_cached_lane");
-    else
-        HS_HIP(launch1((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, st, e0, e2), "launch k_verify_cached_lane2r");
+    HS_HIP(launch1((const void *)k_verify_cached_lane2r, dim3(np / 64), dim3(192), a, st, e0, e2), "launch k_verify_cached_lane2r");
     return 0;
 }
 extern "C" int hs_ed25519_verify_device_cached(hs_ed25519_ctx *ctx, const hs_ed25519_keyset *ks, const uint8_t *d_digests,

@@ -382,7 +382,8 @@ HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {
     ge_add(t, p, c, false);
     ge_p1p1_to_p3(r, t, true);
 }
-// The curve part of one cached verification on ONE lane (both chains serially).
+// The curve part of one cached verification on ONE lane (both chains serially): the plain form the split forms below are
+// held against in tests/emu (its kernel, k_verify_cached_lane, left the product in round 5 - it had no size range left).
 // b16: the base point's 16-bit table; sw: s recoded in radix 65536 (kw: k in radix 256) - 32 + 16 additions.
 HS_HD bool verify_cached_lane(const u32 *atab, const u32 *b16, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
     ge_p3 pa, pb, acc;
@@ -391,25 +392,6 @@ HS_HD bool verify_cached_lane(const u32 *atab, const u32 *b16, u32 kw[8], u32 sw
     ge_add_p3(acc, pa, pb);
     return cached_finish(acc, renc, strict);
 }
-#if defined(__HIPCC__)
-// TWO lanes per signature: the even lane walks the key's table with k, the odd lane the base
-// point's table with s - one instruction stream, per-lane table pointer and digit source -
-// then one DPP exchange and one addition join them.  Half the serial additions per lane and
-// twice the wavefronts for the same batch.
-HS_Q bool verify_cached_lane2(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
-    const bool odd = threadIdx.x & 1u;
-    const u32 *tab = odd ? btab : atab;
-    u32 dw[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) dw[i] = odd ? sw[i] : kw[i];
-    ge_p3 mine, other, acc;
-    cached_chain(mine, tab, dw);
-    other.X = q_perm<1, 0, 3, 2>(mine.X); other.Y = q_perm<1, 0, 3, 2>(mine.Y);
-    other.Z = q_perm<1, 0, 3, 2>(mine.Z); other.T = q_perm<1, 0, 3, 2>(mine.T);
-    ge_add_p3(acc, mine, other);          // both lanes of the pair now hold R' (addition commutes)
-    return cached_finish(acc, renc, strict);
-}
-#endif
 // The default two-lane form: the 32 + 16 additions of one signature split EVENLY, 24 per lane, returning R' for a
 // projective comparison against an R decompressed elsewhere.  The even lane sums the key's windows 31..8; the odd
 // lane the key's windows 7..0 and then the base point's sixteen 16-bit windows.  One instruction stream: every step

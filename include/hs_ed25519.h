@@ -207,8 +207,9 @@ int hs_ed25519_ctx_kernel_times(hs_ed25519_ctx *ctx, double *prepare_ms_sum, dou
  * the default): 0 = by batch size (cold: eight lanes per signature up to 8,192 signatures, the fused
  * four-lanes-per-signature kernels up to 32,768, k_prepare + k_verify above; key cache: k_verify_cached_lane2r - two lanes per
  * signature and a third wavefront decompressing the R's beside them - up to 98,304 signatures and for batch lists; above
- * (from 49,152 on a context marked concurrent) the two-launch form: two-lane chains, then four to sixteen signatures per finish
- * lane compressed with ONE inversion), 1 = the one-lane-per-signature kernels, 3 = the fused /
+ * (from 49,152 on a context marked concurrent) the two-launch form: two-lane chains, then four or eight signatures per finish
+ * lane compressed with ONE inversion), 1 = cold calls: the one-lane-per-signature pair (key-cache calls: as 3 - their one-lane
+ * kernel lost its size range and left the library in round 5), 3 = the fused /
  * two-lane + R-wavefront kernels at any size, 4 = as 3, and hs_ed25519_verify_device_batches uses the pairs form whatever
  * the batch count (3 pins it to the one-signature-per-quad form, 1 to the one-lane pair over the
  * batch list), 5 = key cache: the two-launch form at any size, batch lists included (cold calls as 0, except that a cold batch

@@ -68,7 +68,7 @@ def test_config_dump_reports_every_resolved_knob_without_a_gpu():
     cfg = _lib.config_dump()
     assert cfg["abi_version"] == _lib.ABI_VERSION
     for key in ("tenants", "pool_wide", "pool_narrow", "pool_partitions", "hw_queue_budget", "gpu_max_hw_queues_env", "oct_max_batch",
-                "oct_split_forced", "autotune", "quad_max_batch", "tail_max", "pairs_min_batches", "lane_min_batches", "cached_lane1_min",
+                "oct_split_forced", "autotune", "quad_max_batch", "tail_max", "pairs_min_batches", "lane_min_batches",
                 "cached_c_min_concurrent", "cached_c_min_lone", "rlc_min_batch", "min_gpu_batch", "devices", "env_seen"):
         assert key in cfg, key
     assert cfg["cached_c_min_lone"] == 98305 and cfg["hw_queue_budget"] == _lib.hw_queue_budget(cfg["tenants"])

@@ -24,7 +24,7 @@ def test_a_million_crafted_tuples_through_every_kernel_form():
     assert rep["mismatches"] == 0, rep["first_mismatches"][:4]
     rlc = {k: f for k, f in rep["forms"].items() if k.startswith("k_rlc_")}
     assert all(f["verifications"] == 2 << 20 for k, f in rep["forms"].items() if k not in rlc), rep["forms"]
-    assert len(rep["forms"]) >= 19 and len(rlc) == 2
+    assert len(rep["forms"]) >= 17 and len(rlc) == 2
     for f in rlc.values():       # mixed calls localised to BATCH's labels; honest-only calls accepted by the combination itself
         assert f["mismatches"] == 0 and f["honest_calls"] >= 8 and f["calls_accepted_by_the_combination"] == f["honest_calls"], f
     # the classes the differential exists for were there, with both verdicts

@@ -176,7 +176,7 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     ks = _lib.KeySet([bytes(pks[32 * i:32 * i + 32]) for i in range(n)])
     ok, bm = _lib.verify_tc_packed(rnd, hq, bytes(pks), bytes(sigs), keyset=ks)
     assert not ok and bits(bm, n) == expect
-    # the two-kernel path (n > 32,768 by size) and the one-lane cached kernel (n > 98,304 by size), forced per context
+    # the two-kernel cold path (n > 32,768 by size), forced per context (key-cache calls of that context: the default kernel)
     r = DeviceRunner(n, kernel=_lib.KERNEL_LANE)
     assert r.tc_bits(rnd, hq, bytes(pks), bytes(sigs)) == expect
     keys = [bytes(pks[32 * i:32 * i + 32]) for i in range(n)]
@@ -185,10 +185,10 @@ def test_tc_digests_built_on_device_cold_and_cached(oracle):
     ks.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, "cached-lane", "cached-lane2r", "cached-c"])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, "cached-lane2r", "cached-c"])
 def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     """160 randomized torsion-mix signatures labelled by the big-int oracle, through both cold
-    kernels and the three key-cache forms (forced per context: one lane, two lanes + R wavefront, chains + batched finish
+    kernels and the two key-cache forms (forced per context: two lanes + R wavefront, chains + batched finish
     by compression), both modes."""
     vec = torsion_fuzz
     n = len(vec)
@@ -197,7 +197,7 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     sg = b"".join(H(v["sig"]) for v in vec)
     if isinstance(kernel, str):
         ks = _lib.KeySet(keys)
-        r = DeviceRunner(n, kernel={"cached-lane": _lib.KERNEL_LANE, "cached-lane2r": _lib.KERNEL_FUSED, "cached-c": _lib.KERNEL_CACHED_C}[kernel])
+        r = DeviceRunner(n, kernel={"cached-lane2r": _lib.KERNEL_FUSED, "cached-c": _lib.KERNEL_CACHED_C}[kernel])
         strict = r.bits(dg, None, sg, n, _lib.STRICT, False, keyset=ks, keys=keys)
         batch = r.bits(dg, None, sg, n, _lib.BATCH, False, keyset=ks, keys=keys)
         r.close()
@@ -211,11 +211,11 @@ def test_torsion_fuzz_every_path(torsion_fuzz, kernel):
     assert [bool(b) for b in batch] == [v["cofactorless"] for v in vec]
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_LANE, _lib.KERNEL_FUSED, _lib.KERNEL_CACHED_C])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_FUSED, _lib.KERNEL_CACHED_C])
 def test_cached_kernel_variants_agree(oracle, edge_vectors, kernel):
     """The default cached kernel up to 98,304 signatures is the three-wavefront one (two lanes per signature + concurrent
-    R decompression), one lane per signature above, and for the largest calls two-lane chains + a batched finish by
-    compression (k_cached_chain2 + k_cached_finish).  Force each on small inputs: edge vectors in both modes and a
+    R decompression), above that two-lane chains + a batched finish by compression (k_cached_chain2 + k_cached_finish).
+    Force each on small inputs: edge vectors in both modes and a
     corrupted QC vs the oracle (700 signatures: 64 finish lanes walking 11 each)."""
     r = DeviceRunner(1024, kernel=kernel)
     n = len(edge_vectors)

@@ -426,12 +426,12 @@ def test_edge_vectors_through_batches_per_launch(edge_vectors, torsion_fuzz, ker
     ctx.close()
 
 
-@pytest.mark.parametrize("kernel", [_lib.KERNEL_AUTO, _lib.KERNEL_LANE, _lib.KERNEL_CACHED_C])
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_AUTO, _lib.KERNEL_CACHED_C])
 def test_several_key_cache_batches_in_one_launch(oracle, kernel):
     """hs_ed25519_verify_device_batches_cached: 18 independent batches (two grids) against one key set - different
     sizes, digest forms and modes, permuted / repeated / unknown key indices, corrupted signatures - each with its
     own bitmap and reject counter; verdicts vs the oracle (an unknown index is a rejected signature).  Through the
-    default kernel (two lanes per signature + R wavefront), the one-lane kernel over the batch list, and two-lane chains + the
+    default kernel (two lanes per signature + R wavefront) and two-lane chains + the
     batched finish by compression (k_cached_chain2_batches / k_cached_finish_batches, by selector)."""
     import random
     dev = torch.device("cuda", 0)

@@ -33,7 +33,8 @@ def sweep():
     ks = _lib.KeySet([pks[32 * i:32 * i + 32] for i in range(nmax)])
     d_dg, d_sg = t(dg), t(sg)
     d_ki = torch.arange(nmax, dtype=torch.int32, device=dev)
-    forms = (("lane2r", _lib.KERNEL_FUSED), ("lane", _lib.KERNEL_LANE), ("c", _lib.KERNEL_CACHED_C))
+    # (profiles/r4_j_cached_c_ab.md and r4_t_* carry a third column, "lane": the one-lane kernel k_verify_cached_lane, retired in round 5)
+    forms = (("lane2r", _lib.KERNEL_FUSED), ("c", _lib.KERNEL_CACHED_C))
     print("| signatures | " + " | ".join("%s p50 / kernel ms" % f for f, _ in forms) + " | " + " | ".join("%s M sig/s, 4 in flight" % f for f, _ in forms) + " |")
     print("|---|" + "---|" * (2 * len(forms)))
     for n in SIZES:

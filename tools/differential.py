@@ -41,11 +41,9 @@ def forms(_lib):
         ("k_verify_fused_pairs_batches", "cold_list", K.KERNEL_AUTO, 4096, 4, False),
         ("k_prepare_batches + k_verify_batches", "cold_list", K.KERNEL_AUTO, 4096, 16, False),
         ("k_verify_cached_lane2r", "cached", K.KERNEL_AUTO, 65536, 1, False),
-        ("k_verify_cached_lane", "cached", K.KERNEL_LANE, 131072, 1, False),
         ("k_cached_chain2 + k_cached_finish (4 per lane)", "cached", K.KERNEL_CACHED_C, 131072, 1, False),
         ("k_cached_chain2 + k_cached_finish (8 per lane)", "cached", K.KERNEL_CACHED_C, 131072, 1, True),
         ("k_verify_cached_lane2r_batches", "cached_list", K.KERNEL_AUTO, 4096, 4, False),
-        ("k_verify_cached_lane_batches", "cached_list", K.KERNEL_LANE, 4096, 4, False),
         ("k_cached_chain2_batches + k_cached_finish_batches", "cached_list", K.KERNEL_CACHED_C, 4096, 4, False),
     ]
 

@@ -4,8 +4,9 @@
      contexts in flight, n = 2,048 ... 262,144 -> where the library's threshold belongs
   2. per-signature cold path above the fused kernel's default range: k_verify_fused (four lanes per signature,
      table in LDS) forced at every size vs k_prepare + k_verify (one lane per signature, table in private memory)
-  3. key-cache path: k_verify_cached_lane2r (two lanes per signature + an R-decompression wavefront) vs
-     k_verify_cached_lane (one lane per signature) by size, with the affine 128-byte table entries
+  3. key-cache path: k_verify_cached_lane2r (two lanes per signature + an R-decompression wavefront) vs the two-launch form
+     (k_cached_chain2 + k_cached_finish) by size.  (profiles/r2_sweeps.md section 3 compares it with the one-lane kernel
+     k_verify_cached_lane, which left the library in round 5.)
 Synthetic sets are signed on the GPU (hs_ed25519_public_keys / hs_ed25519_sign_batch)."""
 import os
 import sys
@@ -101,8 +102,8 @@ for n in ([] if os.environ.get('HS_SWEEP_ONLY') == '3' else (8192, 16384, 32768,
 
 if os.environ.get("HS_SWEEP_SKIP3"):
     sys.exit(0)
-print("\n## 3. Key-cache path (batch semantics, shared digest, one key per signature): two-lane + R-wavefront kernel vs one-lane kernel\n")
-print("| signatures | lane2r p50 ms | lane p50 ms | lane2r M sig/s (4 in flight) | lane M sig/s (4 in flight) |")
+print("\n## 3. Key-cache path (batch semantics, shared digest, one key per signature): two-lane + R-wavefront kernel vs chains + batched finish\n")
+print("| signatures | lane2r p50 ms | chain2 + finish p50 ms | lane2r M sig/s (4 in flight) | chain2 + finish M sig/s (4 in flight) |")
 print("|---|---|---|---|---|")
 
 
@@ -147,5 +148,5 @@ def measure_cached(n, kernel, nctx=4, calls=20, reps=8):
 
 for n in (1024, 6667, 16384, 66667, 131072, 262144):
     a = measure_cached(n, _lib.KERNEL_FUSED)
-    b = measure_cached(n, _lib.KERNEL_LANE)
+    b = measure_cached(n, _lib.KERNEL_CACHED_C)
     print("| %d | %.3f | %.3f | %.1f | %.1f |" % (n, a[0], b[0], a[1], b[1]), flush=True)
