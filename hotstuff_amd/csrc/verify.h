@@ -351,15 +351,7 @@ HS_HD bool verify_lane(const workspace &ws, u32 i, u32 mode, const u32 *b16) {
     return ok && fe_iszero(acc.X) && fe_eq(acc.Y, acc.Z) && !fe_iszero(acc.Z);
 }
 
-// ---- base-point table (computed once on the host at init) ----------------------------------
-HS_HD void ge_p3_to_niels(ge_niels &n, const ge_p3 &p) {
-    fe zi, x, y, xy;
-    fe_invert(zi, p.Z);
-    fe_mul(x, p.X, zi); fe_mul(y, p.Y, zi);
-    fe_add(n.ypx, y, x); fe_carry(n.ypx);
-    fe_sub(n.ymx, y, x); fe_carry(n.ymx);
-    fe_mul(xy, x, y); fe_mul(n.xy2d, xy, fe_d2());
-}
+// ---- the base point ------------------------------------------------------------------------
 HS_HD void ge_basepoint(ge_p3 &b) {
     const u32 bx[10] = FE26_BX, by[10] = FE26_BY, bt[10] = FE26_BT;
     b.X = fe_const(bx); b.Y = fe_const(by); fe_1(b.Z); b.T = fe_const(bt);

@@ -58,13 +58,6 @@ struct keyset_view {
 };
 
 #if defined(__HIPCC__)
-HS_Q qv q_invert(const qv &z) { qv r; fe_invert(r, z); return r; }
-HS_Q bool q_quad_and01(const qflags &f) {     // lanes 0 and 1 both set, uniform over the quad
-    const int v = f.f ? 1 : 0;
-    const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
-    const int b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
-    return a && b;
-}
 HS_Q bool q_quad_all(const qflags &f) {       // all four lanes set, uniform over the quad
     const int v = f.f ? 1 : 0;
     const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true), b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
@@ -76,50 +69,10 @@ HS_Q void q_store_entry(u32 *entry, const qv &e) {      // a PROJECTIVE entry of
 #pragma unroll
     for (int i = 0; i < 5; i++) p[i] = make_uint2(e.v[2 * i], e.v[2 * i + 1]);
 }
-// lane 0: x' has the encoded sign (or x' = 0); lane 1: y' equals the encoded y; lane 2: Z != 0; lane 3: true
-HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
-    u32 w[8];
-    fe_to_words(w, affine);
-    fe ye; fe_from_words(ye, enc);
-    u32 yw[8];
-    fe_to_words(yw, ye);
-    u32 dy = 0, nz = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { dy |= w[i] ^ yw[i]; nz |= w[i]; }
-    const u32 lane = q_lane();
-    qflags r;
-    // lane 2 holds Z * Z^-1: 1, or 0 when Z = 0 (a faulted accumulator) - fail closed (ge_match_point, verify.h)
-    r.f = lane == 0 ? ((w[0] & 1) == (enc[7] >> 31) || nz == 0) : (lane == 1 ? dy == 0 : (lane == 2 ? nz != 0 : true));
-    return r;
-}
-// lane 0: X == 0; lane 1: Y == Z; (identity test of a projective point held in a quad)
-HS_Q qflags q_identity_lanes(const qv &p) {
-    const qv z = q_perm<2, 2, 2, 2>(p);
-    qflags r;
-    const u32 lane = q_lane();
-    r.f = lane == 0 ? fe_iszero(p) : (lane == 1 ? fe_eq(q_carry(p), q_carry(z)) : true);
-    return r;
-}
 #else
-HS_Q qv q_invert(const qv &z) { qv r; for (int i = 0; i < 4; i++) fe_invert(r.l[i], z.l[i]); return r; }
-HS_Q bool q_quad_and01(const qflags &f) { return f.f[0] && f.f[1]; }
 HS_Q bool q_quad_all(const qflags &f) { return f.f[0] && f.f[1] && f.f[2] && f.f[3]; }
 HS_Q void q_store_entry(u32 *entry, const qv &e) {
     for (int l = 0; l < 4; l++) for (int i = 0; i < 10; i++) entry[10 * l + i] = e.l[l].v[i];
-}
-HS_Q qflags q_match_encoding(const qv &affine, const u32 enc[8]) {
-    u32 wx[8], wy[8], yw[8];
-    fe_to_words(wx, affine.l[0]); fe_to_words(wy, affine.l[1]);
-    fe ye; fe_from_words(ye, enc); fe_to_words(yw, ye);
-    u32 dy = 0, nz = 0;
-    for (int i = 0; i < 8; i++) { dy |= wy[i] ^ yw[i]; nz |= wx[i]; }
-    qflags r; r.f[0] = (wx[0] & 1) == (enc[7] >> 31) || nz == 0; r.f[1] = dy == 0; r.f[2] = !fe_iszero(affine.l[2]); r.f[3] = true;
-    return r;
-}
-HS_Q qflags q_identity_lanes(const qv &p) {
-    qflags r; r.f[0] = fe_iszero(p.l[0]);
-    fe y = p.l[1], z = p.l[2]; fe_carry(y); fe_carry(z);
-    r.f[1] = fe_eq(y, z); r.f[2] = r.f[3] = true; return r;
 }
 #endif
 
@@ -196,44 +149,6 @@ HS_HD void keyset_affine_group(u32 *out /* G x 32 words */, const u32 *in /* G x
         for (int i = 0; i < 10; i++) { o[i] = a.v[i]; o[10 + i] = b.v[i]; o[20 + i] = c.v[i]; }
         o[30] = 0; o[31] = 0;
     }
-}
-
-// ---- verification: one quad per signature -------------------------------------------------
-// atab: this key's table; btab: the base point's table (same layout, +B).
-// kw, sw: radix-256 recodings of k and s.  renc: the 8 words of R's encoding.
-// strict: also reject when [8]R' = O.   Returns the quad-uniform verdict of the curve part.
-HS_Q qv cached_quad_chain(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8]) {
-    qv acc = q_lanes(fe_small(0), fe_small(1), fe_small(1), fe_small(0));
-#pragma nounroll
-    for (int w = HS_KS_WINDOWS - 1; w >= 0; w--) {
-        const int dk = sc_pop_digit8(kw), ds = sc_pop_digit8(sw);
-        const int ik = dk < 0 ? -dk : dk, is = ds < 0 ? -ds : ds;
-        const qv ea = q_load_entry(atab + ((size_t)w * HS_KS_ENTRIES + ik) * HS_KS_ENTRY_WORDS);
-        const qv eb = q_load_entry(btab + ((size_t)w * HS_KS_ENTRIES + is) * HS_KS_ENTRY_WORDS);
-        acc = q_add_cached(acc, q_cached_signed(ea, dk < 0));
-        acc = q_add_cached(acc, q_cached_signed(eb, ds < 0));
-    }
-    return acc;
-}
-HS_Q bool verify_cached_core(const u32 *atab, const u32 *btab, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
-    const qv acc = cached_quad_chain(atab, btab, kw, sw);
-    bool ok = true;
-    if (strict) {       // [8]R' == O ?  (R' == R whenever the signature is accepted)
-        qv t = q_dbl(q_dbl(q_dbl(acc)));
-        ok = !q_quad_and01(q_identity_lanes(t));
-    }
-    const qv zinv = q_invert(q_perm<2, 2, 2, 2>(acc));
-    const qv aff = q_mul(acc, zinv);                        // (x', y', 1, t')
-    return ok && q_quad_all(q_match_encoding(aff, renc));
-}
-// The other way to finish: R was decompressed elsewhere (concurrently, by another wavefront of
-// the workgroup) to affine (rx, ry); compare as points, X == x_R Z and Y == y_R Z - two
-// multiplications instead of an inversion on the critical path.  r_flags: HS_F_* of R.
-HS_Q bool cached_quad_match_point(const qv &acc, const fe &rx, const fe &ry, u32 r_flags, bool strict) {
-    const qflags f = q_match_point(acc, rx, ry);
-    bool ok = (r_flags & HS_F_ONCURVE) != 0;
-    if (strict) ok = ok && !(r_flags & HS_F_SMALL);
-    return ok && q_quad_all(f);
 }
 
 // ---- one lane per signature (throughput form, large batches) -------------------------------
@@ -314,24 +229,6 @@ HS_HD void cached_chain(ge_p3 &acc, const u32 *tab, u32 dw[8]) {
         ge_add_tab_second(acc, acc, h, neg);
     }
 }
-// sum_w T_B16[w][d_w] over the 16 windows of the base point's 16-bit table and a radix-65536 recoded scalar
-HS_HD void cached_chain16(ge_p3 &acc, const u32 *b16, u32 dw[8]) {
-    ge_identity(acc);
-    tab_entry e;
-    int d = sc_pop_digit16(dw);
-    load_tab_entry(e, b16 + ((size_t)(HS_B16_WINDOWS - 1) * HS_B16_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
-#pragma nounroll
-    for (int w = HS_B16_WINDOWS - 1; w >= 0; w--) {
-        const bool neg = d < 0;
-        add_tab_half h;
-        ge_add_tab_first(h, acc, e, neg);
-        if (w > 0) {
-            d = sc_pop_digit16(dw);
-            load_tab_entry(e, b16 + ((size_t)(w - 1) * HS_B16_ENTRIES + (d < 0 ? -d : d)) * HS_KS_ENTRY_WORDS);
-        }
-        ge_add_tab_second(acc, acc, h, neg);
-    }
-}
 // Entry j of window w of the 16-bit base table, PROJECTIVE (Y-X, Y+X, 2dT, 2Z; 40 words - what keyset_affine_group
 // normalises), from the 8-bit table t8 of +B: the stored affine entry (y-x, y+x, 2dxy) of 2^(8(2w+1)) hi B becomes the
 // extended point (2x, 2y, 2, 2xy) - 2xy = 2dxy / d - and the entry of 2^(16w) |lo| B is added to or subtracted from it.
@@ -355,25 +252,6 @@ HS_HD void base16_entry_projective(u32 *out /* 40 words */, const u32 *t8, u32 w
 #pragma unroll
     for (int i = 0; i < 10; i++) { out[i] = c.YmX.v[i]; out[10 + i] = c.YpX.v[i]; out[20 + i] = c.T2d.v[i]; out[30 + i] = z2.v[i]; }
 }
-// The check of R' = (X:Y:Z:T) against R's encoding (and the strict small-order test).
-HS_HD bool cached_finish(const ge_p3 &acc, const u32 renc[8], bool strict) {
-    bool ok = true;
-    if (strict) ok = !ge_is_small_order(acc);      // [8]R' == O ?  (R' == R whenever accepted)
-    fe zi, x, y;
-    fe_invert(zi, acc.Z);
-    fe_mul(x, acc.X, zi);
-    fe_mul(y, acc.Y, zi);
-    u32 xw[8], yw[8], ew[8];
-    fe_to_words(xw, x);
-    fe_to_words(yw, y);
-    fe ye; fe_from_words(ye, renc);
-    fe_to_words(ew, ye);
-    u32 dy = 0, nz = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { dy |= yw[i] ^ ew[i]; nz |= xw[i]; }
-    // Z != 0: fail closed on a faulted (all-zero) accumulator, whose "affine" image is (0, 0) - ge_match_point, verify.h
-    return ok && dy == 0 && ((xw[0] & 1) == (renc[7] >> 31) || nz == 0) && !fe_iszero(acc.Z);
-}
 // p + q for two extended points (q converted to cached form on the fly)
 HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {
     ge_cached c;
@@ -381,16 +259,6 @@ HS_HD void ge_add_p3(ge_p3 &r, const ge_p3 &p, const ge_p3 &q) {
     ge_p1p1 t;
     ge_add(t, p, c, false);
     ge_p1p1_to_p3(r, t, true);
-}
-// The curve part of one cached verification on ONE lane (both chains serially): the plain form the split forms below are
-// held against in tests/emu (its kernel, k_verify_cached_lane, left the product in round 5 - it had no size range left).
-// b16: the base point's 16-bit table; sw: s recoded in radix 65536 (kw: k in radix 256) - 32 + 16 additions.
-HS_HD bool verify_cached_lane(const u32 *atab, const u32 *b16, u32 kw[8], u32 sw[8], const u32 renc[8], bool strict) {
-    ge_p3 pa, pb, acc;
-    cached_chain(pa, atab, kw);
-    cached_chain16(pb, b16, sw);
-    ge_add_p3(acc, pa, pb);
-    return cached_finish(acc, renc, strict);
 }
 // The default two-lane form: the 32 + 16 additions of one signature split EVENLY, 24 per lane, returning R' for a
 // projective comparison against an R decompressed elsewhere.  The even lane sums the key's windows 31..8; the odd

@@ -273,15 +273,6 @@ HS_Q qv q_dbl(const qv &p) {
     return q_mul(l, r);                                                             // (EF, DS, FD, ES)
 }
 
-// acc == (rx, ry) as points: X == x_R Z (lane 0), Y == y_R Z (lane 1), and Z != 0 (lanes 2, 3) -
-// see ge_match_point (verify.h) for why the last test is there.  The caller ANDs the four flags.
-HS_Q qflags q_match_point(const qv &acc, const fe &rx, const fe &ry) {
-    const qv z = q_perm<2, 2, 2, 2>(acc);
-    const qv rhs = q_mul(q_lanes(rx, ry, fe_small(1), fe_small(1)), z);
-    const qv lhs = q_carry(q_sel<0b1100>(acc, z));
-    return q_eq_nz(rhs, lhs);
-}
-
 // The recoded scalars of the half-size form (halfscalar.h) for one signature: |u| and v in signed radix 16, w = v s mod L
 // in signed radix 65536, how many windows u and v need, and the sign of u.
 #ifdef HS_FORCE_NWIN

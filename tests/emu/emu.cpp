@@ -7,6 +7,7 @@
 #include "../../hotstuff_amd/csrc/verify.h"
 #include "../../hotstuff_amd/csrc/verify_quad.h"
 #include "../../hotstuff_amd/csrc/verify_cached.h"
+#include "retired_cores.h"      // cores of kernels that left the product: three more organisations of the same primitives
 #include "../../hotstuff_amd/csrc/rlc.h"
 #include "../../hotstuff_amd/csrc/wire.h"
 using namespace hs;

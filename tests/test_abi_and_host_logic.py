@@ -393,3 +393,43 @@ def test_tools_only_use_what_the_binding_and_the_library_have():
         bad += ["%s: %s" % (f, m.group(1)) for m in re.finditer(r"\b(hs_ed25519_[a-z0-9_]*[a-z0-9])\b(?!_)", s)
                 if m.group(1) not in nm and not m.group(1).startswith(("hs_ed25519_core", "hs_ed25519_h"))]
     assert not bad, sorted(set(bad))
+
+
+def test_product_headers_hold_only_what_the_product_runs():
+    """hotstuff_amd/csrc/*.h also serve tests/emu (the device headers compiled for the CPU), which invites cores of kernels that
+    left the product to linger there: round 5 found ~110 lines of them (the quad and one-lane key-cache cores) and moved them
+    to tests/emu/retired_cores.h.  Crude reachability over names: every function a product header defines is named by a kernel,
+    by the host side, or by something they reach - or by the emulation AND documented as its reference restatement (rlc.h's
+    stage list; the registration's per-entry form)."""
+    csrc = os.path.join(ROOT, "hotstuff_amd", "csrc")
+    src = {f: open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith((".h", ".hip"))}
+    pat = re.compile(r'^(?:template\s*<[^>]*>\s*)?(?:extern "C" |HS_HD|HS_Q|HS_D|__device__|__global__|static|inline)[^\n;{]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\(', re.M)
+    funcs = {}
+    for f, s in src.items():
+        for m in pat.finditer(s):
+            i, semi = s.find("{", m.end()), s.find(";", m.end())
+            if i < 0 or 0 <= semi < i:
+                continue
+            depth, j = 0, i
+            while j < len(s):
+                depth += s[j] == "{"
+                depth -= s[j] == "}"
+                if depth == 0:
+                    break
+                j += 1
+            funcs.setdefault(m.group(1), []).append((f, s[i:j + 1]))
+    roots = [n for n, l in funcs.items() if any(f.endswith(".hip") for f, _ in l)]
+    seen, stack = set(), list(roots)
+    while stack:
+        n = stack.pop()
+        if n in seen:
+            continue
+        seen.add(n)
+        for _, body in funcs.get(n, []):
+            stack += [t for t in set(re.findall(r"\b[A-Za-z_][A-Za-z0-9_]*\b", body)) if t in funcs and t not in seen]
+    dead = sorted(n for n in funcs if n not in seen)
+    # reference restatements the emulation checks the device's parallel forms against, named as such in their headers;
+    # one-line members of the quad vocabulary (both twins) that no current kernel happens to use
+    allowed = {"rlc_b_point", "rlc_bucket_fold", "rlc_final_quad", "keyset_affine_entry", "ge_is_identity", "ge_is_small_order", "sc_pop_digit3",
+               "q_add", "q_sub", "q_pick", "q_eq", "q_load", "q_cached_neg"}
+    assert set(dead) <= allowed, sorted(set(dead) - allowed)
