@@ -757,7 +757,6 @@ static bool oct_split_for(size_t n, size_t simds, int pick) {
     if (n * 2 <= simds * 8) return true;
     return pick != 0;
 }
-static const size_t kQuadMaxBatch = 32768;
 // the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
 // (enqueue_cold): -19 % on the call's p50 up to 16,384 signatures past the round (1.03 against 1.27 ms at 66,667 ... 73,728,
 // 1.07 against 1.31 at 81,920), nothing at 32,768 (profiles/r3_concurrent_ab.txt)
