@@ -152,10 +152,15 @@ def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=14.0):
         openssl = round(synth.openssl_verify_rate(dg, pk, sg, n, stride, 0.5), 1)
     except Exception as e:      # noqa: BLE001 - a bracket, not a result
         openssl = "unavailable: %s" % e
+    try:        # a second bracket: libsodium's single verification (ref10 lineage, as dalek's serial backend)
+        sodium = round(synth.sodium_verify_rate(dg, pk, sg, n, stride, 0.5), 1)
+    except Exception as e:      # noqa: BLE001
+        sodium = "unavailable: %s" % e
     return {
         "value": round(allc, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
         "one_core": round(one, 1), "parallel_efficiency": round(allc / (cores * one), 3),
         "openssl_evp_digestverify_one_core": openssl,
+        "libsodium_verify_detached_one_core": sodium,
         "os_cpu_count": os.cpu_count(),
         "sample": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1 verify_strict, 51-bit limbs, "
                   "-O3 -march=native): the bench's own %d tuples tiled x%d = %d verifications per pass (>= 1,000 per "
@@ -625,7 +630,7 @@ def small_batch_crossover(_lib, synth):
     ks.close()
     return {"rows": rows, "measured_crossover_n": cross,
             "library_hint": {"cold": lib.hs_ed25519_min_gpu_batch(0), "key_cache": lib.hs_ed25519_min_gpu_batch(1)},
-            "cpu": "oracle per-signature strict verification, one core (dalek itself is ~1.5-2x faster per signature)"}
+            "cpu": "oracle per-signature strict verification, one core (cpu_baseline brackets it with OpenSSL's and libsodium's single verification on the same cores; dalek cannot be built here)"}
 
 
 def rlc_ab(_lib, torch, synth, dev, sizes=(6667, 66667), calls=40):
