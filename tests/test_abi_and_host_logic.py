@@ -362,7 +362,8 @@ def test_nothing_after_init_synchronises_the_device_or_uses_the_legacy_stream():
 def test_the_plain_makefile_builds_what_build_engine_builds():
     """hotstuff_amd/csrc/Makefile is the recipe a `crypto/build.rs` can run without Python: the same translation
     units, the same compiler flags and the same disassembly gate as __graft_entry__.build_engine - kept equal here, so the two
-    cannot drift.  (The real build through it was checked by hand: a library of the same size with the same 81 exports.)"""
+    cannot drift.  (The real build through it was checked by hand at the round's last code: a library of the same size, the same 81 exports and - code object
+    for code object - byte-identical device code.)"""
     import subprocess
     import __graft_entry__ as g
     mk = open(os.path.join(g.CSRC, "Makefile")).read()
