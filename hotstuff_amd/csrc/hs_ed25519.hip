@@ -751,11 +751,17 @@ static std::atomic<int> g_autotune{1};                 // HS_ED25519_AUTOTUNE=0:
 // Round 4 inferred it from an instruction-feed probe; the driver's box then ran the inferred form 14 % slower than the probe's
 // class promised.  Round 5 measures the thing itself: hs_ed25519_autotune times both forms on a canned
 // 6,667-signature batch at init and `pick` is the faster one on THIS device (-1 = not measured: the split form).
-static bool oct_split_for(size_t n, size_t simds, int pick) {
+// `whole_chip`: the context's stream may use every CU.  On a stream confined to a slice of the chip (a narrow pool context's
+// 32 CUs, a tenant's share) the measurement does not transfer: above half a slot per SIMD the split form there takes 0.365 - 0.370 ms
+// against the one-wavefront form's 0.255 - 0.259 (1,024 and 667 signatures on one 32-CU slice, a GPU whose whole-chip pick is a 4 %
+// matter; below half a slot the split form wins on a slice as on the chip, 0.215 against 0.255: profiles/r5_y_narrow_oct_ab.md) - which
+// is what a lone synchronous 1,024-signature host call paid on every GPU whose pick was the split form (0.385 against 0.271 ms,
+// `end_to_end_call_p50_ms_one_sync_caller_1024`).  A confined context takes the split form up to half a slot and never above.
+static bool oct_split_for(size_t n, size_t simds, int pick, bool whole_chip = true) {
     const int forced = g_oct_split.load();
     if (forced >= 0) return forced != 0;
     if (n * 2 <= simds * 8) return true;
-    return pick != 0;
+    return whole_chip && pick != 0;
 }
 // the largest sliver past whole rounds of one-lane wavefronts that goes through the four-lane form inside the stage-2 launch
 // (enqueue_cold): -19 % on the call's p50 up to 16,384 signatures past the round (1.03 against 1.27 ms at 66,667 ... 73,728,
@@ -1229,7 +1235,8 @@ int hs::enqueue_cold(hs_ed25519_ctx *ctx, msg_src msgs, const uint8_t *d_pks, co
         const int ksel = ctx->kernel == HS_K_CACHED_C ? HS_K_AUTO : ctx->kernel;      // a key-cache selector leaves cold calls alone
         const bool oct_forced = ksel == HS_K_OCT || ksel == HS_K_OCT_SPLIT;
         if (n <= simds * 8 && (oct_forced || (ksel == HS_K_AUTO && !ctx->several_in_flight && g_oct_max_batch.load() >= n))) {
-            const bool split = oct_forced ? ksel == HS_K_OCT_SPLIT : oct_split_for(n, simds, g_oct_pick[ctx->slot].load(std::memory_order_relaxed));
+            const bool split = oct_forced ? ksel == HS_K_OCT_SPLIT
+                                          : oct_split_for(n, simds, g_oct_pick[ctx->slot].load(std::memory_order_relaxed), simds >= (size_t)g_devs[ctx->slot].cus * 4);
             if (split)
                 HS_HIP(launch1((const void *)k_verify_fused8h, dim3(np / 8), dim3(128), a3, st, ev ? ev[0] : nullptr, ev ? ev[2] : nullptr),
                        "launch k_verify_fused8h");
