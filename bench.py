@@ -162,10 +162,9 @@ def cpu_baseline(dg, pk, sg, n, stride, mode, budget_s=14.0):
         "openssl_evp_digestverify_one_core": openssl,
         "libsodium_verify_detached_one_core": sodium,
         "os_cpu_count": os.cpu_count(),
-        "sample": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1 verify_strict, 51-bit limbs, "
-                  "-O3 -march=native): the bench's own %d tuples tiled x%d = %d verifications per pass (>= 1,000 per "
-                  "thread), %d passes on %d threads (= sched_getaffinity capped by the cgroup quota); 1-thread figure "
-                  "from %d passes over the untiled batch" % (n, tile, big_n, rn, cores, r1),
+        "sample": "oracle port of verify_strict: %d tuples x%d = %d per pass, %d passes on %d threads; one core: %d passes" % (n, tile, big_n, rn, cores, r1),
+        "sample_detail": "oracle/ed25519_oracle.c (C restatement of ed25519-dalek 1.0.1, 51-bit limbs, -O3 -march=native)",
+        "threads_are": "sched_getaffinity capped by the cgroup quota",
     }
 
 
@@ -189,6 +188,100 @@ def cpu_qc_latency(dg, pk, sg, n, calls=5):
     med = lambda v: sorted(v)[len(v) // 2]
     return {"kind": "port", "algorithm": "dalek verify_batch restated: 128-bit RLC + Pippenger (w = 8)",
             "p50_ms_one_core": round(med(one) * 1e3, 3), "p50_ms_all_cores": round(med(many) * 1e3, 3), "cores": cores}
+
+
+def cpu_tc_latency(rnd, hq, pk, sg, n, calls=3):
+    """The CPU twin of `tc_verify_latency`: the reference's loop itself (consensus/src/messages.rs:307-313) - per vote one SHA-512 of
+    (round || high_qc_round), then Signature::verify = verify_strict - on one core (oracle port), and the same loop cut over every
+    core this process may use."""
+    import struct
+    orc = load_oracle()
+    S = ctypes.c_size_t
+    cores = host_cores()
+    out = ctypes.create_string_buffer(n)
+    hq_b = struct.pack("<%dQ" % n, *hq)
+    one, many = [], []
+    for th, acc, reps in ((1, one, calls), (cores, many, calls * 3)):
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            orc.hs_oracle_verify_tc(ctypes.c_uint64(rnd), hq_b, pk, sg, S(n), out, th)
+            acc.append(time.perf_counter() - t0)
+            assert all(out.raw), "oracle rejected a valid TC vote"
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"kind": "port", "algorithm": "the reference's loop: n x (SHA-512(round || high_qc_round), verify_strict)",
+            "p50_ms_one_core": round(med(one) * 1e3, 3), "p50_ms_all_cores": round(med(many) * 1e3, 3), "cores": cores}
+
+
+def tc_latency(_lib, torch, dev, validators=10000, calls=200):
+    """TC::verify (consensus/src/messages.rs:290-315) at N validators: n = floor(2N/3) + 1 votes, every vote signed over ITS OWN
+    digest SHA-512(round || high_qc_round_i)[..32], strict semantics.  The per-vote digests are built on the device
+    (hs_ed25519_verify_tc[_cached]: the host passes the round and n high_qc_rounds).  p50 over `calls` calls, device-resident and
+    through the host-pointer C ABI, cold and with the committee registered; the CPU twin beside it."""
+    import hashlib
+    import struct
+    import synth
+    n = 2 * validators // 3 + 1
+    rnd = 1_000_003
+    hq = [rnd - 1 - (i * 7919) % 50 for i in range(n)]
+    dgs = b"".join(hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq)
+    seeds = b"".join(synth.key_seed(700_000_000 + i) for i in range(n))
+    pk = _lib.public_keys(seeds, n)
+    sg = _lib.sign_batch(b"".join(seeds[32 * i:32 * i + 32] + pk[32 * i:32 * i + 32] for i in range(n)), dgs, n, shared=False)
+    hq_b = struct.pack("<%dQ" % n, *hq)
+    lib = _lib.lib()
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys + [synth.key_seed(710_000_000 + i) for i in range(validators - n)])
+    idx_b = struct.pack("<%dI" % n, *range(n))
+    b_hq, b_pk, b_sg, b_ix = (ctypes.create_string_buffer(x, len(x)) for x in (hq_b, pk, sg, idx_b))
+    a_hq, a_pk, a_sg, a_ix = (ctypes.addressof(x) for x in (b_hq, b_pk, b_sg, b_ix))
+    med = lambda v: sorted(v)[len(v) // 2]
+    p99 = lambda v: sorted(v)[int(len(v) * 0.99)]
+    res = {"n_validators": validators, "signatures": n, "calls": calls,
+           "what": "TC::verify: per-vote digests SHA-512(round || high_qc_round)[..32] built on the device, strict"}
+    for name, call in (("cold", lambda: lib.hs_ed25519_verify_tc(rnd, a_hq, a_pk, a_sg, n, None)),
+                       ("key_cache", lambda: lib.hs_ed25519_verify_tc_cached(ks.handle, rnd, a_hq, a_ix, a_sg, n, None))):
+        lat = []
+        for i in range(calls + 20):
+            t0 = time.perf_counter()
+            rc = call()
+            dt = time.perf_counter() - t0
+            assert rc == 1, "TC rejected (%s, host API): %d %s" % (name, rc, _lib.last_error())
+            if i >= 20:
+                lat.append(dt)
+        res["p50_ms_host_api_" + name], res["p99_ms_host_api_" + name] = round(med(lat) * 1e3, 4), round(p99(lat) * 1e3, 4)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_hq, d_pk, d_sg = t(hq_b), t(pk), t(sg)
+    d_ki = torch.arange(n, dtype=torch.int32, device=dev)
+    bm = torch.zeros(8 * ((n + 63) // 64), dtype=torch.uint8, device=dev)
+    nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = _lib.DeviceContext(n)
+    st = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    torch.cuda.synchronize(dev)
+    for name, kw in (("cold", {}), ("key_cache", {"keyset": ks, "d_key_idx": d_ki.data_ptr()})):
+        lat = []
+        ctx.set_profiling(calls + 20)
+        with torch.cuda.stream(st):
+            for i in range(calls + 20):
+                nr.zero_()
+                st.synchronize()
+                t0 = time.perf_counter()
+                ctx.verify_tc(rnd, d_hq.data_ptr(), d_pk.data_ptr(), d_sg.data_ptr(), n, bm.data_ptr(), nr.data_ptr(), ctx.stream, **kw)
+                bad = int(nr.item())
+                dt = time.perf_counter() - t0
+                assert bad == 0, "device-resident TC (%s): %d rejects" % (name, bad)
+                if i >= 20:
+                    lat.append(dt)
+        kt = ctx.kernel_times()
+        res["p50_ms_" + name], res["p99_ms_" + name] = round(med(lat) * 1e3, 4), round(p99(lat) * 1e3, 4)
+        res["kernel_ms_" + name] = round((kt[0] + kt[1]) / max(1, kt[2]), 4)      # the verification kernel(s); k_tc_digests runs ahead of them
+    assert all((int(w) & ((1 << 64) - 1)) == (1 << 64) - 1 for w in bm.view(torch.int64)[: n // 64].tolist()), "TC bitmap"
+    ctx.close()
+    ks.close()
+    try:
+        res["cpu"] = cpu_tc_latency(rnd, hq, pk, sg, n)
+    except Exception as e:      # noqa: BLE001
+        res["cpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def qc_latency(_lib, torch, synth, dev, validators=10000, calls=200):
@@ -491,9 +584,9 @@ def sharded_committee(_lib, torch, dist, synth, sharding, dev, rank, world, vali
 
 
 def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
-               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (4, 32, 16), (1, 64, 16), (1, 128, 8),
-                         (1, 256, 16)),
-               pinned_shapes=((1, 64, 16), (1, 128, 8), (1, 256, 16), (1, 64, 4), (4, 32, 16))):
+               inflight=((16, 2, 2), (1, 32, 2), (16, 4, 4), (1, 64, 4), (16, 8, 8), (16, 16, 16), (16, 32, 16), (4, 64, 16), (4, 128, 16),
+                         (1, 128, 8), (1, 256, 16), (1, 512, 16)),
+               pinned_shapes=((1, 256, 16), (1, 512, 16), (1, 64, 4), (4, 128, 16))):
     """SURVEY.md 8d's metric proper: host buffers in, host verdict out, through the host-pointer C ABI.
     `threads` NATIVE host threads (tools/libhs_loadgen.so, a client of the public ABI - interpreter threads would measure
     the interpreter lock) each verify their own 1,024-tuple batch in a loop; every call stages into pinned memory,
@@ -523,6 +616,10 @@ def end_to_end(_lib, batches, n, stride, mode, threads=16, seconds=0.8,
                                       seconds if th == threads else seconds / 2)
         return {"host_threads": th, "in_flight_per_thread": k, "batches_per_launch": bpl, "calls": calls, "seconds": round(el, 3),
                 "call_p50_ms": round(p50, 4), "value": round(calls * n / el, 1)}
+    # untimed: the pools (the narrow pool's sixteen CU-masked streams are created at the first small call), their staging, the
+    # workspaces of every kernel form - so that the first row, ONE synchronous caller, times calls and not the pool's creation
+    for th, k, bpl in ((threads, 4, 4), (threads, 16, 16), (1, 1, 1)):
+        _lib.loadgen(None, a[0], stride, a[1], a[2], n, len(batches), mode, th, k, bpl, 0.15)
     for th, k, bpl in shapes:
         row = run(a, th, k, bpl)
         out.setdefault("by_threads", []).append(row)
@@ -716,13 +813,17 @@ def sharded_c_abi(ngpus, ndev, validators=100000, timeout_s=150):
 
 
 PMC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",),
-            ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"))
+            ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"),
+            # round 6: where a wavefront's cycles go - parked (s_waitcnt / barrier), issuing, and what it issues.
+            # MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (disjoint), all in quad-cycles
+            ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA",
+             "SQ_INST_CYCLES_VMEM_RD", "SQ_IFETCH"))
 CALIBRATION = os.path.join("profiles", "pmc_calibration.json")
 
 
 def pmc_passes(timeout_s=150):
-    """Counters of every kernel whose roofline this line quotes, measured IN THIS RUN: three rocprofv3 --pmc passes (FETCH_SIZE
-    and WRITE_SIZE do not fit one pass; the SQ set is the third; no trace domains beside the counters) over SOLO launches
+    """Counters of every kernel whose roofline this line quotes, measured IN THIS RUN: four rocprofv3 --pmc passes (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass; two SQ sets of at most eight; no trace domains beside the counters) over SOLO launches
     (tools/pmc_solo.py bench: one launch at a time, the stream drained in between, so the chip-wide counters of a dispatch hold
     that dispatch only), summed over a counter's instances, the first two dispatches of each kernel@grid dropped.
     FETCH_SIZE / WRITE_SIZE are corrected with the calibration in profiles/pmc_calibration.json (FETCH_SIZE reports half of the
@@ -843,7 +944,12 @@ def summarise_extras(cfg, detail, pmc):
                     "qc_kernel_ms_cold": q["kernel_ms_device_resident"], "qc_kernel_ms_key_cache": c["kernel_ms_device_resident"],
                     "qc_kernel_cold": q["kernel"], "qc_kernel_key_cache": c.get("kernel"),
                     "one_sync_caller_verifies_per_s_qc_cold": q["verifies_per_s_at_p50_host_api"],
-                    "one_sync_caller_verifies_per_s_qc_key_cache": c.get("verifies_per_s_at_p50_host_api")})
+                    "one_sync_caller_verifies_per_s_qc_cached": c.get("verifies_per_s_at_p50_host_api")})
+        cpu = q.get("cpu") or {}
+        if "p50_ms_one_core" in cpu:      # dalek's verify_batch as computed (RLC + Pippenger, oracle port), the CPU twin of the QC rows
+            cfg["cpu_qc_verify_batch_p50_ms_one_core"], cfg["cpu_qc_verify_batch_p50_ms_all_cores"], cfg["cpu_cores"] = cpu["p50_ms_one_core"], cpu["p50_ms_all_cores"], cpu["cores"]
+        elif "error" in cpu:
+            cfg["cpu_qc_error"] = cpu["error"][:120]
         alt = q.get("alternating_calls") or {}
         if "p50_ms_cold" in alt:      # the cold-instruction regime: each QC kernel right after the other one
             cfg["qc_verify_p50_ms_cold_alternating"], cfg["qc_verify_p50_ms_key_cache_alternating"] = alt["p50_ms_cold"], alt["p50_ms_key_cache"]
@@ -865,16 +971,41 @@ def summarise_extras(cfg, detail, pmc):
             c_ = pmc_pick(pmc, name, wg)
             if c_:
                 for ctr, short in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_BUSY_CYCLES", "busy_cycles"),
-                                   ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_WAVES", "waves")):
+                                   ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_WAVES", "waves"), ("SQ_WAIT_ANY", "wait_any"),
+                                   ("SQ_ACTIVE_INST_ANY", "active_any"), ("SQ_ACTIVE_INST_VALU", "active_valu"), ("SQ_ACTIVE_INST_VMEM", "active_vmem"),
+                                   ("SQ_ACTIVE_INST_LDS", "active_lds"), ("SQ_ACTIVE_INST_SCA", "active_sca"), ("SQ_INST_CYCLES_VMEM_RD", "cycles_vmem_rd"),
+                                   ("SQ_IFETCH", "ifetch")):
                     if ctr in c_:
                         cfg["sq_%s_%s" % (name[2:], short)] = round(c_[ctr])
+                # do the three disjoint states account for the wavefronts' cycles?  (1.0 = they do; the driver's box decides what a
+                # slower key-cache QC is made of: parked on memory / barriers, stalled at issue, or issuing)
+                if all(k_ in c_ for k_ in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")) and c_["SQ_WAVE_CYCLES"] > 0:
+                    cfg["sq_%s_states_sum_frac" % name[2:]] = round((c_["SQ_WAIT_ANY"] + c_["SQ_WAIT_INST_ANY"] + c_["SQ_ACTIVE_INST_ANY"]) / c_["SQ_WAVE_CYCLES"], 3)
+    tc = detail.get("tc_verify_latency", {})
+    if "error" in tc:
+        cfg["tc_error"] = tc["error"][:120]
+    elif tc:
+        cfg.update({"tc_validators": tc["n_validators"], "tc_signatures": tc["signatures"],
+                    "tc_verify_p50_ms_cold": tc["p50_ms_cold"], "tc_verify_p50_ms_key_cache": tc["p50_ms_key_cache"],
+                    "tc_verify_p50_ms_cold_host_api": tc["p50_ms_host_api_cold"], "tc_verify_p50_ms_key_cache_host_api": tc["p50_ms_host_api_key_cache"],
+                    "tc_kernel_ms_cold": tc["kernel_ms_cold"], "tc_kernel_ms_key_cache": tc["kernel_ms_key_cache"]})
+        cpu = tc.get("cpu") or {}
+        if "p50_ms_one_core" in cpu:
+            cfg["cpu_tc_verify_p50_ms_one_core"], cfg["cpu_tc_verify_p50_ms_all_cores"] = cpu["p50_ms_one_core"], cpu["p50_ms_all_cores"]
+            cfg.setdefault("cpu_cores", cpu["cores"])
+        elif "error" in cpu:
+            cfg["cpu_tc_error"] = cpu["error"][:120]
     mp = detail.get("multi_process", {})
     for r_ in mp.get("rows", []) if isinstance(mp, dict) else []:
+        if r_.get("processes") == 4 and r_.get("tenancy_hint") and "value" in r_:
+            cfg["four_tenants_bursts_of_4_verifies_per_s"] = r_["value"]
+            cfg["four_tenants_bursts_of_4_max_over_min"] = round(max(r_["per_process"]) / max(1.0, min(r_["per_process"])), 3)
+    for r_ in mp.get("rows_bursts_of_16", []) if isinstance(mp, dict) else []:
         if r_.get("processes") == 4 and r_.get("tenancy_hint") and "value" in r_:
             cfg["four_tenants_verifies_per_s"] = r_["value"]
             cfg["four_tenants_max_over_min"] = round(max(r_["per_process"]) / max(1.0, min(r_["per_process"])), 3)
     sr = detail.get("streamed_rounds", {})
-    for key, short in (("cold_zero_copy", "streamed_rounds_cold_signatures_per_s"), ("key_cache_zero_copy", "streamed_rounds_key_cache_signatures_per_s")):
+    for key, short in (("cold_zero_copy", "streamed_cold_signatures_per_s"), ("key_cache_zero_copy", "streamed_key_cache_signatures_per_s")):
         if isinstance(sr.get(key), dict):
             cfg[short] = sr[key]["signatures_per_s"]
     ab = detail.get("rlc_ab", {})
@@ -884,6 +1015,55 @@ def summarise_extras(cfg, detail, pmc):
     sb = detail.get("small_batch_crossover", {})
     if "measured_crossover_n" in sb:
         cfg["small_batch_crossover_n_cold"], cfg["small_batch_crossover_n_key_cache"] = sb["measured_crossover_n"]["cold"], sb["measured_crossover_n"]["key_cache"]
+
+
+# What the driver's record keeps of the line: the first 24 keys of `config`, 40 characters of a key, 120 of a string (BENCH_r05's
+# `parsed` lost both QC p50s to that).  So the keys that ARE the metric come first, in this order, and nothing in the objects the
+# record keeps is longer than it may be (tests/test_bench_line.py holds finalize_line to that).
+CONFIG_FIRST = (
+    "workload", "qc_validators", "qc_signatures",
+    "qc_verify_p50_ms_cold", "qc_verify_p50_ms_key_cache", "qc_verify_p50_ms_cold_host_api", "qc_verify_p50_ms_key_cache_host_api",
+    "cpu_qc_verify_batch_p50_ms_one_core", "cpu_qc_verify_batch_p50_ms_all_cores",
+    "tc_verify_p50_ms_cold", "tc_verify_p50_ms_key_cache", "cpu_tc_verify_p50_ms_one_core",
+    "end_to_end_verifies_per_s_best", "one_sync_caller_1024_verifies_per_s", "one_sync_caller_verifies_per_s_qc_cold",
+    "four_tenants_verifies_per_s", "int_roofline_mad_frac", "int_roofline_issue_frac", "entry_point", "cpu_cores",
+    "cpu_tc_verify_p50_ms_all_cores", "e2e_one_thread_tickets_verifies_per_s", "qc_verify_p50_ms_cold_alternating", "tc_verify_p50_ms_cold_host_api")
+KEY_MAX, STR_MAX = 40, 120
+TOP_FIRST = ("metric", "value", "value_host_to_host", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def finalize_line(out, strict=False):
+    """Order the line for the record: `value_host_to_host` beside `value`, the metric's keys first in `config`.  A key or a string
+    the driver would cut is a programming error: `strict` (the unit test) raises on it; the bench run itself cuts it here, where
+    the cut is chosen and counted (`line_cuts`), rather than lose a finished measurement over a name."""
+    cfg = out.get("config", {})
+    ordered = {k: cfg[k] for k in CONFIG_FIRST if k in cfg}
+    ordered.update((k, v) for k, v in cfg.items() if k not in ordered)
+    out["config"] = ordered
+    if "end_to_end_verifies_per_s_best" in ordered:
+        out["value_host_to_host"] = ordered["end_to_end_verifies_per_s_best"]      # SURVEY 8d's metric proper: host buffers in, host verdict out
+    res = {k: out[k] for k in TOP_FIRST if k in out}
+    res.update((k, v) for k, v in out.items() if k not in res)
+    cuts = 0
+    for name in ("config", "roofline", "cpu_baseline"):
+        if not isinstance(res.get(name), dict):
+            continue
+        fixed = {}
+        for k, v in res[name].items():
+            if len(k) > KEY_MAX:
+                if strict:
+                    raise ValueError("bench line: %s key %r is longer than the %d characters the driver's record keeps" % (name, k, KEY_MAX))
+                k, cuts = k[:KEY_MAX], cuts + 1
+            if isinstance(v, str) and len(v) > STR_MAX:
+                if strict:
+                    raise ValueError("bench line: %s[%r] is %d characters, the driver's record keeps %d: %r" % (name, k, len(v), STR_MAX, v))
+                v, cuts = v[:STR_MAX], cuts + 1
+            fixed[k] = v
+        res[name] = fixed
+    if cuts:
+        res["line_cuts"] = cuts
+    return res
 
 
 def launcher_command(ngpus, argv, port=None):
@@ -955,6 +1135,9 @@ def main():
                     help="batches per hs_ed25519_verify_device_batches_cached launch in the committee_cached extra")
     ap.add_argument("--cached-variants", type=int, default=16,
                     help="committee_cached extra: distinct message sets per batch of signers (1 = the same certificates re-verified)")
+    ap.add_argument("--inputs", choices=("hbm", "pinned"), default="hbm",
+                    help="measurement aid: 'pinned' leaves the headline's inputs in pinned host memory (hs_ed25519_host_alloc) and the kernels "
+                         "read them over PCIe, as the host API's zero-copy calls do - never the figure of record (`value` is HBM-resident)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qc", action="store_true", help="skip the QC-verify p50 latency extra")
     ap.add_argument("--no-cached", action="store_true", help="skip the committee-key-cache extra")
@@ -993,6 +1176,9 @@ def main():
         try:
             mp_early = multi_process(args.batch)
             mp_early["ran"] = "before this process initialised the GPU (no fifth GPU process beside the tenants)"
+            # the same four tenants submitting bursts of SIXTEEN (4 threads x 32 tickets each): what a node that batches its vote
+            # ingest (hotstuff_amd/ingest.py, consensus/src/core.rs:203-225) hands over at once
+            mp_early["rows_bursts_of_16"] = multi_process(args.batch, procs=(4,), shape=(4, 32, 16), tenancy_modes=(True,))["rows"]
         except Exception as e:        # extras never cost the headline line
             mp_early = {"error": "%s: %s" % (type(e).__name__, e)}
     # stdout carries exactly one line: rank 0's JSON.  Everything else any rank or library writes to
@@ -1084,6 +1270,9 @@ def main():
 
     # raw addresses once, outside the timed loop (the step itself is one C-ABI call)
     p_in = [tuple(x.data_ptr() for x in d) for d in d_in]
+    if args.inputs == "pinned":
+        pinned_in = [tuple(_lib.PinnedBuffer(x) for x in bt) for bt in batches + more]
+        p_in = [tuple(x.addr for x in d) for d in pinned_in]
     p_dg, p_pk, p_sg = p_in[0]
     p_bm = [b.data_ptr() for b in bitmaps]
     p_nr = [nrej[j:].data_ptr() for j in range(ns * K)]
@@ -1138,10 +1327,22 @@ def main():
     enqueue_s = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    rank_info = None
     if exchange:
+        elapsed_local = elapsed
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank's own elapsed time and its GPU's init-time kernel pick, gathered: the record then shows a lagging GPU, and a
+        # completed all-gather over the control plane is the proof of how many ranks it really spans
+        try:
+            pick = {"k_verify_fused8": 0.0, "k_verify_fused8h": 1.0}.get(_lib.config_dump()["devices"][0].get("oct_pick"), -1.0)
+        except Exception:      # noqa: BLE001
+            pick = -2.0
+        mine = torch.tensor([elapsed_local, pick, float(device_index)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_info = [[float(v) for v in x.tolist()] for x in allr]
 
     # correctness of what was timed: every synthetic signature is valid
     assert int(nrej.sum().item()) == 0, "engine rejected valid signatures during the timed region"
@@ -1319,8 +1520,8 @@ def main():
     prep_pmc = pmc_pick(pmc, "k_prepare_batches")
     if head_pmc and "bytes" in head_pmc:
         traffic = head_pmc["bytes"]
-        traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, solo launches, x %.3f / x %.2f (%s)" % (
-            pmc["calibration"]["fetch_factor"], pmc["calibration"]["write_factor"], CALIBRATION)
+        traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, solo launches, x %.3f / x %.2f (pmc_calibration.json)" % (
+            pmc["calibration"]["fetch_factor"], pmc["calibration"]["write_factor"])
     elif pmc and "error" in pmc:
         traffic_src = "unmeasured: " + pmc["error"][:90]
     e2e = None
@@ -1347,14 +1548,16 @@ def main():
             "dtype": "u32 limbs (radix 2^25.5), u64 accumulate",
             "data": "synthetic",
             "config": {
-                "workload": ("QC shape: %d-signature batches over one digest, batch semantics, HBM-resident; %d batches/launch on %d CU-masked streams" % (n, K, ns)
+                # (<= 120 characters; says which rate `value` is)
+                "workload": ("QC shape: %d-sig batches, batch law; value = HBM-resident rate; value_host_to_host = host buffers in, verdict out" % n
                              if shared else
-                             "BASELINE configs[1]: %d-tuple (digest,pk,sig) batches, strict, HBM-resident, %d distinct batches per GPU; %d batches/launch on %d CU-masked streams" % (n, D if K > 1 else ns, K, ns)),
+                             "configs[1]: %d-tuple batches, strict; value = HBM-resident rate; value_host_to_host = host buffers in, verdict out" % n),
+                "workload_detail": "%d distinct batches per GPU, %d per launch, %d CU-masked streams" % (D if K > 1 else ns, K, ns),
                 "signatures_per_batch": n, "batches_per_step_per_gpu": B, "verifications_per_step_per_gpu": B * n,
                 "distinct_tuples_per_gpu": (D if K > 1 else ns) * n, "streams": ns, "cu_partitions": args.partitions,
                 "timed_region_s": round(elapsed, 4), "batches_per_launch": K, "launches_in_timed_region_per_gpu": launches_per_step * args.steps,
-                "entry_point": "hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device",
-                "exchange": "none on this workload (independent batches per rank, SURVEY 8e); sharded_committee / sharded_c_abi have it" if exchange else "none (1 GPU)",
+                "entry_point": ("hs_ed25519_verify_device_batches" if K > 1 else "hs_ed25519_verify_device") + (" (inputs in PINNED HOST memory: not of record)" if args.inputs == "pinned" else ""),
+                "exchange": "none on this workload (independent batches per rank); sharded_committee / sharded_c_abi have it" if exchange else "none (1 GPU)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name,
@@ -1370,7 +1573,7 @@ def main():
                 "avg_kernel_ms": round(avg_verify_ms, 4), "avg_k_prepare_ms": round(avg_prepare_ms, 4) if avg_prepare_ms > 0 else None,
                 "launches_timed": launches, "event_stride": args.event_stride,
                 "timing": "dispatch timestamps (hipExtLaunchKernel events on the launch stream) of sampled launches in the timed region",
-                "note": "integer-VALU bound (SURVEY 8d): HBM fraction tiny by construction; config.int_roofline_* are the bounds that bind",
+                "note": "integer-VALU bound (SURVEY 8d): HBM fraction tiny by construction; config.int_roofline_* are what binds",
             },
             "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
@@ -1405,14 +1608,16 @@ def main():
             for r_ in e2e.get("by_threads", []):
                 shape = (r_["host_threads"], r_["in_flight_per_thread"], r_["batches_per_launch"])
                 if shape == (16, 8, 8):
-                    cfg["end_to_end_verifies_per_s_16_threads_x_8_tickets"] = r_["value"]
+                    cfg["e2e_16_threads_x_8_tickets_verifies_s"] = r_["value"]
                 if shape == (1, 1, 1):
-                    cfg["end_to_end_verifies_per_s_one_sync_caller_1024"] = r_["value"]
-                    cfg["end_to_end_call_p50_ms_one_sync_caller_1024"] = r_["call_p50_ms"]
-                if shape == (1, 256, 16):
-                    cfg["end_to_end_verifies_per_s_one_thread_256_tickets"] = r_["value"]
+                    cfg["one_sync_caller_1024_verifies_per_s"] = r_["value"]
+                    cfg["one_sync_caller_1024_call_p50_ms"] = r_["call_p50_ms"]
+                if shape[0] == 1 and shape[1] > 1 and r_["value"] > cfg.get("e2e_one_thread_tickets_verifies_per_s", 0):
+                    cfg["e2e_one_thread_tickets_verifies_per_s"] = r_["value"]      # ONE host thread, ordinary (unpinned) buffers, tickets in bursts
+                    cfg["e2e_one_thread_tickets_shape"] = "%d tickets, bursts of %d" % (shape[1], shape[2])
             if "value" in e2e:
                 cfg["end_to_end_verifies_per_s_best"] = e2e["value"]
+                cfg["end_to_end_best_shape"] = "%d threads x %d tickets, bursts of %d" % (e2e["host_threads"], e2e["in_flight_per_thread"], e2e["batches_per_launch"])
             if "error" in e2e:
                 cfg["end_to_end_error"] = e2e["error"][:120]
         if world == 1 and not args.no_cached:
@@ -1426,7 +1631,7 @@ def main():
                     cfg["cached_qc_66667_traffic_over_algorithmic"] = lc["roofline"].get("traffic_over_algorithmic")
                     cfg["cached_qc_66667_table_gather_GBps"] = lc["roofline"].get("design_traffic_GBps")
                 if isinstance(lc.get("four_in_flight_two_launch_form_signatures_per_s"), float):
-                    cfg["cached_qc_66667_four_in_flight_signatures_per_s"] = lc["four_in_flight_two_launch_form_signatures_per_s"]
+                    cfg["cached_qc_66667_4_in_flight_sigs_per_s"] = lc["four_in_flight_two_launch_form_signatures_per_s"]
             detail["committee_cached"] = cached
         if world == 1 and not args.no_qc:
             # streamed_rounds first: a ring (and its 5 GB key set) built while the process's first extra context of QC size is
@@ -1434,6 +1639,7 @@ def main():
             # profiles/r3_streamed_probe.txt; the round-2 tree behaves identically): a coupling in the runtime, not the ring's steady state
             for key, fn in (("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
                             ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
+                            ("tc_verify_latency", lambda: tc_latency(_lib, torch, dev)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
                             ("multi_process", lambda: mp_early if mp_early is not None else multi_process(n))):
@@ -1452,6 +1658,12 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(dg, pk, sg, n, stride, mode)
                 out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+                # the CPU twins of the two latency rows (the reference's verify_batch and TC loop, oracle ports), beside the rate
+                for src, dst in (("cpu_qc_verify_batch_p50_ms_one_core", "qc_verify_batch_p50_ms_one_core"),
+                                 ("cpu_qc_verify_batch_p50_ms_all_cores", "qc_verify_batch_p50_ms_all_cores"),
+                                 ("cpu_tc_verify_p50_ms_one_core", "tc_verify_p50_ms_one_core"), ("cpu_tc_verify_p50_ms_all_cores", "tc_verify_p50_ms_all_cores")):
+                    if src in cfg:
+                        out["cpu_baseline"][dst] = cfg[src]
             except Exception as e:
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ---- multi-GPU extras, AFTER the headline is complete.  Each runs under a deadline on rank 0: if a collective or
@@ -1461,6 +1673,14 @@ def main():
         out["config"].update({"ranks_world": world, "ranks_gpus_visible": ndev, "ranks_control_plane": backend if exchange else "none",
                               "ranks_virtual": virtual,
                               "ranks_launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"})
+        if rank_info:
+            per_rank = [n * B * args.steps / max(r_[0], 1e-9) for r_ in rank_info]
+            out["config"].update({
+                ("rccl_ranks_seen" if backend == "nccl" else "gloo_ranks_seen"): len(rank_info),      # ranks whose all_gather contribution arrived
+                "rank_value_min": round(min(per_rank), 1), "rank_value_max": round(max(per_rank), 1),
+                "rank_value_max_over_min": round(max(per_rank) / max(min(per_rank), 1.0), 4),
+                "rank_autotune_picks": ",".join({0: "fused8", 1: "fused8h"}.get(int(r_[1]), "unmeasured") for r_ in rank_info)[:120],
+                "rank_devices": ",".join(str(int(r_[2])) for r_ in rank_info)[:120]})
 
     def guarded(key, seconds, fn, every_rank):
         """run extra `key` (on every rank, or on rank 0 while the others wait at the next barrier) under rank 0's deadline"""
@@ -1468,8 +1688,8 @@ def main():
             def late():
                 o = dict(out)
                 o["config"] = dict(out["config"])
-                o["config"][key + "_error"] = "did not finish within %d s; the line was printed by the watchdog, the ranks were abandoned" % seconds
-                return json.dumps(o)
+                o["config"][(key + "_error")[:KEY_MAX]] = "did not finish within %d s; line printed by the watchdog, ranks abandoned" % seconds
+                return json.dumps(finalize_line(o))
             dog.arm(late, seconds)
         res = None
         try:
@@ -1485,17 +1705,17 @@ def main():
             out[key] = res                # the N > 1 line has no other extras (they are gated on one rank): these two stay in it, whole
             cfgm = out["config"]
             if isinstance(res, dict) and "error" in res:
-                cfgm[key + "_error"] = str(res["error"])[:120]
+                cfgm[(key + "_error")[:KEY_MAX]] = str(res["error"])[:120]
             elif isinstance(res, dict):
                 for form in ("cold", "key_cache"):          # sharded_committee: the QC of the large committee cut over the ranks
                     if isinstance(res.get(form), dict) and "p50_ms" in res[form]:
                         cfgm["%s_p50_ms_%s" % (key, form)] = res[form]["p50_ms"]
-                        cfgm["%s_verifies_per_s_%s" % (key, form)] = res[form]["verifies_per_s"]
+                        cfgm["%s_verifies_s_%s" % (key, form)] = res[form]["verifies_per_s"]
                 if "signatures" in res:
                     cfgm[key + "_signatures"] = res["signatures"]
                 for k2, v2 in res.items():                   # sharded_c_abi: flat scalar rows of the one-process form
-                    if isinstance(v2, (int, float)) and k2 not in ("signatures",) and len(cfgm) < 120:
-                        cfgm["%s_%s" % (key, k2)] = v2
+                    if isinstance(v2, (int, float, str)) and k2 not in ("signatures",) and len(cfgm) < 120:
+                        cfgm[("%s_%s" % (key, k2))[:40]] = v2[:120] if isinstance(v2, str) else v2
 
     # the workload that has an exchange step: one very large committee sharded over the GPUs, one process per GPU,
     # all-gather of the per-shard accept bitmaps (RCCL over xGMI; gloo when ranks share a device)
@@ -1518,7 +1738,7 @@ def main():
             out["detail_keys"] = sorted(detail)
         except Exception as e:      # noqa: BLE001
             out["detail_file"] = "not written: %s" % e
-    line = json.dumps(out) if rank == 0 else None
+    line = json.dumps(finalize_line(out)) if rank == 0 else None
     if exchange:
         if rank == 0:
             dog.arm(lambda: line, 60)

@@ -218,6 +218,8 @@ def lib():
                 l.hs_ed25519_shard_msm_min.restype = sz
                 l.hs_ed25519_set_shard_msm_min.argtypes = [sz]
                 l.hs_ed25519_shard_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+                l.hs_ed25519_shard_rccl_fallbacks.argtypes = []
+                l.hs_ed25519_shard_rccl_fallbacks.restype = ctypes.c_ulonglong
                 l.hs_ed25519_hw_queue_budget.argtypes = [ctypes.c_uint]
                 l.hs_ed25519_hw_queue_budget.restype = ctypes.c_uint
                 l.hs_ed25519_abi_version.argtypes = []
@@ -344,8 +346,13 @@ def set_rlc_key(key):
 def shard_msm_stats():
     """(sharded BATCH_RLC calls that ran the one-combination stage, how many of them it accepted outright)"""
     a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
-    lib().hs_ed25519_shard_msm_stats(ctypes.byref(a), ctypes.byref(b))
+    check(lib().hs_ed25519_shard_msm_stats(ctypes.byref(a), ctypes.byref(b)), "hs_ed25519_shard_msm_stats")
     return a.value, b.value
+
+
+def shard_rccl_fallbacks():
+    """sharded calls that asked for the RCCL exchange and went through pinned host memory because it could not be set up"""
+    return int(lib().hs_ed25519_shard_rccl_fallbacks())
 
 
 def verify_packed_sharded(digests, pks, sigs, n, mode, shared, want_bitmap=False):

@@ -17,6 +17,24 @@ class CryptoError(Exception):
     """crypto::CryptoError (= ed25519::Error, lib.rs:18): opaque, carries no reason."""
 
 
+# The embedder's CPU verifier: callable(digests, digest_stride, pks, sigs, n, mode) -> list of n bools (mode _lib.STRICT or
+# _lib.BATCH, packed bytes as the C ABI takes them) - in the Rust shim the reference's own dalek bodies (INTEGRATION.md
+# section 3).  An ENGINE FAULT (_lib.EngineError: no device, a HIP error, a library shut down) is not a verdict: with a CPU
+# verifier set every entry point below answers there - never Ok on error, and never Err for a valid certificate because the
+# device failed (a TC refused during a view change costs liveness, consensus/src/core.rs:434-439); without one the fault is
+# CryptoError, as before.  engine_faults counts the calls answered on the CPU for that reason.
+cpu_verify = None
+engine_faults = 0
+
+
+def _after_fault(e, digests, digest_stride, pks, sigs, n, mode):
+    global engine_faults
+    if cpu_verify is None:
+        raise CryptoError(str(e)) from e
+    engine_faults += 1
+    return list(cpu_verify(bytes(digests), digest_stride, bytes(pks), bytes(sigs), n, _lib.BATCH if mode == _lib.BATCH_RLC else mode))
+
+
 def _fixed(b, n, what):
     b = bytes(b)
     if len(b) != n:
@@ -95,7 +113,7 @@ class Signature:
         try:
             ok, _ = _lib.verify_packed(digest.b, public_key.b, self.flatten(), 1, _lib.STRICT, shared=True)
         except _lib.EngineError as e:
-            raise CryptoError(str(e)) from e
+            ok = all(_after_fault(e, digest.b, 0, public_key.b, self.flatten(), 1, _lib.STRICT))
         if not ok:
             raise CryptoError()
 
@@ -125,7 +143,7 @@ class Signature:
                 # hs_ed25519_rlc_min_batch() signatures up, the per-signature kernels below it and as its localiser
                 ok, _ = _lib.verify_packed(digest.b, bytes(pks), bytes(sigs), n, _lib.BATCH_RLC, shared=True)
         except _lib.EngineError as e:
-            raise CryptoError(str(e)) from e
+            ok = all(_after_fault(e, digest.b, 0, pks, sigs, n, _lib.BATCH))
         if not ok:
             raise CryptoError()
 
@@ -149,5 +167,5 @@ class Signature:
             else:
                 _, bm = _lib.verify_packed(dg, pks, sigs, n, _lib.STRICT, shared=False, want_bitmap=True)
         except _lib.EngineError as e:
-            raise CryptoError(str(e)) from e
+            return [bool(v) for v in _after_fault(e, dg, 32, pks, sigs, n, _lib.STRICT)]
         return [bool(bm[i >> 3] >> (i & 7) & 1) for i in range(n)]

@@ -46,9 +46,16 @@ enum { HS_K_AUTO = 0, HS_K_LANE = 1, HS_K_FUSED = 3, HS_K_FUSED_PAIRS = 4,
 // selectors that only concern cold single calls of up to 8 signatures per SIMD behave as HS_K_AUTO everywhere else
 inline bool hs_k_auto_like(int k) { return k == HS_K_AUTO || k == HS_K_OCT || k == HS_K_OCT_SPLIT; }
 
+namespace hs {
+// a stream that several pool contexts launch on (the narrow pool: kNarrowDepth contexts - each with its own staging, workspace
+// and completion event - queue on one CU-masked stream, so that a slice's next launch is already queued when one ends)
+struct stream_box { hipStream_t s = nullptr; int device = 0; ~stream_box(); };
+}
 struct hs_ed25519_ctx {
     int slot = 0, device = 0;
     hipStream_t stream = nullptr;
+    std::shared_ptr<hs::stream_box> stream_share;   // set: `stream` belongs to this box (destroyed with its last context), not to the context
+    unsigned lane = 0;            // narrow pool: which of the pool's streams
     hipEvent_t done = nullptr;    // host-call groups: recorded behind the launch
     bool narrow = false;          // a pool context whose stream is confined to one slice of the CUs (small host-API calls)
     unsigned part = 0;            // which slice (narrow pool contexts)
@@ -99,6 +106,8 @@ struct dev_state {
     std::vector<hs_ed25519_ctx *> free_ctx[2];
     int live[2] = {0, 0};
     unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)
+    unsigned lane_busy[64] = {0};            // narrow contexts in flight per stream of the pool (an idle stream before a queued one)
+    std::vector<std::shared_ptr<stream_box>> lanes;   // the narrow pool's streams, by lane
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
     // hs_ed25519_autotune: kernel time of the two eight-lane cold forms on a canned 6,667-signature batch on THIS device
     // ([0] k_verify_fused8, [1] k_verify_fused8h; 0 = not measured) and the faster one (-1 = not measured: the split form)
@@ -112,13 +121,15 @@ extern std::atomic<size_t> g_max_batch;
 constexpr int kMaxSlots = 64;                // hs_ed25519_init_devices takes at most this many device slots
 extern std::atomic<int> g_oct_pick[kMaxSlots];   // per slot: the faster eight-lane cold form as measured (0 one wavefront, 1 split, -1 not measured); read by
                                              // every cold call without a lock, written by hs_ed25519_autotune - hence atomics beside g_devs, not inside it
-extern int kMaxPool[2];                      // contexts per pool: [0] wide, [1] narrow
+extern int kMaxPool[2];                      // STREAMS per pool: [0] wide, [1] narrow
+extern int kNarrowDepth;                     // narrow pool: contexts per stream (launches queued per stream, each with its own staging)
 extern unsigned kPoolPartitions;             // CU slices the narrow pool's streams are spread over
 extern unsigned kTenants, kTenantIndex;      // this process is tenant kTenantIndex of kTenants on its GPU (hs_ed25519_set_tenancy)
 extern bool kTenantWide;                     // co-tenants: confine the wide pool's streams to the tenant's CU share as well
 constexpr size_t kPartitionMaxBatch = 1024;  // host calls up to this many signatures are served by the narrow pool
 constexpr size_t kZeroCopyMax = 16384;       // host-pointer calls up to this size let the kernels read pinned memory directly
-int ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words);
+int ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words,
+            std::shared_ptr<stream_box> share = nullptr);
 int ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging);
 // a narrow (CU-partitioned) context for small n, a wide one above; nowait: HS_ED25519_E_BUSY instead of waiting for a free one
 int pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait = false);

@@ -717,6 +717,12 @@ std::atomic<int> hs::g_oct_pick[hs::kMaxSlots];      // set to -1 by init
 // (more streams in flight than queues collapse, profiles/r1_stream_sweep.txt), so the pools stay small: sixteen
 // narrow contexts - two per CU partition - for the small calls that come in bulk, four wide ones for the big calls.
 int hs::kMaxPool[2] = {4, 16};                 // HS_ED25519_POOL_NARROW overrides the second (read at init; measurement aid)
+// Round 6: two contexts per narrow stream.  A group's launch (2 - 3 ms at sixteen batches) used to be the only work on its stream:
+// from its end until the host had woken, collected sixteen verdicts, staged the next 2 MB and launched, the stream's share of its
+// CU slice stood idle.  With a second context (own pinned staging, workspace and event) queued on the same stream the next
+// launch is already there.  Streams - hardware queues - stay at sixteen.  HS_ED25519_POOL_DEPTH overrides (measurement aid).
+int hs::kNarrowDepth = 2;
+hs::stream_box::~stream_box() { if (s) { (void)hipSetDevice(device); (void)hipStreamDestroy(s); } }
 // key cache, single calls: where the two-launch form - chains, then the batched finish by compression - takes over.  Its
 // second launch is a tail of 0.07 - 0.11 ms (four to sixteen signatures per lane and one 254-squaring inversion on a handful of
 // lone wavefronts), so it pays only where the chain phase is much longer than that (profiles/r4_j_cached_c_ab.md, same box):
@@ -777,7 +783,12 @@ static std::atomic<size_t> g_tail_max{kTailMax};      // HS_ED25519_TAIL_MAX: sw
 // host buffers through hs_ed25519_submit bursts (16 slices of 16 CUs with one context each: 41.7 M - the two
 // wavefronts of a SIMD then come from ONE launch and run 18 % longer; profiles/r2_e2e_async.txt).  The synchronous
 // calls pay for it at 16 concurrent callers (21.5 against 26.8 M verifies/s; equal up to 8 callers).
-unsigned hs::kPoolPartitions = 8;               // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
+// Round 6: FOUR slices of 64 CUs, four streams each - the shape of the device-resident headline.  With the pool created in turn
+// (pool_get) the same GPU, same run (profiles/r6_k_e2e_pool_shape.md): bursts of sixteen 99 - 103 M verifies/s from host buffers
+// on four slices against 74 - 83 M on eight; bursts of one to four equal (36 / 60 / 76 M); a lone 1,024-signature call 0.257 ms
+// against 0.270 (half a wavefront slot per SIMD of its slice: the split eight-lane form); only sixteen threads with two bursts of
+// EIGHT each in flight prefer eight slices (92 against 86 M).
+unsigned hs::kPoolPartitions = 4;               // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
 // Several node processes on one GPU (the reference's `fab local` runs four node processes on one host,
 // benchmark/benchmark/local.py:94-104).  Every process brings its own pools - 16 narrow + 4 wide stream contexts - and
 // the device multiplexes all of them; past ~16 streams in flight throughput collapses (profiles/r1_stream_sweep.txt).
@@ -829,7 +840,8 @@ int hs::ctx_reserve(hs_ed25519_ctx *c, size_t n, bool staging) {
     return 0;
 }
 
-int hs::ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words) {
+int hs::ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t *cu_mask, uint32_t mask_words,
+                std::shared_ptr<stream_box> share) {
     if (!g_init.load()) return fail(HS_ED25519_E_NOT_INIT, "hs_ed25519_init has not succeeded");
     if (slot < 0 || slot >= (int)g_devs.size()) return fail(HS_ED25519_E_ARG, "ctx_create: no such device slot");
     const int device = g_devs[slot].ordinal;
@@ -839,11 +851,14 @@ int hs::ctx_new(hs_ed25519_ctx **out, size_t max_batch, int slot, const uint32_t
     c->slot = slot; c->device = device;
     c->cus = g_devs[slot].cus;
     if (cu_mask) { unsigned pc = 0; for (uint32_t w = 0; w < mask_words; w++) pc += (unsigned)__builtin_popcount(cu_mask[w]); if (pc) c->cus = pc; }
-    hipError_t e = cu_mask ? hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask)
-                           : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, cu_mask ? "hipExtStreamCreateWithCUMask" : "hipStreamCreate", e); }
+    if (share) { c->stream = share->s; c->stream_share = share; }      // a context of the narrow pool: it queues on one of the pool's streams
+    else {
+        hipError_t e = cu_mask ? hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask)
+                               : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(HS_ED25519_E_DEVICE, cu_mask ? "hipExtStreamCreateWithCUMask" : "hipStreamCreate", e); }
+    }
     int rc = ctx_reserve(c, max_batch ? max_batch : 64, false);
-    if (rc) { (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
+    if (rc) { if (!c->stream_share) (void)hipStreamDestroy(c->stream); ctx_release(c); delete c; return rc; }
     *out = c;
     return 0;
 }
@@ -875,7 +890,8 @@ extern "C" int hs_ed25519_ctx_device(const hs_ed25519_ctx *c) { return c ? c->de
 extern "C" void hs_ed25519_ctx_destroy(hs_ed25519_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); if (!c->stream_share) (void)hipStreamDestroy(c->stream); }
+    c->stream_share.reset();          // a shared stream goes with the last context (or pool entry) that names it
     if (c->done) (void)hipEventDestroy(c->done);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_tc) (void)hipFree(c->d_tc);
@@ -948,13 +964,13 @@ static int build_base_tables(dev_state &d) {
 // verifies/s alone, 66 M and a 1.6x spread with ONE more queue held by an idle fifth process, 0.1 - 33 M and up to 160x with
 // 8 - 32 more: tools/queue_probe.py, profiles/r4_c_queue_probe_pools_of_7.md).  So co-tenants take few queues and leave
 // headroom for whatever else opens the GPU (a monitoring agent, a bench harness).  A tenant's pools are the single process's
-// (16 narrow contexts on eight 32-CU slices, 4 wide) divided by the tenants: for four, 4 narrow contexts on two 32-CU slices
-// - two launches per slice is what keeps two wavefronts on every SIMD for bursts of four AND of sixteen (3 contexts on one
-// 64-CU slice measured 77.9 M at bursts of sixteen but 54.6 M at bursts of four, where three half-filling launches leave the
-// SIMDs at 1.5 wavefronts: profiles/r4_b_mp_sweep.txt, r4_d) - one wide context, one queue for the process's own default
-// stream: 6 queues per tenant, 24 for four, 22 for two.
-static unsigned tenant_partitions(unsigned tenants) { return tenants <= 1 ? 8u : (8 / tenants < 1 ? 1u : 8 / tenants); }
-static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : 2 * (int)tenant_partitions(tenants); }
+// (16 narrow streams, 4 wide) divided by the tenants: for four, 4 narrow streams on two 32-CU slices of the tenant's 64 CUs
+// - two launches per slice is what keeps two wavefronts on every SIMD for bursts of four AND of sixteen (round 6, four streams
+// on ONE 64-CU slice, the single process's shape: 73.2 M at bursts of four against 77.5, 85.5 against 84.0 M at bursts of
+// sixteen, profiles/r6_l_mp_sweep.txt; round 4, three contexts on one slice: 54.6 M at bursts of four) - one wide context, one
+// queue for the process's own default stream: 6 queues per tenant, 24 for four, 22 for two.
+static unsigned tenant_partitions(unsigned tenants) { return tenants <= 1 ? 4u : (tenants <= 4 ? 2u : 1u); }      // 4 x 64 CUs; two tenants 2 x 64 each; four 2 x 32 each; eight 1 x 32
+static int pool_narrow_for(unsigned tenants) { return tenants <= 1 ? 16 : 2 * (int)(8 / tenants < 1 ? 1u : 8 / tenants); }      // streams; x kNarrowDepth contexts
 static int pool_wide_for(unsigned tenants) { return tenants <= 1 ? 4 : (4 / tenants < 1 ? 1 : 4 / (int)tenants); }
 extern "C" unsigned hs_ed25519_hw_queue_budget(unsigned tenants) {
     if (tenants < 1) tenants = 1;
@@ -987,7 +1003,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     g_env_seen.clear();
     if (const char *e = env_knob("HS_ED25519_TENANTS")) { const int v = atoi(e); if (v >= 1 && v <= 8) { kTenants = (unsigned)v; if (kTenantIndex >= kTenants) kTenantIndex = 0; } }
     if (const char *e = env_knob("HS_ED25519_TENANT_INDEX")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < kTenants) kTenantIndex = (unsigned)v; }
-    kMaxPool[0] = 4; kMaxPool[1] = 16; kPoolPartitions = 8;
+    kMaxPool[0] = 4; kMaxPool[1] = 16; kPoolPartitions = 4; kNarrowDepth = 2;
     if (kTenants > 1) {
         kMaxPool[1] = pool_narrow_for(kTenants);
         kMaxPool[0] = pool_wide_for(kTenants);
@@ -1025,6 +1041,7 @@ extern "C" int hs_ed25519_init_devices(const int *ordinals, size_t count, size_t
     if (const char *e = env_knob("HS_ED25519_QUAD_MAX_BATCH")) { const long v = atol(e); if (v >= 64 && v <= 32768) g_quad_max_batch.store((size_t)v); }
     if (const char *e = env_knob("HS_ED25519_POOL_NARROW")) { const int v = atoi(e); if (v >= 1 && v <= 64) kMaxPool[1] = v; }
     if (const char *e = env_knob("HS_ED25519_POOL_PARTITIONS")) { const int v = atoi(e); if (v >= 1 && v <= 64) kPoolPartitions = (unsigned)v; }
+    if (const char *e = env_knob("HS_ED25519_POOL_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) kNarrowDepth = v; }
     (void)env_knob("HS_ED25519_MIN_GPU_BATCH"); (void)env_knob("HS_ED25519_SHARD_MSM_MIN");      // read where they are used; listed in the dump
     int have = 0;
     HS_HIP(hipGetDeviceCount(&have), "hipGetDeviceCount");
@@ -1088,6 +1105,7 @@ extern "C" void hs_ed25519_shutdown(void) {
             for (hs_ed25519_ctx *c : d.free_ctx[k]) hs_ed25519_ctx_destroy(c);
             d.free_ctx[k].clear(); d.live[k] = 0;
         }
+        d.lanes.clear();
         free_base_tables(d);
         // tickets still outstanding keep their group alive; its context is destroyed when they are waited on
     }
@@ -1098,13 +1116,13 @@ extern "C" const char *hs_ed25519_last_error(void) { return t_err; }
 // what init resolved, as JSON (include/hs_ed25519.h); no device call
 extern "C" size_t hs_ed25519_config_dump(char *buf, size_t cap) {
     std::string o;
-    char t[512];
+    char t[2048];      // the longest chunk below is ~620 characters with every value at its 20-digit widest (512 could truncate into invalid JSON)
     std::lock_guard<std::mutex> lk(g_mu);
     const size_t pm = g_pairs_min_batches.load(), lm = g_lane_min_batches.load();
     snprintf(t, sizeof t, "{\"abi_version\": %u, \"initialised\": %s, \"tenants\": %u, \"tenant_index\": %u, \"tenant_wide\": %s, "
-             "\"pool_wide\": %d, \"pool_narrow\": %d, \"pool_partitions\": %u, \"hw_queue_budget\": %u, \"gpu_max_hw_queues_env\": %d, ",
+             "\"pool_wide\": %d, \"pool_narrow\": %d, \"pool_narrow_depth\": %d, \"pool_partitions\": %u, \"hw_queue_budget\": %u, \"gpu_max_hw_queues_env\": %d, ",
              (unsigned)HS_ED25519_ABI_VERSION, g_init.load() ? "true" : "false", kTenants, kTenantIndex, kTenantWide ? "true" : "false",
-             kMaxPool[0], kMaxPool[1], kPoolPartitions, hs_ed25519_hw_queue_budget(kTenants), g_hw_queues_env);
+             kMaxPool[0], kMaxPool[1], kNarrowDepth, kPoolPartitions, hs_ed25519_hw_queue_budget(kTenants), g_hw_queues_env);
     o += t;
     snprintf(t, sizeof t, "\"max_batch_hint\": %zu, \"narrow_pool_max_batch\": %zu, \"zero_copy_max\": %zu, \"oct_max_batch\": %zu, \"oct_split_forced\": %d, "
              "\"autotune\": %d, \"quad_max_batch\": %zu, \"tail_max\": %zu, \"pairs_min_batches\": %lld, \"lane_min_batches\": %lld, \"lane_min_total\": %zu, "

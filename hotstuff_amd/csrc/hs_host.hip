@@ -66,22 +66,25 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
         dev_state &d = g_devs[slot];
         const bool have_free = !d.free_ctx[k].empty();
         // a new context when none is free - and, in the narrow pool, until every CU slice has one
-        if (d.live[k] < kMaxPool[k] && (!have_free || (k == 1 && d.live[k] < (int)kPoolPartitions))) { d.live[k]++; break; }
+        // (narrow pool: kNarrowDepth contexts queue on each of its kMaxPool[1] streams)
+        if (d.live[k] < kMaxPool[k] * (k == 1 ? kNarrowDepth : 1) && (!have_free || (k == 1 && d.live[k] < (int)kPoolPartitions))) { d.live[k]++; break; }
         if (have_free) {
-            // narrow pool: two contexts share each CU slice - take a free context on the slice with the fewest launches
-            // in flight (with eight of sixteen contexts busy, a last-in-first-out pick left half the chip idle half of
-            // the time: 42 against 74 M verifies/s for four threads keeping eight sixteen-batch launches in flight)
+            // narrow pool: two streams share each CU slice and kNarrowDepth contexts each stream - take a free context whose
+            // stream is idle if there is one, and among those the slice with the fewest launches in flight (with eight of
+            // sixteen contexts busy, a last-in-first-out pick left half the chip idle half of the time: 42 against 74 M
+            // verifies/s for four threads keeping eight sixteen-batch launches in flight)
             size_t pick = d.free_ctx[k].size() - 1;
             if (k == 1) {
                 unsigned best = ~0u;
                 for (size_t i = d.free_ctx[k].size(); i-- > 0;) {
-                    const unsigned busy = d.part_busy[d.free_ctx[k][i]->part % 64];
+                    const hs_ed25519_ctx *f = d.free_ctx[k][i];
+                    const unsigned busy = d.lane_busy[f->lane % 64] * 256u + d.part_busy[f->part % 64];
                     if (busy < best) { best = busy; pick = i; }
                 }
             }
             hs_ed25519_ctx *c = d.free_ctx[k][pick];
             d.free_ctx[k].erase(d.free_ctx[k].begin() + (long)pick);
-            if (k == 1) d.part_busy[c->part % 64]++;
+            if (k == 1) { d.part_busy[c->part % 64]++; d.lane_busy[c->lane % 64]++; }
             // a whole-chip call that finds another one in flight on its device runs the throughput forms (enqueue_cold)
             else c->several_in_flight = d.live[0] - (int)d.free_ctx[0].size() > 1;
             if (nowait) { c->held = t_held.at(slot, k); c->held->fetch_add(1, std::memory_order_relaxed); }
@@ -107,18 +110,52 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
             }
         }
     }
-    const unsigned part = (unsigned)(g_devs[slot].live[k] - 1) % kPoolPartitions, cus = g_devs[slot].cus;
+    const unsigned lane = (unsigned)(g_devs[slot].live[k] - 1) % (unsigned)(kMaxPool[k] > 0 ? kMaxPool[k] : 1);
+    const unsigned part = lane % kPoolPartitions, cus = g_devs[slot].cus;
     const bool others_busy = k == 0 && g_devs[slot].live[0] - (int)g_devs[slot].free_ctx[0].size() > 1;
+    const int ordinal = g_devs[slot].ordinal;
     lk.unlock();
     hs_ed25519_ctx *c = nullptr;
     int rc = -1;
     // this tenant's share of the chip (the whole of it by default)
     const unsigned t_lo = cus * kTenantIndex / kTenants, t_cus = cus * (kTenantIndex + 1) / kTenants - t_lo;
-    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the tenant's CUs
+    auto slice_mask = [&](unsigned p) {          // slice p of the tenant's CUs
         std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-        const unsigned lo = t_lo + t_cus * part / kPoolPartitions, hi = t_lo + t_cus * (part + 1) / kPoolPartitions;
+        const unsigned lo = t_lo + t_cus * p / kPoolPartitions, hi = t_lo + t_cus * (p + 1) / kPoolPartitions;
         for (unsigned u = lo; u < hi; u++) mask[u / 32] |= 1u << (u % 32);
-        rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size());
+        return mask;
+    };
+    // Pool contexts are created one at a time, and the narrow pool's CU-masked streams all at once, in lane order, by whichever
+    // thread needs the first of them (round 6).  Sixteen threads whose first calls created the pool CONCURRENTLY left the
+    // process at 86 - 88 M verifies/s for good where a pool created by one thread ran 102 - 105 M on the same GPU, same load
+    // (profiles/r6_j_pool_creation_order.md): streams created with hipExtStreamCreateWithCUMask in parallel do not end up
+    // configured as the same streams created in turn.
+    static std::mutex s_create_mu;
+    std::lock_guard<std::mutex> creating(s_create_mu);
+    if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the tenant's CUs
+        lk.lock();
+        bool need = g_init.load() && slot < (int)g_devs.size() && g_devs[slot].lanes.empty();
+        lk.unlock();
+        if (need && hipSetDevice(ordinal) == hipSuccess) {
+            std::vector<std::shared_ptr<stream_box>> boxes((size_t)(kMaxPool[1] > 0 ? kMaxPool[1] : 1));
+            for (size_t l = 0; l < boxes.size(); l++) {
+                const std::vector<uint32_t> mask = slice_mask((unsigned)l % kPoolPartitions);
+                hipStream_t st = nullptr;
+                if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); break; }      // CU masking unavailable: plain streams, one per context
+                boxes[l] = std::shared_ptr<stream_box>(new (std::nothrow) stream_box());
+                if (!boxes[l]) { (void)hipStreamDestroy(st); break; }
+                boxes[l]->s = st; boxes[l]->device = ordinal;
+            }
+            lk.lock();
+            if (g_init.load() && slot < (int)g_devs.size() && g_devs[slot].lanes.empty()) g_devs[slot].lanes.swap(boxes);
+            lk.unlock();
+        }
+        std::shared_ptr<stream_box> share;
+        lk.lock();
+        if (g_init.load() && slot < (int)g_devs.size() && lane < g_devs[slot].lanes.size()) share = g_devs[slot].lanes[lane];
+        lk.unlock();
+        const std::vector<uint32_t> mask = slice_mask(part);
+        if (share) rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size(), share);
         if (rc) (void)hipGetLastError();          // CU masking unavailable: a plain stream serves as well
     } else if (k == 0 && kTenants > 1 && kTenantWide && t_cus > 0 && t_cus < cus) {
         // co-tenants: the whole-chip calls of this process stay on its own share too, or four tenants' QC-sized calls
@@ -132,10 +169,15 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     if (rc) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].live[k]--; g_cv.notify_all(); return rc; }
     c->narrow = k == 1;
     c->part = part;
+    c->lane = lane;
     c->overflow = overflow;
     c->several_in_flight = others_busy;
     if (nowait) { c->held = t_held.at(slot, k); c->held->fetch_add(1, std::memory_order_relaxed); }
-    if (k == 1) { lk.lock(); if (g_init.load() && slot < (int)g_devs.size()) g_devs[slot].part_busy[part % 64]++; lk.unlock(); }
+    if (k == 1) {
+        lk.lock();
+        if (g_init.load() && slot < (int)g_devs.size()) { g_devs[slot].part_busy[part % 64]++; g_devs[slot].lane_busy[lane % 64]++; }
+        lk.unlock();
+    }
     *out = c;
     return 0;
 }
@@ -145,6 +187,7 @@ void hs::pool_put(hs_ed25519_ctx *c) {
     if (!g_init.load() || c->slot >= (int)g_devs.size()) { lk.unlock(); hs_ed25519_ctx_destroy(c); return; }
     const int k = c->narrow ? 1 : 0;
     if (c->narrow && g_devs[c->slot].part_busy[c->part % 64]) g_devs[c->slot].part_busy[c->part % 64]--;
+    if (c->narrow && g_devs[c->slot].lane_busy[c->lane % 64]) g_devs[c->slot].lane_busy[c->lane % 64]--;
     if (c->overflow) {                                  // lent over the cap: exactly this one goes, the pool keeps its own
         g_devs[c->slot].live[k]--;
         lk.unlock();
@@ -295,7 +338,10 @@ struct host_group {
     const hs_ed25519_keyset *ks = nullptr;
     int slot = 0;
     // all under mu
-    unsigned members = 0, staged = 0, refs = 0;
+    unsigned members = 0, staged = 0;
+    unsigned refs = 0;            // members not yet collected + the submitting thread's reference to its open group: the struct lives while > 0
+    unsigned member_refs = 0;     // members not yet collected: the context and the key set go back when the last one is (the
+                                  // thread's reference used to pin both until that thread's next submit - a key set could not be destroyed)
     bool closed = false, launched = false;
     int launch_rc = 0;
     hs_ed25519_batch desc[kGroupMax];
@@ -307,7 +353,7 @@ static size_t group_out_stride() { return bitmap_bytes(kPartitionMaxBatch); }
 static int group_close_and_launch(host_group *g) {
     std::unique_lock<std::mutex> lk(g->mu);
     g->closed = true;
-    if (g->launched) return g->launch_rc;
+    if (g->launched || !g->c) return g->launch_rc;       // (no context: every member was collected - the thread's stale reference)
     g->cv.wait(lk, [g] { return g->staged == g->members || g->launched; });
     if (g->launched) return g->launch_rc;
     int rc = 0;
@@ -320,15 +366,26 @@ static int group_close_and_launch(host_group *g) {
     g->cv.notify_all();
     return rc;
 }
-static void group_unref(host_group *g) {
+// member: a member's reference (its verdict was collected, or its submit failed); else the submitting thread's.  A group whose
+// last member has been collected is closed (group_finish closes before it reads): nothing can join it, so what it holds - the pool
+// context, the hold on the key set - goes back at once, whatever thread-local pointer still names the struct.
+static void group_unref(host_group *g, bool member) {
     bool last;
-    { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
-    if (last) { pool_put(g->c); ks_release(g->ks); delete g; }
+    hs_ed25519_ctx *c = nullptr;
+    const hs_ed25519_keyset *ks = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (member && --g->member_refs == 0) g->closed = true;
+        last = --g->refs == 0;
+        if ((last || (g->member_refs == 0 && g->closed)) && g->c) { c = g->c; ks = g->ks; g->c = nullptr; g->ks = nullptr; }
+    }
+    if (c) { pool_put(c); ks_release(ks); }
+    if (last) delete g;
 }
 // this thread's open group (it holds a reference); a thread that exits launches what it left open
 struct open_group_slot {
     host_group *g = nullptr;
-    void drop(bool launch) { if (g) { if (launch) (void)group_close_and_launch(g); group_unref(g); g = nullptr; } }
+    void drop(bool launch) { if (g) { if (launch) (void)group_close_and_launch(g); group_unref(g, false); g = nullptr; } }
     ~open_group_slot() { drop(true); }
 };
 static thread_local open_group_slot t_open;
@@ -352,7 +409,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
         {
             std::lock_guard<std::mutex> lk(g->mu);
             if (!g->closed && g->ks == ks && g->members < kGroupMax) {      // same kind (a key set pins its device slot, cold calls take any)
-                idx = g->members++; g->refs++; joined = true;
+                idx = g->members++; g->refs++; g->member_refs++; joined = true;
                 if (!more || g->members == kGroupMax) { g->closed = true; closer = true; }
             }
         }
@@ -370,7 +427,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
         if (!rc && !(g = new (std::nothrow) host_group())) rc = fail(HS_ED25519_E_NOMEM, "out of memory");
         if (rc) { pool_put(c); return rc; }
         g->c = c; g->ks = ks; g->slot = slot; ks_hold(ks);      // released when the last member's reference goes (group_unref)
-        g->members = 1; g->refs = 1; idx = 0;
+        g->members = 1; g->refs = 1; g->member_refs = 1; idx = 0;
         if (more) { g->refs++; t_open.g = g; }                  // the thread's reference to its open group
         else { g->closed = true; closer = true; }
     }
@@ -401,7 +458,7 @@ static int group_submit(host_group **g_out, unsigned *idx_out, const hs_ed25519_
     if (closer) {
         if (t_open.g == g) t_open.drop(false);
         const int rc = group_close_and_launch(g);
-        if (rc) { group_unref(g); *g_out = nullptr; return rc; }
+        if (rc) { group_unref(g, true); *g_out = nullptr; return rc; }
     }
     return 0;
 }
@@ -416,7 +473,7 @@ static int group_finish(host_group *g, unsigned idx, size_t n, uint8_t *bitmap) 
         if (bitmap) memcpy(bitmap, outp, (n + 7) / 8);
         verdict = bitmap_all_ones(outp, n) ? 1 : 0;
     } else if (g->launched) (void)hipStreamSynchronize(g->c->stream);      // nothing of this group may still run when the context goes back
-    group_unref(g);
+    group_unref(g, true);
     return verdict;
 }
 static bool group_sized(size_t n, uint32_t mode) { return n && n <= kPartitionMaxBatch && mode <= HS_ED25519_BATCH_RLC; }

@@ -102,21 +102,28 @@ int rccl_fail(const char *what, ncclResult_t r) {
     snprintf(buf, sizeof buf, "%s: %s", what, s_rccl.GetErrorString ? s_rccl.GetErrorString(r) : "RCCL error");
     return fail(HS_ED25519_E_DEVICE, buf);
 }
+// A refused set-up (no librccl, one GPU in two slots, ncclCommInitAll failing) is remembered with its reason until
+// hs_ed25519_shard_reset: every later call answers through the host exchange at once instead of repeating the dlopen search and
+// ncclCommInitAll under s_mu - hundreds of ms per call, serialising all sharded callers.
+char s_rccl_refused[200] = "";
 int rccl_ensure() {      // under s_mu: communicators for the current device list
+    if (s_rccl_refused[0]) return fail(HS_ED25519_E_DEVICE, s_rccl_refused);
     int rc = rccl_load();
-    if (rc) return rc;
     const int k = dev_slots();
-    if ((int)s_comms.size() != k) {
+    if (!rc && (int)s_comms.size() != k) {
         std::vector<int> ords(k);
         for (int s = 0; s < k; s++) ords[s] = dev_ordinal(s);
-        for (int a = 0; a < k; a++) for (int b = a + 1; b < k; b++)
-            if (ords[a] == ords[b]) return fail(HS_ED25519_E_ARG, "RCCL exchange: the same GPU appears in two device slots (use the host exchange)");
-        std::vector<ncclComm_t> comms(k);
-        ncclResult_t r = s_rccl.CommInitAll(comms.data(), k, ords.data());
-        if (r != ncclSuccess) return rccl_fail("ncclCommInitAll", r);
-        s_comms.swap(comms);
+        for (int a = 0; a < k && !rc; a++) for (int b = a + 1; b < k && !rc; b++)
+            if (ords[a] == ords[b]) rc = fail(HS_ED25519_E_ARG, "RCCL exchange: the same GPU appears in two device slots (use the host exchange)");
+        if (!rc) {
+            std::vector<ncclComm_t> comms(k);
+            ncclResult_t r = s_rccl.CommInitAll(comms.data(), k, ords.data());
+            if (r != ncclSuccess) rc = rccl_fail("ncclCommInitAll", r);
+            else s_comms.swap(comms);
+        }
     }
-    return 0;
+    if (rc) snprintf(s_rccl_refused, sizeof s_rccl_refused, "%.190s", hs_ed25519_last_error());
+    return rc;
 }
 // under s_mu: a gather set of at least k * slice_bytes per slot
 int gather_set_get(gather_set **out, size_t slice_bytes) {
@@ -153,6 +160,7 @@ extern "C" void hs_ed25519_shard_reset(void) {      // called by tests / before 
     s_free_sets.clear();
     if (s_rccl.CommDestroy) for (ncclComm_t c : s_comms) if (c) (void)s_rccl.CommDestroy(c);
     s_comms.clear();
+    s_rccl_refused[0] = 0;      // a new device list (or a librccl that has appeared) gets a new attempt
 }
 // how many ranks the in-process RCCL exchange runs over (communicators of ncclCommInitAll): 0 until the first
 // HS_ED25519_EXCHANGE_RCCL call has initialised them
@@ -198,6 +206,7 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
             std::lock_guard<std::mutex> lk(s_mu);
             rc = rccl_ensure();
             if (!rc) rc = gather_set_get(&gs, slice_bytes);
+            const bool no_setup = rc != 0;      // the one class of failure that falls back; a device fault while staging is returned
             std::vector<uint8_t *> send(k, nullptr);
             for (int s = 0; s < k && !rc; s++) {
                 hs_ed25519_ctx *c = jobs[s].c;
@@ -218,15 +227,16 @@ int run_items(const std::vector<shard_item> &items, size_t digest_stride, uint32
                 }
                 if (e != hipSuccess) rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the slice", e);
             }
-            if (rc) {
+            if (no_setup) {
                 // The collective could not be SET UP (no librccl, a device list ncclCommInitAll refuses, no memory for the gather
                 // buffers): every slot's bitmap slice still comes home through its context's pinned bitmap, so the call answers
-                // through the host exchange instead of failing.  Errors once the grouped call has started are returned.
+                // through the host exchange instead of failing; hs_ed25519_last_error keeps the reason.  A device
+                // error while staging the slices, or once the grouped call has started, is returned.
                 (void)hipGetLastError();
                 s_rccl_fallbacks++;
                 want_rccl = false;
                 rc = 0;
-            } else {
+            } else if (!rc) {
                 ncclResult_t r = s_rccl.GroupStart();
                 for (int s = 0; s < k && r == ncclSuccess; s++)
                     r = s_rccl.AllGather(send[s], gs->buf[s], slice_bytes, ncclUint8, s_comms[s], st[s]);   // in place
@@ -376,21 +386,24 @@ int sharded_msm_stage(const uint8_t *digests, size_t digest_stride, const uint8_
         std::lock_guard<std::mutex> lk(s_mu);
         rc = rccl_ensure();
         if (!rc) rc = gather_set_get(&gs, kRlcPartBytes);
+        const bool no_setup = rc != 0;
         for (int s = 0; s < k && !rc; s++) {
             if (hipSetDevice(jobs[s].c->device) != hipSuccess ||
                 hipMemcpyAsync(gs->buf[s] + (size_t)s * kRlcPartBytes, jobs[s].d_partial, kRlcPartBytes, hipMemcpyDeviceToDevice, jobs[s].c->stream) != hipSuccess)
                 rc = fail(HS_ED25519_E_DEVICE, "RCCL exchange: staging the partial point");
         }
-        if (rc) {
+        if (no_setup) {
             // The collective could not be SET UP (no librccl, ncclCommInitAll refused this device list, no memory for the gather
             // buffers): every device still holds its 384-byte record, and the host exchange below needs nothing else - so the call
-            // verifies through it instead of failing.  An error once the grouped call has started is returned as before.
+            // verifies through it instead of failing.  A device error while staging, or once the grouped call has
+            // started, is returned.
             (void)hipGetLastError();
             s_rccl_fallbacks++;
             via_rccl = false;
             rc = 0;
         }
     }
+    if (rc) return rc;
     if (via_rccl) {
         {
             std::lock_guard<std::mutex> lk(s_mu);
@@ -453,9 +466,11 @@ extern "C" int hs_ed25519_set_shard_msm_min(size_t n) { s_msm_override.store(n);
 extern "C" int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts) {
     if (calls) *calls = s_msm_calls.load();
     if (accepts) *accepts = s_msm_accepts.load();
-    const unsigned long long f = s_rccl_fallbacks.load();
-    return f > 0x7fffffffull ? 0x7fffffff : (int)f;
+    return 0;
 }
+// sharded calls that asked for the RCCL exchange and answered through pinned host memory because the collective could not be set
+// up (the reason: hs_ed25519_last_error of the first such call; remembered until hs_ed25519_shard_reset)
+extern "C" unsigned long long hs_ed25519_shard_rccl_fallbacks(void) { return s_rccl_fallbacks.load(); }
 
 extern "C" int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
                                                 uint32_t mode, uint8_t *bitmap) {

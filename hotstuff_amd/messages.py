@@ -145,7 +145,15 @@ class TC:
                                           b"".join(a.b for a, _, _ in self.votes),
                                           b"".join(s.flatten() for _, s, _ in self.votes), keyset=ks)
         except _lib.EngineError as e:
-            raise InvalidSignature() from e
+            # an engine fault is not a verdict: the reference's own loop (per-vote digest on the host, strict verification) through
+            # the embedder's CPU verifier when there is one (crypto.cpu_verify); InvalidSignature without one, as before
+            from . import crypto
+            try:
+                ok = all(crypto._after_fault(e, b"".join(self.vote_digest(r).b for _, _, r in self.votes), 32,
+                                             b"".join(a.b for a, _, _ in self.votes), b"".join(s.flatten() for _, s, _ in self.votes),
+                                             len(self.votes), _lib.STRICT))
+            except CryptoError as ce:
+                raise InvalidSignature() from ce
         if not ok:
             raise InvalidSignature()
 

@@ -29,7 +29,9 @@
 // tests read like the reference's own (crypto_tests.rs, messages_tests.rs).  There is no CPU
 // fallback: an engine error (no GPU, HIP failure) is an Err like any other, never an Ok.
 #pragma once
+#include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -107,6 +109,22 @@ struct SmallBatch {
     static bool on_cpu(size_t n, bool keys_registered) { return cpu_verify() && n > 0 && n < threshold(keys_registered); }
 };
 
+namespace detail {
+// An engine fault (rc < 0: no device, a HIP error, a library that was shut down) is not a verdict.  With a CPU verifier supplied
+// by the embedder (SmallBatch::cpu_verify - in the Rust shim: the reference's own dalek bodies) the
+// call is answered THERE, in every entry point alike (round 6; until then only verify_batch's shim text fell back): a device
+// fault then neither accepts anything nor rejects a valid certificate - a TC refused during a view change costs liveness
+// (consensus/src/core.rs:434-439 drops what fails to verify).  Without a CPU verifier a fault stays an error: never Ok.
+// engine_faults() counts the calls answered on the CPU for that reason, so a host can see that it runs without its GPU.
+inline std::atomic<unsigned long long> &engine_faults() { static std::atomic<unsigned long long> n{0}; return n; }
+inline int settle(int rc, const uint8_t *digests, size_t digest_stride, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                  uint32_t mode, uint8_t *bitmap) {
+    if (rc >= 0 || !SmallBatch::cpu_verify()) return rc;
+    engine_faults()++;
+    return SmallBatch::cpu_verify()(digests, digest_stride, pks, sigs, n, mode == HS_ED25519_BATCH_RLC ? (uint32_t)HS_ED25519_BATCH : mode, bitmap);
+}
+}  // namespace detail
+
 struct Signature {
     std::array<uint8_t, 32> part1{}, part2{};             // R, s.  Default = 64 zero bytes (lib.rs Default derive)
 
@@ -128,9 +146,9 @@ struct Signature {
         if (SmallBatch::on_cpu(1, false))                  // one signature: the CPU path when the embedder provides one
             return detail::to_result(SmallBatch::cpu_verify()(digest.b.data(), 32, public_key.b.data(), sig.data(), 1,
                                                               HS_ED25519_STRICT, nullptr));
-        if (!detail::ensure_init()) return CryptoResult{false};
-        return detail::to_result(hs_ed25519_verify_multi(digest.b.data(), public_key.b.data(), sig.data(), 1,
-                                                         HS_ED25519_STRICT, nullptr));
+        const int rc = detail::ensure_init() ? hs_ed25519_verify_multi(digest.b.data(), public_key.b.data(), sig.data(), 1, HS_ED25519_STRICT, nullptr)
+                                             : HS_ED25519_E_NOT_INIT;
+        return detail::to_result(detail::settle(rc, digest.b.data(), 32, public_key.b.data(), sig.data(), 1, HS_ED25519_STRICT, nullptr));
     }
     // lib.rs:206-219: one digest shared by every (key, signature) pair; an empty batch is Ok.
     // Vec<(PublicKey, Signature)> has no guaranteed layout, so the votes are copied into packed buffers.
@@ -144,26 +162,26 @@ struct Signature {
         if (SmallBatch::on_cpu(votes.size(), false))       // e.g. the 3 votes of a 4-node committee
             return detail::to_result(SmallBatch::cpu_verify()(digest.b.data(), 0, pks.data(), sigs.data(), votes.size(),
                                                               HS_ED25519_BATCH, nullptr));
-        if (!detail::ensure_init()) return CryptoResult{false};
-        // dalek's verify_batch as it is computed (one random linear combination), per-signature localisation
-        // inside the same call; below hs_ed25519_rlc_min_batch() the engine runs the per-signature kernels alone
-        // with several device slots open the call is cut into one shard per GPU (hs_shard.hip)
-        const auto fn = detail::several_devices() ? hs_ed25519_verify_shared_sharded : hs_ed25519_verify_shared;
-        return detail::to_result(fn(digest.b.data(), pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH_RLC, nullptr));
+        int rc = HS_ED25519_E_NOT_INIT;
+        if (detail::ensure_init()) {
+            // dalek's verify_batch as it is computed (one random linear combination), per-signature localisation
+            // inside the same call; below hs_ed25519_rlc_min_batch() the engine runs the per-signature kernels alone
+            // with several device slots open the call is cut into one shard per GPU (hs_shard.hip)
+            const auto fn = detail::several_devices() ? hs_ed25519_verify_shared_sharded : hs_ed25519_verify_shared;
+            rc = fn(digest.b.data(), pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH_RLC, nullptr);
+        }
+        return detail::to_result(detail::settle(rc, digest.b.data(), 0, pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH, nullptr));
     }
     // Several certificates at once - a block's payload certificates, the QCs of a catch-up range: every entry is
     // one verify_batch call (same law, same Ok-on-empty), all in flight together through the ticket API, small
     // certificates sharing launches (HS_ED25519_SUBMIT_MORE).  Result i = verify_batch(certs[i]).
     static std::vector<CryptoResult> verify_batches(const std::vector<std::pair<Digest, std::vector<std::pair<PublicKey, Signature>>>> &certs) {
         std::vector<CryptoResult> out(certs.size(), CryptoResult{false});
-        if (certs.empty() || !detail::ensure_init()) return out;
+        if (certs.empty()) return out;
+        const bool engine = detail::ensure_init();
         std::vector<std::pair<size_t, hs_ed25519_ticket *>> inflight;
-        auto collect_oldest = [&]() {
-            out[inflight.front().first] = detail::to_result(hs_ed25519_ticket_wait(inflight.front().second, nullptr));
-            inflight.erase(inflight.begin());
-        };
         std::vector<uint8_t> pks, sigs;
-        for (size_t c = 0; c < certs.size(); c++) {
+        auto pack = [&](size_t c) {
             const auto &votes = certs[c].second;
             pks.resize(32 * votes.size()); sigs.resize(64 * votes.size());
             for (size_t i = 0; i < votes.size(); i++) {
@@ -171,6 +189,26 @@ struct Signature {
                 const auto f = votes[i].second.flatten();
                 std::memcpy(&sigs[64 * i], f.data(), 64);
             }
+        };
+        // an engine fault on certificate c: the CPU verifier answers for it, when there is one (detail::settle)
+        auto on_cpu_after_fault = [&](size_t c, int rc) {
+            std::vector<uint8_t> keep_p, keep_s;
+            keep_p.swap(pks); keep_s.swap(sigs);            // (the caller may be mid-way through packing another certificate)
+            pack(c);
+            const CryptoResult r = detail::to_result(detail::settle(rc, certs[c].first.b.data(), 0, pks.data(), sigs.data(), certs[c].second.size(), HS_ED25519_BATCH, nullptr));
+            pks.swap(keep_p); sigs.swap(keep_s);
+            return r;
+        };
+        auto collect_oldest = [&]() {
+            const size_t c = inflight.front().first;
+            const int rc = hs_ed25519_ticket_wait(inflight.front().second, nullptr);
+            inflight.erase(inflight.begin());
+            out[c] = rc < 0 ? on_cpu_after_fault(c, rc) : detail::to_result(rc);
+        };
+        for (size_t c = 0; c < certs.size(); c++) {
+            const auto &votes = certs[c].second;
+            pack(c);
+            if (!engine) { out[c] = votes.empty() ? CryptoResult{true} : on_cpu_after_fault(c, HS_ED25519_E_NOT_INIT); continue; }
             if (SmallBatch::on_cpu(votes.size(), false)) {
                 out[c] = detail::to_result(SmallBatch::cpu_verify()(certs[c].first.b.data(), 0, pks.data(), sigs.data(), votes.size(),
                                                                   HS_ED25519_BATCH, nullptr));
@@ -182,7 +220,7 @@ struct Signature {
                 const int rc = hs_ed25519_submit(&t, nullptr, certs[c].first.b.data(), 0, pks.data(), sigs.data(), votes.size(),
                                                  HS_ED25519_BATCH_RLC, flags);
                 if (rc == 0) { inflight.push_back({c, t}); break; }
-                if (rc != HS_ED25519_E_BUSY || inflight.empty()) { out[c] = CryptoResult{false}; break; }   // engine error: Err
+                if (rc != HS_ED25519_E_BUSY || inflight.empty()) { out[c] = on_cpu_after_fault(c, rc); break; }   // engine error: the CPU verifier, or Err
                 collect_oldest();
             }
         }
@@ -205,7 +243,10 @@ struct Signature {
         }
         int rc;
         if (SmallBatch::on_cpu(n, false)) rc = SmallBatch::cpu_verify()(dg.data(), 32, pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data());
-        else rc = detail::ensure_init() ? hs_ed25519_verify_multi(dg.data(), pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data()) : -1;
+        else {
+            rc = detail::ensure_init() ? hs_ed25519_verify_multi(dg.data(), pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data()) : HS_ED25519_E_NOT_INIT;
+            if (rc < 0) { std::fill(bm.begin(), bm.end(), 0); rc = detail::settle(rc, dg.data(), 32, pks.data(), sigs.data(), n, HS_ED25519_STRICT, bm.data()); }
+        }
         if (rc < 0) return out;
         out.resize(n);
         for (size_t i = 0; i < n; i++) out[i] = (bm[i >> 3] >> (i & 7)) & 1;
@@ -355,8 +396,13 @@ struct QC {                                                // messages.rs:164-16
                 const auto f = votes[i].second.flatten();
                 std::memcpy(&sigs[64 * i], f.data(), 64);
             }
-            const int rc = hs_ed25519_verify_shared_cached(committee.keyset(), d.b.data(), idx.data(), sigs.data(), votes.size(),
-                                                           HS_ED25519_BATCH_RLC, nullptr);
+            int rc = hs_ed25519_verify_shared_cached(committee.keyset(), d.b.data(), idx.data(), sigs.data(), votes.size(),
+                                                     HS_ED25519_BATCH_RLC, nullptr);
+            if (rc < 0) {                                  // engine fault: the votes carry their keys - the CPU verifier answers (detail::settle)
+                std::vector<uint8_t> pks(32 * votes.size());
+                for (size_t i = 0; i < votes.size(); i++) std::memcpy(&pks[32 * i], votes[i].first.b.data(), 32);
+                rc = detail::settle(rc, d.b.data(), 0, pks.data(), sigs.data(), votes.size(), HS_ED25519_BATCH, nullptr);
+            }
             return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
         }
         return Signature::verify_batch(digest(), votes).is_ok() ? ConsensusResult::Ok()
@@ -376,7 +422,7 @@ struct TC {                                                // messages.rs:283-28
                                                        committee, ConsensusError::TCRequiresQuorum);
         if (s.is_err()) return s;
         if (votes.empty()) return ConsensusResult::Ok();
-        if (!detail::ensure_init()) return ConsensusResult::Err(ConsensusError::InvalidSignature);
+        const bool engine = detail::ensure_init();
         std::vector<uint8_t> pks(32 * votes.size()), sigs(64 * votes.size());
         std::vector<uint64_t> hq(votes.size());
         for (size_t i = 0; i < votes.size(); i++) {
@@ -385,13 +431,25 @@ struct TC {                                                // messages.rs:283-28
             std::memcpy(&sigs[64 * i], f.data(), 64);
             hq[i] = std::get<2>(votes[i]);
         }
-        int rc;
-        if (committee.keyset()) {
+        int rc = HS_ED25519_E_NOT_INIT;
+        if (engine && committee.keyset()) {
             std::vector<uint32_t> idx(votes.size());
             for (size_t i = 0; i < votes.size(); i++) idx[i] = committee.key_index(std::get<0>(votes[i]));
             rc = hs_ed25519_verify_tc_cached(committee.keyset(), round, hq.data(), idx.data(), sigs.data(), votes.size(), nullptr);
-        } else {
+        } else if (engine) {
             rc = hs_ed25519_verify_tc(round, hq.data(), pks.data(), sigs.data(), votes.size(), nullptr);
+        }
+        if (rc < 0 && SmallBatch::cpu_verify()) {
+            // engine fault: the reference's own loop (messages.rs:307-313) - the per-vote digests hashed on the host, strict
+            // verification by the CPU verifier - so that a device fault during a view change does not reject a valid TC
+            std::vector<uint8_t> dg(32 * votes.size());
+            for (size_t i = 0; i < votes.size(); i++) {
+                uint8_t m[16];
+                for (int b = 0; b < 8; b++) { m[b] = (uint8_t)(round >> (8 * b)); m[8 + b] = (uint8_t)(hq[i] >> (8 * b)); }
+                const Digest d = detail::sha512_32(m, 16);
+                std::memcpy(&dg[32 * i], d.b.data(), 32);
+            }
+            rc = detail::settle(rc, dg.data(), 32, pks.data(), sigs.data(), votes.size(), HS_ED25519_STRICT, nullptr);
         }
         return rc == 1 ? ConsensusResult::Ok() : ConsensusResult::Err(ConsensusError::InvalidSignature);
     }

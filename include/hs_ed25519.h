@@ -288,13 +288,16 @@ int hs_ed25519_shard_rccl_ranks(void);    /* ranks of the in-process RCCL exchan
  * HS_ED25519_BATCH's.  Runs from hs_ed25519_shard_msm_min() signatures up (default hs_ed25519_rlc_min_batch() x device slots:
  * below ~40,000 signatures per device the per-signature kernels answer sooner; env HS_ED25519_SHARD_MSM_MIN or
  * hs_ed25519_set_shard_msm_min override), below that as HS_ED25519_BATCH.  hs_ed25519_shard_msm_stats: calls that ran the
- * combination and how many of them it accepted outright; its return value counts the exchanges (bitmap slices or partial
- * points) that were asked to travel by RCCL but went through pinned host memory because the collective could not be SET UP
- * (no librccl, a device list ncclCommInitAll refuses, no memory for the gather buffers) - every device still holds its part
- * then, so the call verifies instead of failing; an error after the grouped call has started is returned as an error. */
+ * combination and how many of them it accepted outright (returns 0).  hs_ed25519_shard_rccl_fallbacks: the exchanges (bitmap
+ * slices or partial points) that were asked to travel by RCCL but went through pinned host memory because the collective
+ * could not be SET UP (no librccl, a device list ncclCommInitAll refuses, no memory for the gather buffers) - every device
+ * still holds its part then, so the call verifies instead of failing, hs_ed25519_last_error says why, and the refusal is
+ * remembered until hs_ed25519_shard_reset (no new attempt per call); a device error while staging, or after the grouped call
+ * has started, is returned as an error. */
 size_t hs_ed25519_shard_msm_min(void);
 int hs_ed25519_set_shard_msm_min(size_t n);
 int hs_ed25519_shard_msm_stats(unsigned long long *calls, unsigned long long *accepts);
+unsigned long long hs_ed25519_shard_rccl_fallbacks(void);
 int hs_ed25519_verify_shared_sharded(const uint8_t digest[32], const uint8_t *pks, const uint8_t *sigs, size_t n,
                                      uint32_t mode, uint8_t *bitmap);
 int hs_ed25519_verify_multi_sharded(const uint8_t *digests, const uint8_t *pks, const uint8_t *sigs, size_t n,

@@ -13,7 +13,7 @@
  *   crypto/src/lib.rs:185-191  Signature::new          -> hs_oracle_sign
  *   crypto/src/lib.rs:200-204  Signature::verify       -> hs_oracle_verify_strict
  *   crypto/src/lib.rs:206-219  Signature::verify_batch -> hs_oracle_verify_batch
- *   consensus/src/messages.rs:197, 307-313 (QC / TC call sites)
+ *   consensus/src/messages.rs:197 (QC call site), 307-313 (TC::verify's loop) -> hs_oracle_verify_tc
  * Parity status: pinned on RFC 8032 vectors + OpenSSL-generated fixtures
  * (tests/golden) and on oracle/ed25519_ref.py (big-int); the edge classes are
  * "parity unpinned" by the reference itself - it has no vectors.
@@ -539,6 +539,33 @@ void hs_oracle_sign_many(const uint8_t *seeds, const uint8_t *msgs, size_t mlen,
                          uint8_t *pk_out, uint8_t *sig_out, int nthreads) {
     job_t j = {0}; j.seeds = seeds; j.msgs = msgs; j.mlen = mlen; j.mstride = mstride; j.pk_out = pk_out; j.sig_out = sig_out;
     run_jobs(&j, n, nthreads, sign_job);
+}
+/* TC::verify's signature loop as the reference runs it (consensus/src/messages.rs:307-313): per vote
+ *   digest = SHA-512(round.to_le_bytes() || high_qc_round.to_le_bytes())[..32];  signature.verify(&digest, author)  (= verify_strict)
+ * out[i] = verdict per vote.  bench.py times it beside hs_ed25519_verify_tc. */
+typedef struct { job_t j; uint64_t round; const uint64_t *hq; } tjob_t;
+static void *tc_job(void *arg) {
+    tjob_t *t = arg; job_t *j = &t->j;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        uint8_t m[16], h[64];
+        for (int b = 0; b < 8; b++) { m[b] = (uint8_t)(t->round >> (8 * b)); m[8 + b] = (uint8_t)(t->hq[i] >> (8 * b)); }
+        hs_oracle_sha512(m, 16, h);
+        j->out[i] = (uint8_t)verify_one(h, 32, j->pks + 32 * i, j->sigs + 64 * i, 1);
+    }
+    return NULL;
+}
+void hs_oracle_verify_tc(uint64_t round, const uint64_t *hq_rounds, const uint8_t *pks, const uint8_t *sigs, size_t n,
+                         uint8_t *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t *th = malloc(nthreads * sizeof *th); tjob_t *jobs = calloc(nthreads, sizeof *jobs);
+    for (int t = 0; t < nthreads; t++) {
+        job_t *j = &jobs[t].j; j->pks = pks; j->sigs = sigs; j->out = out;
+        j->lo = n * t / nthreads; j->hi = n * (t + 1) / nthreads; jobs[t].round = round; jobs[t].hq = hq_rounds;
+        if (nthreads == 1) tc_job(&jobs[t]); else pthread_create(&th[t], NULL, tc_job, &jobs[t]);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
 }
 /* batch verify of n pairs split into nthreads independent sub-batches (all must pass) */
 typedef struct { job_t j; int ok; uint64_t entropy; } bjob_t;

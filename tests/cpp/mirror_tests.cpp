@@ -6,6 +6,7 @@
 // Keys and signatures come from a fixture file written by tests/test_gpu_cpp_mirror.py (OpenSSL):
 // signing is not on the path.  usage: mirror_tests <fixture.bin>     exit code = failed cases
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <vector>
 #include "../../include/hotstuff_crypto.hpp"
@@ -336,6 +337,58 @@ int main(int argc, char **argv) {
         CHECK("hs_ed25519_verify_shared_sharded on one device slot", hs_ed25519_device_count() == 1 && plan && ok == 1 && bm[0] == 7 && bad == 0 && bm2[0] == 5);
     }
     hs_ed25519_shutdown();
+    // ---- an engine fault is not a verdict (round 6): with the library shut down every C-ABI call returns
+    // HS_ED25519_E_NOT_INIT.  Without a CPU verifier each entry point is Err - never Ok; with one (here the test oracle's per-
+    // signature laws, loaded at run time: what the Rust shim's dalek bodies are) EVERY entry point answers there - a valid TC is
+    // accepted, an invalid one rejected - where until round 6 only verify_batch's shim text fell back.
+    {
+        std::vector<std::pair<PublicKey, Signature>> votes;
+        for (int i = 3; i >= 1; i--) votes.push_back({x.pk[i], x.sig[i]});
+        TC tc; tc.round = x.tc_round;
+        for (int i = 0; i < 4; i++) tc.votes.push_back(std::make_tuple(x.pk[i], x.tc_sig[i], x.tc_hq[i]));
+        TC tc_bad = tc; std::get<2>(tc_bad.votes[1]) += 1;       // a vote that claims another high_qc_round than it signed
+        std::vector<Digest> dgs(3, x.digest);
+        SmallBatch::cpu_verify() = nullptr;
+        const bool dead = hs_ed25519_verify_shared(x.digest.b.data(), x.pk[0].b.data(), x.sig[0].flatten().data(), 1, HS_ED25519_BATCH, nullptr) < 0;
+        CHECK("engine shut down, no CPU verifier: every entry point is Err, none Ok",
+              dead && x.sig[3].verify(x.digest, x.pk[3]).is_err() && Signature::verify_batch(x.digest, votes).is_err() &&
+              Signature::verify_many(dgs, votes).empty() && qc().verify(committee).is_err() && tc.verify(committee).is_err());
+        typedef void (*many_fn)(const uint8_t *, size_t, size_t, const uint8_t *, const uint8_t *, size_t, int, uint8_t *, int);
+        static many_fn oracle_many = nullptr;
+        const char *so = std::getenv("HS_ORACLE_SO");
+        void *h = dlopen(so ? so : "oracle/libhs_oracle.so", RTLD_NOW);
+        oracle_many = h ? (many_fn)dlsym(h, "hs_oracle_verify_many") : nullptr;
+        CHECK("the test oracle (the CPU verifier of the fault-injection case) loads", oracle_many != nullptr);
+        if (oracle_many) {
+            static int cpu_calls = 0;
+            SmallBatch::cpu_verify() = [](const uint8_t *dg, size_t stride, const uint8_t *pks, const uint8_t *sigs, size_t n, uint32_t mode, uint8_t *bm) -> int {
+                cpu_calls++;
+                std::vector<uint8_t> out(n ? n : 1);
+                oracle_many(dg, 32, stride, pks, sigs, n, mode == HS_ED25519_STRICT ? 1 : 0, out.data(), 1);
+                int all = 1;
+                for (size_t i = 0; i < n; i++) { if (bm && out[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); if (!out[i]) all = 0; }
+                return all; };
+            const unsigned long long f0 = detail::engine_faults().load();
+            // (three or four votes are below hs_ed25519_min_gpu_batch and would go to the CPU path by POLICY: a threshold of zero sends
+            //  every call to the engine first, so that what is tested is the fault path.  The library reads the variable per call.)
+            setenv("HS_ED25519_MIN_GPU_BATCH", "0", 1);
+            CHECK("with a threshold of zero every call reaches the engine first", SmallBatch::threshold(false) == 0 && !SmallBatch::on_cpu(1, false));
+            CHECK("engine fault + CPU verifier: a valid signature / batch / QC / TC is accepted through the fallback",
+                  x.sig[3].verify(x.digest, x.pk[3]).is_ok() && Signature::verify_batch(x.digest, votes).is_ok() &&
+                  Signature::verify_many(dgs, votes) == std::vector<bool>(3, true) && qc().verify(committee).is_ok() && tc.verify(committee).is_ok());
+            QC q_bad = qc(); q_bad.votes[1].second = x.qc_sig[0];
+            std::vector<std::pair<PublicKey, Signature>> bad_votes = votes; bad_votes[2].second = Signature{};
+            CHECK("engine fault + CPU verifier: an invalid one is rejected",
+                  x.sig[3].verify(x.bad_digest, x.pk[3]).is_err() && Signature::verify_batch(x.digest, bad_votes).is_err() &&
+                  Signature::verify_many(dgs, bad_votes) == std::vector<bool>({true, true, false}) && q_bad.verify(committee).is_err() && tc_bad.verify(committee).is_err());
+            std::vector<std::pair<Digest, std::vector<std::pair<PublicKey, Signature>>>> certs = {{x.digest, votes}, {x.digest, bad_votes}, {x.digest, {}}, {x.bad_digest, votes}};
+            const auto got = Signature::verify_batches(certs);
+            CHECK("engine fault + CPU verifier: verify_batches answers every certificate on the CPU",
+                  got.size() == 4 && got[0].is_ok() && got[1].is_err() && got[2].is_ok() && got[3].is_err());
+            CHECK("every one of those calls was counted as an engine fault", detail::engine_faults().load() >= f0 + 12 && cpu_calls >= 12);
+            SmallBatch::cpu_verify() = nullptr;
+        }
+    }
     printf("%d failed\n", failures);
     return failures;
 }

@@ -9,7 +9,7 @@ import re
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import ROOT, oracle_verify_many
 from hotstuff_amd import _lib
 from hotstuff_amd.crypto import CryptoError, Digest, PublicKey, Signature
 from hotstuff_amd.messages import (QC, TC, AuthorityReuse, Committee, QCRequiresQuorum, TCRequiresQuorum,
@@ -126,6 +126,60 @@ def test_no_gpu_means_loud_failure_never_success():
     c = Committee({PublicKey(bytes([i]) * 32): 1 for i in range(4)})
     with pytest.raises(InvalidSignature):
         TC(3, [(PublicKey(bytes([i]) * 32), Signature(), 1) for i in range(3)]).verify(c)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="without a GPU every call is an engine fault: the fault path itself")
+def test_an_engine_fault_is_answered_by_the_embedders_cpu_verifier_in_every_entry_point(oracle, openssl_vectors):
+    """the shim text fell back to dalek on `rc < 0` in verify_batch only - a device fault during a
+    view change would have rejected a valid TC.  With crypto.cpu_verify set (here: the test oracle's per-signature laws, what the
+    shim's dalek bodies are) verify, verify_batch, verify_many, QC::verify and TC::verify all answer on the CPU: valid accepted,
+    invalid rejected, never Ok on error; without it, every one of them still raises."""
+    import hashlib
+    import struct
+    from hotstuff_amd import crypto
+    from hotstuff_amd.messages import InvalidSignature
+    import synth
+    fx, keys, committee, votes = _fixture(openssl_vectors)
+
+    def cpu(digests, stride, pks, sigs, n, mode):
+        return [bool(b) for b in oracle_verify_many(oracle, digests, stride, pks, sigs, n, 1 if mode == _lib.STRICT else 0, threads=1)]
+    qc = QC(Digest(), 1, votes)
+    rnd, hq = 9, [3, 5, 5]
+    seeds = [synth.key_seed(7100 + i) for i in range(3)]
+    tc_votes = []
+    for s_, h in zip(seeds, hq):
+        pk_, sg_ = synth.sign(s_, hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32])
+        tc_votes.append((PublicKey(pk_), Signature.from_bytes(sg_), h))
+    tc_committee = Committee({v[0]: 1 for v in tc_votes})
+    tc = TC(rnd, tc_votes)
+    d = qc.digest()
+    assert crypto.cpu_verify is None
+    for call in (lambda: votes[0][1].verify(d, votes[0][0]), lambda: Signature.verify_batch(d, votes), lambda: Signature.verify_many([d] * len(votes), votes)):
+        with pytest.raises(CryptoError):
+            call()
+    with pytest.raises(InvalidSignature):
+        tc.verify(tc_committee)
+    crypto.cpu_verify = cpu
+    try:
+        f0 = crypto.engine_faults
+        votes[0][1].verify(d, votes[0][0])
+        Signature.verify_batch(d, votes)
+        assert Signature.verify_many([d] * len(votes), votes) == [True] * len(votes)
+        qc.verify(committee)
+        tc.verify(tc_committee)
+        assert crypto.engine_faults == f0 + 5
+        with pytest.raises(CryptoError):
+            votes[0][1].verify(Digest(bytes(32)), votes[0][0])
+        bad = [votes[0], (votes[1][0], Signature.default())] + votes[2:]
+        with pytest.raises(CryptoError):
+            Signature.verify_batch(d, bad)
+        assert Signature.verify_many([d] * len(bad), bad) == [True, False] + [True] * (len(bad) - 2)
+        with pytest.raises(InvalidSignature):
+            QC(Digest(), 1, bad).verify(committee)
+        with pytest.raises(InvalidSignature):
+            TC(rnd, [(a, s_, h + (i == 1)) for i, (a, s_, h) in enumerate(tc_votes)]).verify(tc_committee)      # a vote claiming another high_qc_round
+    finally:
+        crypto.cpu_verify = None
 
 
 def test_context_hints_reject_a_null_context():

@@ -59,7 +59,9 @@ def _fixture(tmp_path):
 
 
 def _run(tmp_path):
-    r = subprocess.run([_build(tmp_path), _fixture(tmp_path)], capture_output=True, text=True, timeout=120)
+    # HS_ORACLE_SO: the CPU verifier of the fault-injection case (test infrastructure, loaded by the test program at run time)
+    env = dict(os.environ, HS_ORACLE_SO=os.path.join(ROOT, "oracle", "libhs_oracle.so"))
+    r = subprocess.run([_build(tmp_path), _fixture(tmp_path)], capture_output=True, text=True, timeout=120, env=env)
     lines = [l for l in r.stdout.splitlines() if l[:4] in ("ok  ", "FAIL")]
     return r.returncode, {l[5:]: l.startswith("ok") for l in lines}
 
@@ -68,7 +70,7 @@ def _run(tmp_path):
 def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
     assert torch.cuda.is_available()
     rc, cases = _run(tmp_path)
-    assert len(cases) == 49, cases
+    assert len(cases) == 56, cases
     assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
 
 
@@ -95,6 +97,16 @@ def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
                  "hs_ed25519_verify_shared_sharded on one device slot"):
         assert not cases[name], name          # would need the GPU: must not be Ok
     assert rc != 0
+    # an engine fault is not a verdict (round 6): no GPU here, so EVERY call is an engine fault - without a CPU verifier all Err,
+    # with one (the test oracle) valid certificates are accepted and invalid ones rejected, in every entry point
+    for name in ("engine shut down, no CPU verifier: every entry point is Err, none Ok",
+                 "the test oracle (the CPU verifier of the fault-injection case) loads",
+                 "with a threshold of zero every call reaches the engine first",
+                 "engine fault + CPU verifier: a valid signature / batch / QC / TC is accepted through the fallback",
+                 "engine fault + CPU verifier: an invalid one is rejected",
+                 "engine fault + CPU verifier: verify_batches answers every certificate on the CPU",
+                 "every one of those calls was counted as an engine fault"):
+        assert cases[name], name
 
 
 if __name__ == "__main__":      # python tests/test_gpu_cpp_mirror.py fixture <path>: the fixture file alone (the sanitizer runs of the mirror)

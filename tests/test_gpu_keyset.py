@@ -318,3 +318,31 @@ def test_destroy_waits_for_tickets_in_flight_on_the_key_set(oracle):
     assert bits(bm, n) == expect
     assert done.wait(5), "destroy did not return after the last ticket was collected"
     t.join()
+
+
+def test_destroy_is_not_held_by_a_collected_burst_left_open(oracle):
+    """every ticket of a burst flagged HS_ED25519_SUBMIT_MORE ("launches when any ticket is waited on") has been
+    collected, the submitting thread submits nothing else - the thread's own reference to its open group used to pin the key set
+    (and the pool context) until that thread's next submit or exit: hs_ed25519_keyset_destroy spun ten seconds and leaked the
+    tables.  The last collected member now gives both back."""
+    import time
+    n = 300
+    dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
+    keys = [pk[32 * i:32 * i + 32] for i in range(n)]
+    ks = _lib.KeySet(keys)
+    packed, idx = ks.indices(keys)
+    tks = [_lib.Ticket(dg, packed, sg, n, _lib.BATCH, shared=True, keyset=ks, more=True) for _ in range(3)]
+    for tk in tks:
+        ok, bm = tk.wait()
+        assert ok and all(bits(bm, n))
+    t0 = time.perf_counter()
+    ks.close()
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, "keyset_destroy took %.2f s after every ticket of the open burst had been collected" % dt
+    # the thread's stale reference to that group is harmless: its next burst starts a group of its own
+    ks2 = _lib.KeySet(keys)
+    packed2, _ = ks2.indices(keys)
+    tk = _lib.Ticket(dg, packed2, sg, n, _lib.BATCH, shared=True, keyset=ks2, more=True)
+    ok, bm = tk.wait()
+    assert ok and all(bits(bm, n))
+    ks2.close()

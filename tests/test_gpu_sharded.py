@@ -216,11 +216,12 @@ def test_one_combination_falls_back_to_the_host_exchange_when_rccl_cannot_be_set
     try:
         n = 1500
         dg, pk, sg = synth.make_batch(n, shared=True, cache_dir=CACHE)
-        f0 = lib.hs_ed25519_shard_msm_stats(None, None)
+        f0 = _lib.shard_rccl_fallbacks()
+        assert lib.hs_ed25519_shard_msm_stats(None, None) == 0      # a status, like every other int-returning entry point
         c0, a0 = _lib.shard_msm_stats()
         ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)
         assert ok and all(bits(bm, n)) and _lib.shard_msm_stats() == (c0 + 1, a0 + 1)
-        assert lib.hs_ed25519_shard_msm_stats(None, None) == f0 + 1
+        assert _lib.shard_rccl_fallbacks() == f0 + 1 and lib.hs_ed25519_shard_msm_stats(None, None) == 0
         dg, pk, sg, bad = synth.corrupt(dg, pk, sg, n, True, rate_byte=20)
         expect = oracle_verify_many(oracle, dg, 0, pk, sg, n, 0)
         ok, bm = _lib.verify_packed_sharded(dg, pk, sg, n, _lib.BATCH_RLC, True, want_bitmap=True)

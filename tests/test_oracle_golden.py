@@ -295,3 +295,32 @@ def test_what_no_independent_implementation_pins(edge_vectors, torsion_fuzz):
     cases = _all_labelled(edge_vectors, torsion_fuzz)
     noncanon = [n for n, m, p, s, v in cases if not referees.encoding_is_canonical(s[:32], E.decompress)]
     assert len(noncanon) == 6 and all(n.startswith("smallorder:R=") for n in noncanon)
+
+
+def test_tc_loop_is_hash_then_strict_verify(oracle, edge_vectors):
+    """hs_oracle_verify_tc (the CPU twin bench.py times beside hs_ed25519_verify_tc) is the reference's loop
+    (consensus/src/messages.rs:307-313): per vote SHA-512(round_le || high_qc_round_le)[..32] by hashlib, then the strict law -
+    held to hs_oracle_verify_many on the same digests, over honest votes, a vote that claims another high_qc_round than it signed,
+    a corrupted signature, and a small-order key (strict's extra rejection), on one thread and on three."""
+    import ctypes
+    import hashlib
+    import struct
+    import synth
+    n, rnd = 40, 1_000_003
+    hq = [rnd - 1 - (i * 7919) % 50 for i in range(n)]
+    dg = [hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq]
+    pks, sgs = bytearray(), bytearray()
+    for i in range(n):
+        p, s_ = synth.sign(synth.key_seed(9000 + i), dg[i])
+        pks += p; sgs += s_
+    hq[7] += 1                                   # signed over another high_qc_round
+    sgs[64 * 11 + 3] ^= 4                        # corrupted signature
+    small = next(v for v in edge_vectors if v.get("strict") is False and v.get("cofactorless") is True)
+    pks[32 * 20:32 * 21] = H(small["pk"])        # a key strict refuses whatever the signature
+    digests = b"".join(hashlib.sha512(struct.pack("<QQ", rnd, h)).digest()[:32] for h in hq)
+    expect = oracle_verify_many(oracle, digests, 32, bytes(pks), bytes(sgs), n, 1, threads=1)
+    assert [i for i in range(n) if not expect[i]] == [7, 11, 20]
+    for threads in (1, 3):
+        out = ctypes.create_string_buffer(n)
+        oracle.hs_oracle_verify_tc(ctypes.c_uint64(rnd), struct.pack("<%dQ" % n, *hq), bytes(pks), bytes(sgs), S(n), out, threads)
+        assert out.raw[:n] == expect

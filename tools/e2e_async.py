@@ -21,13 +21,18 @@ bufs.append(ctypes.create_string_buffer(struct.pack("<%dI" % (n * nb), *range(n 
 a = [ctypes.addressof(x) for x in bufs]
 ks = _lib.KeySet([b[1][32 * i:32 * i + 32] for b in batches for i in range(n)]) if cached else None
 # threads x tickets in flight per thread x batches per launch (HS_ED25519_SUBMIT_MORE bursts)
-shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
+# a shape ending in "p": the same from caller-owned pinned buffers (hs_ed25519_host_alloc: read in place, no staging copy)
+pin = [_lib.PinnedBuffer(x.raw) for x in bufs[:3]]
+pa = [x.addr for x in pin]
+shapes = [tuple(int(v) for v in s.rstrip("p").split("x")) + (s.endswith("p"),) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
                                                                           "4x8x2", "4x16x4", "1x8x2", "1x16x2", "1x32x2", "1x32x4"])]
-tag = ("key-cache " if cached else "") + "pool=%s partitions=%s" % (os.environ.get("HS_ED25519_POOL_NARROW", "16"), os.environ.get("HS_ED25519_POOL_PARTITIONS", "8"))
-for th, k, bpl in shapes:
-    cv, pv, ev = _lib.loadgen(ks.handle if ks else None, a[0], 32, a[3] if ks else a[1], a[2], n, nb, _lib.STRICT, th, k, bpl, 0.5)
+cfg = _lib.config_dump()
+tag = ("key-cache " if cached else "") + "pool=%s depth=%s partitions=%s" % (cfg["pool_narrow"], cfg.get("pool_narrow_depth", 1), cfg["pool_partitions"])
+for th, k, bpl, pinned in shapes:
+    src = pa if pinned and not ks else a
+    cv, pv, ev = _lib.loadgen(ks.handle if ks else None, src[0], 32, a[3] if ks else src[1], src[2], n, nb, _lib.STRICT, th, k, bpl, 0.5)
 
     class _V:          # keep the print below as it was
         def __init__(self, v): self.value = v
     calls, p50, el = _V(cv), _V(pv), _V(ev)
-    print("%s threads=%d in_flight=%d per_launch=%d  %.1f M verifies/s  p50 %.3f ms" % (tag, th, k, bpl, calls.value * n / el.value / 1e6, p50.value), flush=True)
+    print("%s threads=%d in_flight=%d per_launch=%d%s  %.1f M verifies/s  p50 %.3f ms" % (tag, th, k, bpl, " caller-pinned" if pinned else "", calls.value * n / el.value / 1e6, p50.value), flush=True)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 gpurun visits.  gpurun --timeout 1500 -- 'bash tools/gpu_r5.sh <tag> <stage> [stage ...]'   (files land in gpurun_out/r5_<tag>_*)
+# gpurun visits (rounds 5 and 6).  gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> <stage> [stage ...]'   (files land in gpurun_out/r6_<tag>_*)
 #   tests   the GPU suite + smoke()
 #   bench   the driver's command; the line, its detail file and a one-screen summary
 #   diff    the scale differential: 10^7 crafted tuples through every kernel form + 10^7 / 10^5 scalars through half_scalar
@@ -7,13 +7,15 @@
 #   stream  BASELINE configs[4]: 10 s of back-to-back 6,667-signature rounds from one host thread through the ring
 #   cap     tools/capture_probe (which runtime calls of another thread break a thread-local capture) + the ring / key-set
 #           thread tests ten times over
+#   e2e     the host-API rate (tools/e2e_async.py) against the narrow pool's shape: HS_ED25519_POOL_PARTITIONS x HS_ED25519_POOL_DEPTH, one
+#           process per shape (the knobs are read at init); E2E_SHAPES / E2E_CONFIGS override the rows
 #   san     the host side under -fsanitize=thread and address,undefined (python -c "import __graft_entry__ as g; g.build_sanitized()"
 #           first, here: build/san/ travels with the snapshot): canary, the 15-thread stress client, the C++ mirror tests
 tag=${1:-a}; shift
 mkdir -p gpurun_out
 export HS_SYNTH_CACHE=/tmp/hs_synth
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5_${tag}
+O=gpurun_out/${HS_ROUND:-r6}_${tag}
 for stage in "$@"; do
 case $stage in
 tests)
@@ -34,10 +36,19 @@ for l in open(sys.argv[1]):
     print("QC N=%s: cold p50 %s ms (kernel %s, %s by %s; fused8 %s / fused8h %s ms here, autotune %s / %s), key cache p50 %s ms (kernel %s); host API %s / %s ms" % (
         g("qc_validators"), g("qc_verify_p50_ms_cold"), g("qc_kernel_ms_cold"), g("qc_cold_form_chosen"), g("qc_cold_form_chosen_by"), g("qc_kernel_ms_verify_fused8"), g("qc_kernel_ms_verify_fused8h"),
         g("autotune_ms_verify_fused8"), g("autotune_ms_verify_fused8h"), g("qc_verify_p50_ms_key_cache"), g("qc_kernel_ms_key_cache"), g("qc_verify_p50_ms_cold_host_api"), g("qc_verify_p50_ms_key_cache_host_api")))
-    print("e2e 16x8 %s  one sync caller 1,024: %s (%s ms)  QC cold %s  QC cached %s | 4 tenants %s (spread %s) | streamed %s / %s | cached list %s, 66,667: %s ms frac %s" % (
-        g("end_to_end_verifies_per_s_16_threads_x_8_tickets"), g("end_to_end_verifies_per_s_one_sync_caller_1024"), g("end_to_end_call_p50_ms_one_sync_caller_1024"),
-        g("one_sync_caller_verifies_per_s_qc_cold"), g("one_sync_caller_verifies_per_s_qc_key_cache"), g("four_tenants_verifies_per_s"), g("four_tenants_max_over_min"),
-        g("streamed_rounds_cold_signatures_per_s"), g("streamed_rounds_key_cache_signatures_per_s"), g("committee_cached_verifies_per_s"), g("cached_qc_66667_kernel_ms"), g("cached_qc_66667_hbm_frac")))
+    print("host->host best %s (%s)  one thread %s (%s)  16x8 %s | one sync caller 1,024: %s (%s ms)  QC cold %s  QC cached %s | 4 tenants %s (spread %s), bursts of 4: %s" % (
+        j.get("value_host_to_host"), g("end_to_end_best_shape"), g("e2e_one_thread_tickets_verifies_per_s"), g("e2e_one_thread_tickets_shape"), g("e2e_16_threads_x_8_tickets_verifies_s"),
+        g("one_sync_caller_1024_verifies_per_s"), g("one_sync_caller_1024_call_p50_ms"), g("one_sync_caller_verifies_per_s_qc_cold"), g("one_sync_caller_verifies_per_s_qc_cached"),
+        g("four_tenants_verifies_per_s"), g("four_tenants_max_over_min"), g("four_tenants_bursts_of_4_verifies_per_s")))
+    print("TC N=%s: cold p50 %s ms (kernel %s), key cache %s (kernel %s); host API %s / %s | CPU twins (%s cores): QC verify_batch %s / %s ms, TC loop %s / %s ms" % (
+        g("tc_validators"), g("tc_verify_p50_ms_cold"), g("tc_kernel_ms_cold"), g("tc_verify_p50_ms_key_cache"), g("tc_kernel_ms_key_cache"), g("tc_verify_p50_ms_cold_host_api"),
+        g("tc_verify_p50_ms_key_cache_host_api"), g("cpu_cores"), g("cpu_qc_verify_batch_p50_ms_one_core"), g("cpu_qc_verify_batch_p50_ms_all_cores"),
+        g("cpu_tc_verify_p50_ms_one_core"), g("cpu_tc_verify_p50_ms_all_cores")))
+    print("QC alternating %s / %s | streamed %s / %s | cached list %s, 66,667: %s ms frac %s | lane2r states/wave_cycles %s wait_any %s wait_inst %s active %s of %s" % (
+        g("qc_verify_p50_ms_cold_alternating"), g("qc_verify_p50_ms_key_cache_alternating"), g("streamed_cold_signatures_per_s"), g("streamed_key_cache_signatures_per_s"),
+        g("committee_cached_verifies_per_s"), g("cached_qc_66667_kernel_ms"), g("cached_qc_66667_hbm_frac"), g("sq_verify_cached_lane2r_states_over_wave_cycles"),
+        g("sq_verify_cached_lane2r_wait_any"), g("sq_verify_cached_lane2r_wait_inst_any"), g("sq_verify_cached_lane2r_active_any"), g("sq_verify_cached_lane2r_wave_cycles")))
+    print("first 24 config keys:", list(c)[:24])
     print("cpu", j.get("cpu_baseline", {}).get("value"), "detail", j.get("detail_file"), "config keys", len(c))
 PY
     tail -3 ${O}_bench.err | cut -c1-300
@@ -54,8 +65,8 @@ for k in ('random', 'adversarial'):
 "
     ;;
 prof)
-    timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r5_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
-    python tools/rocpd_summary.py $(find /tmp/r5_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
+    timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/r6_kth -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu --no-extras > ${O}_bench_headline_under_rocprof.json.txt 2> ${O}_kth.err; echo "rocprofv3 rc=$?"
+    python tools/rocpd_summary.py $(find /tmp/r6_kth -name "*results.db" | head -1) > ${O}_bench_headline_kernel_stats.csv; head -4 ${O}_bench_headline_kernel_stats.csv | cut -c1-160
     ;;
 stream)
     timeout 120 python tools/streamed_10s.py 10 > ${O}_streamed_10s.md 2> ${O}_streamed_10s.err; echo "streamed_10s rc=$?"; cat ${O}_streamed_10s.md
@@ -74,6 +85,14 @@ PY
         timeout 300 python -m pytest tests/test_gpu_ring.py tests/test_gpu_keyset.py -x -q -m gpu -s -k "captures or synchronises or destroy_waits" > ${O}_cap_pytest_$i.txt 2>&1
         echo "run $i rc=$? $(grep -E 'passed|failed' ${O}_cap_pytest_$i.txt | tail -1) $(grep -h 'device synchronisations' ${O}_cap_pytest_$i.txt)"
     done
+    ;;
+e2e)
+    : > ${O}_e2e_pool_shape.md
+    for cfg in ${E2E_CONFIGS:-8:1 8:2 4:1 4:2}; do
+        HS_ED25519_POOL_PARTITIONS=${cfg%%:*} HS_ED25519_POOL_DEPTH=${cfg##*:} timeout 300 python tools/e2e_async.py ${E2E_SHAPES:-1x1x1 16x1x1 16x2x2 16x4x4 16x8x8 16x16x16 4x32x16 4x64x16 1x256x16 1x512x16} >> ${O}_e2e_pool_shape.md 2>> ${O}_e2e.err
+        echo >> ${O}_e2e_pool_shape.md
+    done
+    cat ${O}_e2e_pool_shape.md
     ;;
 san)
     for kind in tsan asan; do

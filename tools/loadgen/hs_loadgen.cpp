@@ -17,6 +17,7 @@
 // -100 (bad arguments) / -101 (a call rejected its valid batch).
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -44,6 +45,7 @@ extern "C" int hs_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, s
             while (!go.load()) std::this_thread::yield();
             if (inflight > 1) {          // a window of tickets: submit until full (or the pool is busy), then collect the oldest
                 const unsigned burst = batches_per_launch < 1 ? 1 : (batches_per_launch > inflight ? inflight : batches_per_launch);
+                const bool any_order = getenv("HS_LOADGEN_ANY") != nullptr;
                 std::deque<std::pair<hs_ed25519_ticket *, std::chrono::steady_clock::time_point>> win;
                 auto collect = [&]() -> bool {
                     const int rc = hs_ed25519_ticket_wait(win.front().first, nullptr);
@@ -70,6 +72,12 @@ extern "C" int hs_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, s
                     }
                     if (!ok) break;
                     if (win.empty()) { std::this_thread::yield(); continue; }
+                    if (any_order && win.size() > burst) {
+                        // an async host awaits its tickets concurrently: take whichever burst has completed (hs_ed25519_ticket_ready on
+                        // its first ticket) before blocking on the oldest
+                        for (size_t i = burst; i + burst <= win.size(); i += burst)
+                            if (hs_ed25519_ticket_ready(win[i].first) == 1) { std::rotate(win.begin(), win.begin() + (long)i, win.begin() + (long)(i + burst)); break; }
+                    }
                     ok = collect();
                 }
                 while (!win.empty()) if (!collect()) { while (!win.empty()) { (void)hs_ed25519_ticket_wait(win.front().first, nullptr); win.pop_front(); } }

@@ -26,15 +26,12 @@ def row(k, shape, env, tenancy=True):
 
 row(1, (4, 8, 4), {}, False)
 row(1, (4, 32, 16), {}, False)
-# the default tenant pools (4 narrow contexts on two 32-CU slices) at bursts of four and sixteen, then other splits of the
-# tenant's 64 CUs at BOTH burst sizes (round 4's second shape, 3 contexts on one 64-CU slice, was chosen on bursts of sixteen
-# alone and lost a quarter at bursts of four)
-SPLITS = ({}, {"HS_ED25519_POOL_NARROW": "4", "HS_ED25519_POOL_PARTITIONS": "1"}, {"HS_ED25519_POOL_NARROW": "3", "HS_ED25519_POOL_PARTITIONS": "1"},
-          {"HS_ED25519_POOL_NARROW": "6", "HS_ED25519_POOL_PARTITIONS": "2"})
+# the default tenant pools (round 6: 4 narrow streams x 2 contexts on the tenant's ONE 64-CU slice) at bursts of four and sixteen, then
+# round 5's split (two 32-CU slices) and queue depth 1, at both burst sizes
+SPLITS = ({}, {"HS_ED25519_POOL_PARTITIONS": "2"}, {"HS_ED25519_POOL_DEPTH": "1"}, {"HS_ED25519_POOL_PARTITIONS": "2", "HS_ED25519_POOL_DEPTH": "1"})
 for env in SPLITS:
-    for shape in ((4, 8, 4), (4, 32, 16), (1, 8, 4), (1, 32, 16)):
+    for shape in ((4, 8, 4), (4, 32, 16), (1, 128, 16), (2, 64, 16)):
         row(4, shape, env)
-row(4, (4, 8, 4), {}, False)
 row(4, (4, 32, 16), {}, False)
 row(2, (4, 8, 4), {})
-row(2, (4, 32, 16), {})
+row(2, (4, 64, 16), {})

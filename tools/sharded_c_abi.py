@@ -77,6 +77,16 @@ def main():
                 out[name]["rccl_ranks"] = lib.hs_ed25519_shard_rccl_ranks()      # communicators ncclCommInitAll gave this process
         except Exception as e:
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # what the first real multi-GPU record has to say about itself, flat (bench.py lifts top-level scalars into `config`): how many
+    # ranks the in-process RCCL communicators span, how many exchanges fell back to pinned host memory (and why), each slot's pick
+    try:
+        out["rccl_ranks"] = lib.hs_ed25519_shard_rccl_ranks()
+        out["rccl_fallbacks"] = _lib.shard_rccl_fallbacks()
+        if out["rccl_fallbacks"]:
+            out["rccl_fallback_reason"] = _lib.last_error()[:120]
+        out["autotune_picks"] = ",".join(d.get("oct_pick", "?").replace("k_verify_", "") for d in _lib.config_dump()["devices"])
+    except Exception as e:
+        out["rccl_ranks_error"] = "%s: %s" % (type(e).__name__, e)
     # the committee registered as a key set on every GPU: whole table per GPU, or each GPU the keys it owns
     try:
         lib.hs_ed25519_set_shard_exchange(_lib.EXCHANGE_HOST)
