@@ -1171,8 +1171,12 @@ def main():
     # the GPU: `fab local` has no fifth GPU process, and a bench that already holds ~20 hardware queues of its own beside the
     # tenants pushed the driver's runlist into oversubscription - the tenants were then time-sliced (round 3's 39-46 M
     # verifies/s and the 2.8x spread between identical tenants; tools/queue_probe.py, profiles/r4_queue_probe.md)
+    # measurement aid: HS_BENCH_ONLY="qc_verify_latency,tc_verify_latency" runs the headline and only the named extras
+    only = set(x for x in os.environ.get("HS_BENCH_ONLY", "").split(",") if x)
+    if only:
+        args.no_cached = args.no_pmc = args.no_cpu = True
     mp_early = None
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_extras or args.no_qc):
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_extras or args.no_qc) and (not only or "multi_process" in only):
         try:
             mp_early = multi_process(args.batch)
             mp_early["ran"] = "before this process initialised the GPU (no fifth GPU process beside the tenants)"
@@ -1525,7 +1529,7 @@ def main():
     elif pmc and "error" in pmc:
         traffic_src = "unmeasured: " + pmc["error"][:90]
     e2e = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and (not only or "end_to_end" in only):
         try:
             e2e = end_to_end(_lib, batches, n, stride, mode)
         except Exception as e:
@@ -1643,6 +1647,8 @@ def main():
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
                             ("multi_process", lambda: mp_early if mp_early is not None else multi_process(n))):
+                if only and key not in only:
+                    continue
                 try:
                     detail[key] = fn()
                 except Exception as e:        # extras never cost the headline line
