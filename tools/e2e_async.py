@@ -11,7 +11,12 @@ import synth  # noqa: E402
 from hotstuff_amd import _lib  # noqa: E402
 
 n, nb = 1024, 16
-_lib.init(0, 8192)
+# HS_E2E_SLOTS=k: k device slots on GPU 0 (virtual devices: each slot its own base-point tables and pools; cold calls go round the slots)
+slots = int(os.environ.get("HS_E2E_SLOTS", "1"))
+if slots > 1:
+    _lib.init_devices([0] * slots, 8192)
+else:
+    _lib.init(0, 8192)
 lib = _lib.lib()
 batches = [synth.make_batch(n, shared=False, first=n * j, cache_dir="/tmp/hs_synth") for j in range(nb)]
 import struct  # noqa: E402
@@ -27,7 +32,7 @@ pa = [x.addr for x in pin]
 shapes = [tuple(int(v) for v in s.rstrip("p").split("x")) + (s.endswith("p"),) for s in (sys.argv[1:] or ["16x1x1", "16x2x1", "16x2x2", "16x4x2", "16x4x4", "8x4x2", "8x8x2", "8x8x4",
                                                                           "4x8x2", "4x16x4", "1x8x2", "1x16x2", "1x32x2", "1x32x4"])]
 cfg = _lib.config_dump()
-tag = ("key-cache " if cached else "") + "pool=%s depth=%s partitions=%s" % (cfg["pool_narrow"], cfg.get("pool_narrow_depth", 1), cfg["pool_partitions"])
+tag = ("key-cache " if cached else "") + ("slots=%d " % slots if slots > 1 else "") + "pool=%s depth=%s partitions=%s" % (cfg["pool_narrow"], cfg.get("pool_narrow_depth", 1), cfg["pool_partitions"])
 for th, k, bpl, pinned in shapes:
     src = pa if pinned and not ks else a
     cv, pv, ev = _lib.loadgen(ks.handle if ks else None, src[0], 32, a[3] if ks else src[1], src[2], n, nb, _lib.STRICT, th, k, bpl, 0.5)
