@@ -1174,7 +1174,8 @@ def main():
     # measurement aid: HS_BENCH_ONLY="qc_verify_latency,tc_verify_latency" runs the headline and only the named extras
     only = set(x for x in os.environ.get("HS_BENCH_ONLY", "").split(",") if x)
     if only:
-        args.no_cached = args.no_pmc = args.no_cpu = True
+        args.no_cached = args.no_cpu = True
+        args.no_pmc = "pmc" not in only
     mp_early = None
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_extras or args.no_qc) and (not only or "multi_process" in only):
         try:
