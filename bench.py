@@ -1151,7 +1151,7 @@ def main():
                     help="where the verbose extras go (the line carries their headline scalars in `config` and this path)")
     ap.add_argument("--partitions", type=int, default=None,
                     help="CU-masked streams: split the chip into this many slices (0 = plain streams; "
-                         "default 8 (one XCD each, two stream contexts per slice) for batches up to 4,096 signatures, 0 above)")
+                         "default 8 (32 CUs each, two stream contexts per slice) for batches up to 4,096 signatures, 0 above)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: become one (same ranks the driver's torch.distributed.run line starts)
@@ -1160,7 +1160,7 @@ def main():
         os.execv(cmd[0], cmd)
     if args.partitions is None:
         env = os.environ.get("HS_BENCH_PARTITIONS")
-        # 8 slices of 32 CUs = one XCD (its own L2) each, two stream contexts per slice: measured best for the quad kernels
+        # 8 slices of 32 CUs (4 on every XCD: profiles/r6_u_cu_mask_probe.md), two stream contexts per slice: measured best for the quad kernels
         # (profiles/r2_partition_sweep.txt: 16 x 16 CUs 43.9 M/s, 8 x 32 CUs with two streams each 51.1 M/s); the one-lane
         # pair over sixteen batches per launch wants wider slices: 4 x 64 CUs 88.6 M/s, 2 x 128 85.3, none 86.6, 8 x 32 lower
         lane_form = args.kernel == "lane" or (args.kernel == "auto" and args.batches_per_launch >= 8 and args.batches_per_launch * args.batch >= 8192)

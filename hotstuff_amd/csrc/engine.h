@@ -102,7 +102,7 @@ struct dev_state {
     int ordinal = -1;
     u32 *base_tab = nullptr;                 // key-cache path: the base point's own window table (8-bit windows; also the RLC path's [b]B)
     u32 *base_tab16 = nullptr;               // the base point's 16-bit window table (verify_cached.h: 16 x 32,769 x 128 B), built from base_tab
-    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one XCD-aligned slice of the CUs)
+    // the host API's pools of stream contexts on this device: [0] wide (whole chip), [1] narrow (one slice of the CU mask)
     std::vector<hs_ed25519_ctx *> free_ctx[2];
     int live[2] = {0, 0};
     unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)

@@ -778,7 +778,8 @@ static std::atomic<size_t> g_tail_max{kTailMax};      // HS_ED25519_TAIL_MAX: sw
 // pool, whose streams are confined to one slice of the CUs each: concurrent callers then occupy their own slices
 // of the chip instead of being stacked onto the same CUs by the dispatcher (bench.py `end_to_end`); one caller
 // alone loses nothing, its batch is at most one wavefront per SIMD either way.
-// The narrow pool's streams are confined to XCD-aligned slices of the chip: 8 slices of 32 CUs, two contexts on each.
+// The narrow pool's streams are confined to slices of the CU mask (until round 5: 8 slices of 32 CUs, two contexts on each; a slice is
+// the same share of EVERY XCD - the mask's bits are dealt round robin over the XCDs, profiles/r6_u_cu_mask_probe.md - not one XCD).
 // Two launches of two 1,024-signature batches then share a slice at two wavefronts per SIMD: 49-50 M verifies/s from
 // host buffers through hs_ed25519_submit bursts (16 slices of 16 CUs with one context each: 41.7 M - the two
 // wavefronts of a SIMD then come from ONE launch and run 18 % longer; profiles/r2_e2e_async.txt).  The synchronous
@@ -793,7 +794,7 @@ unsigned hs::kPoolPartitions = 4;               // HS_ED25519_POOL_PARTITIONS ov
 // benchmark/benchmark/local.py:94-104).  Every process brings its own pools - 16 narrow + 4 wide stream contexts - and
 // the device multiplexes all of them; past ~16 streams in flight throughput collapses (profiles/r1_stream_sweep.txt).
 // A process that knows it is tenant `index` of `tenants` on its GPU takes 1/tenants of the stream budget and confines its
-// narrow pool to its own 1/tenants of the CUs (XCD-aligned for 2, 4, 8 tenants), so co-tenants neither share hardware
+// narrow pool to its own 1/tenants of the CUs (of every XCD: see above), so co-tenants neither share hardware
 // queues nor stack their small batches on the same CUs.  hs_ed25519_set_tenancy before init, or the environment
 // (HS_ED25519_TENANTS / HS_ED25519_TENANT_INDEX); default 1 / 0 = the whole chip.
 unsigned hs::kTenants = 1, hs::kTenantIndex = 0;

@@ -1,5 +1,5 @@
 // hs_host.hip - the host-pointer side of libhs_ed25519.so (include/hs_ed25519.h): what the reference's shim binds.
-//   pools of stream contexts per device slot (wide / narrow = confined to an XCD-aligned slice of the CUs)
+//   pools of stream contexts per device slot (wide / narrow = confined to a slice of the CU mask: the same share of every XCD, profiles/r6_u_cu_mask_probe.md)
 //   hs_ed25519_verify_{shared,multi}[_cached], hs_ed25519_verify_tc[_cached]      synchronous, host buffers in, verdict out
 //   hs_ed25519_submit / ticket_ready / ticket_wait                                asynchronous; the small calls of a burst share a launch
 //   hs_ed25519_ring_*                                                             streamed rounds through pinned slots (BASELINE config 5)

@@ -1,12 +1,13 @@
 """Asynchronous host-pointer verification (hs_ed25519_submit / hs_ed25519_ticket_wait) and the launch-sharing of
 small host calls (HS_ED25519_SUBMIT_MORE): every verdict and bitmap vs the oracle."""
+import os
 import threading
 
 import pytest
 import torch
 
 import synth
-from conftest import bits, oracle_verify_many
+from conftest import ROOT, bits, oracle_verify_many
 from hotstuff_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -230,3 +231,24 @@ def test_a_caller_that_holds_nothing_waits_for_the_pool_instead_of_growing_it(or
     assert not a.is_alive() and not b.is_alive(), "deadlock"
     assert 1 <= state["held"] <= 8 and state["holder_ok"] and state["caller_ok"]
     assert state["caller_waited"] >= 2.4 and state["caller_done_at"] >= state["released_at"]
+
+
+def test_a_pool_created_by_sixteen_threads_runs_like_one_created_by_one():
+    """Round 6's finding: sixteen threads whose FIRST calls created the narrow pool's CU-masked streams concurrently left the
+    process at 86 - 88 M verifies/s for good, where the same pool created by one thread ran 102 - 105 M (profiles/
+    r6_j_pool_creation_order.md).  pool_get now creates the pool's streams in turn whoever asks first.  Two fresh processes, the
+    same bursts of sixteen from four threads, after a first row of sixteen threads / of one thread: the rates must agree (the
+    bug was a ratio of 0.84; run-to-run scatter is ~2 %)."""
+    import re
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "e2e_async.py")
+
+    def rate(first):
+        r = subprocess.run([sys.executable, tool, first, "4x128x16", "4x128x16"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HS_SYNTH_CACHE=os.environ.get("HS_SYNTH_CACHE", "/tmp/hs_synth")))
+        rows = re.findall(r"threads=4 in_flight=128 per_launch=16\s+([0-9.]+) M verifies/s", r.stdout)
+        assert len(rows) == 2, r.stdout + r.stderr[-2000:]
+        return max(float(x) for x in rows)
+    many, one = rate("16x16x16"), rate("1x256x16")
+    assert many >= 0.92 * one, "pool created by sixteen threads: %.1f M verifies/s, by one thread: %.1f M" % (many, one)

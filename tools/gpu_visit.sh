@@ -99,7 +99,7 @@ san)
         d=build/san/$kind
         [ -x $d/stress_host ] || { echo "no $kind build"; continue; }
         if [ $kind = tsan ]; then export TSAN_OPTIONS="suppressions=$PWD/tests/cpp/tsan.supp history_size=4 second_deadlock_stack=1 exitcode=66 log_path=$PWD/${O}_tsan_report"
-        else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"; fi
+        else export ASAN_OPTIONS="detect_leaks=0 exitcode=67 log_path=$PWD/${O}_asan_report protect_shadow_gap=0 quarantine_size_mb=4096" UBSAN_OPTIONS="print_stacktrace=1"; fi
         timeout 60 $d/stress_host canary > ${O}_${kind}_canary.txt 2>&1; echo "$kind canary rc=$? (66 / 67 = the detector fired)"
         rm -f ${O}_${kind}_report*
         timeout 600 $d/stress_host ${HS_STRESS_SECONDS:-6} > ${O}_${kind}_stress.txt 2>&1; echo "$kind stress_host rc=$?"; tail -2 ${O}_${kind}_stress.txt
