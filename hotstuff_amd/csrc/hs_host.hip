@@ -111,6 +111,13 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
         }
     }
     const unsigned lane = (unsigned)(g_devs[slot].live[k] - 1) % (unsigned)(kMaxPool[k] > 0 ? kMaxPool[k] : 1);
+    // Lane l serves slice l mod (slices): CONSECUTIVELY created streams go to DIFFERENT slices.  Not a detail (round 6, profiles/
+    // r6_x_lane_map.md): the streams get their hardware queues in creation order and consecutive queues sit on different pipes of the
+    // command processor, so this way the streams of ONE slice share a pipe (lanes s, s + 4, s + 8, s + 12).  The other way round -
+    // lanes 4 s ... 4 s + 3 on slice s, every pipe serving all four slices - the same sixteen streams run 85 - 86 M verifies/s instead
+    // of 103 - 104 M: a dispatch that cannot place its wavefronts yet (its slice's SIMDs are full) holds its pipe, and the queues of
+    // the OTHER slices behind it on that pipe wait although their SIMDs are free.  Which is what a pool created by sixteen threads
+    // at once got wrong at random (86 - 88 M, r6_j): the ORDER of creation, not its concurrency - hence creation in turn, below.
     const unsigned part = lane % kPoolPartitions, cus = g_devs[slot].cus;
     const bool others_busy = k == 0 && g_devs[slot].live[0] - (int)g_devs[slot].free_ctx[0].size() > 1;
     const int ordinal = g_devs[slot].ordinal;
@@ -128,8 +135,8 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     // Pool contexts are created one at a time, and the narrow pool's CU-masked streams all at once, in lane order, by whichever
     // thread needs the first of them (round 6).  Sixteen threads whose first calls created the pool CONCURRENTLY left the
     // process at 86 - 88 M verifies/s for good where a pool created by one thread ran 102 - 105 M on the same GPU, same load
-    // (profiles/r6_j_pool_creation_order.md): streams created with hipExtStreamCreateWithCUMask in parallel do not end up
-    // configured as the same streams created in turn.
+    // (profiles/r6_j_pool_creation_order.md): created in parallel the streams get their hardware queues - and with them their
+    // pipes - in a random order (the masks themselves are applied either way); see `part` above for why the order matters.
     static std::mutex s_create_mu;
     std::lock_guard<std::mutex> creating(s_create_mu);
     if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the tenant's CUs
