@@ -51,6 +51,14 @@ __device__ const u32 *g_b16;                      // window 0 of the base point'
 #ifndef HS_LANE_WAVES
 #define HS_LANE_WAVES 2                 // wavefronts per SIMD the one-lane stage 2 is compiled for (3 = 168 VGPRs with 36 B of spills: measured equal)
 #endif
+// ... and THREE for its batch-list form (round 6).  Device-resident, deep queues: equal (104.6 - 105.1 against 103.9 - 104.6 M).  From
+// host buffers, where every stream holds one or two launches: a third sixteen-batch launch now FITS its 64-CU slice instead of
+// holding the slice's pipe until one of two ends (hs_host.hip pool_get, profiles/r6_x_lane_map.md) - bursts of eight 85 - 86 ->
+// 88 - 90 M verifies/s, one thread with tickets 100 - 102 -> 104 M, and four tenants at bursts of sixteen 83.6 -> 92 M, whose
+// blocked pipes are shared with the OTHER tenants' queues (profiles/r6_af_lane_waves_ab.md).
+#ifndef HS_LANE_LIST_WAVES
+#define HS_LANE_LIST_WAVES 3
+#endif
 // (64, 3): at most 168 VGPRs so that three wavefronts fit a SIMD next to the quad kernels
 __global__ void __launch_bounds__(64, 3)
 k_prepare(workspace ws, msg_src msgs, const u32 *__restrict__ pks, const u32 *__restrict__ sigs, u32 n, u32 mode,
@@ -146,7 +154,7 @@ k_prepare_batches(lane_batch_list L) {
     }
     prepare_point(B.ws, i0 + threadIdx.x, is_r, s_pk + 8 * threadIdx.x, s_sig + 16 * threadIdx.x, msg, B.mode);
 }
-__global__ void __launch_bounds__(64, HS_LANE_WAVES)
+__global__ void __launch_bounds__(64, HS_LANE_LIST_WAVES)
 k_verify_batches(lane_batch_list L) {
     u32 k = 0;
 #pragma unroll
