@@ -102,7 +102,10 @@ uint32_t hs_ed25519_abi_version(void);
  * initialises - the host's main() exports it before any thread starts.  When the
  * variable is missing or smaller than the budget, init still succeeds and hs_ed25519_last_error() holds a warning
  * text ("hs_ed25519_init: warning: ...").  HS_ED25519_SET_ENV=1 restores the old behaviour (setenv without
- * overwrite) for single-threaded hosts that want it. */
+ * overwrite) for single-threaded hosts that want it.
+ * The timing of the two kernel forms runs AFTER the engine has been marked initialised (it uses ordinary calls on a pool
+ * context): a second thread whose calls arrive while another thread is still inside its first hs_ed25519_init is served, and
+ * the pick is then measured under that load - call init once, before the callers start. */
 int hs_ed25519_init(int device, size_t max_batch);
 void hs_ed25519_shutdown(void);
 /* Human-readable text of the last engine error (or init warning) seen by the calling thread. */
