@@ -14,9 +14,10 @@ issues independent certificates.  With the driver's `--steps 20 --warmup 5` the 
 ~0.2 s, steady state whatever `steps` is.  The timed region is bracketed by a barrier and a device synchronize on both
 sides; the maximum over ranks is taken.
 
-`value` is the HBM-resident rate the contract asks for.  `end_to_end` (same JSON line) is SURVEY.md
-8d's metric proper - host buffers in, host verdict out through the host-pointer C ABI
-(hs_ed25519_verify_multi from 16 host threads; pinned staging, PCIe both ways included).
+`value` is the HBM-resident rate the contract asks for.  `value_host_to_host` (same JSON line, = config.end_to_end_verifies_per_s_best)
+is SURVEY.md 8d's metric proper - host buffers in, host verdict out through the host-pointer C ABI (tickets from 1 - 16 native
+host threads; pinned staging, PCIe both ways included).  `config` opens with the keys that ARE the metric, in the order the
+driver's record keeps them (CONFIG_FIRST / finalize_line): QC and TC p50 cold / key cache, their CPU twins, the host-to-host rates.
 
 With N > 1 every rank verifies its own independent batches (weak scaling; the units are independent,
 SURVEY.md 8e, so the headline has no data-path collective).  The workload with a real exchange step -
@@ -34,7 +35,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with:
   cpu_baseline  the CPU restatement of the reference's dalek path (oracle/, kind "port"), timed on
                 the host cores this process may use, on a bounded sample of the same workload.
   extras        `end_to_end`, `committee_cached`, `qc_verify_latency` (p50 at N = 10,000, with the
-                CPU batch verification timed beside it), `rlc_ab` (per-signature vs batch-RLC/MSM path
+                CPU batch verification timed beside it), `tc_verify_latency` (TC::verify at N = 10,000: per-vote digests built
+                on the device, strict; the reference's loop on the CPU beside it), `rlc_ab` (per-signature vs batch-RLC/MSM path
                 at 6,667 and 66,667 signatures), `streamed_rounds` (configs[4]),
                 `small_batch_crossover` (GPU vs one CPU core at n = 1 ... 32).
 """
