@@ -796,7 +796,8 @@ static std::atomic<size_t> g_tail_max{kTailMax};      // HS_ED25519_TAIL_MAX: sw
 // (pool_get) the same GPU, same run (profiles/r6_k_e2e_pool_shape.md): bursts of sixteen 99 - 103 M verifies/s from host buffers
 // on four slices against 74 - 83 M on eight; bursts of one to four equal (36 / 60 / 76 M); a lone 1,024-signature call 0.257 ms
 // against 0.270 (half a wavefront slot per SIMD of its slice: the split eight-lane form); only sixteen threads with two bursts of
-// EIGHT each in flight prefer eight slices (92 against 86 M).
+// EIGHT each in flight prefer eight slices (92 - 103 against 86 - 90 M: a launch of one wavefront per SIMD of its slice is the shape
+// that fills it).
 unsigned hs::kPoolPartitions = 4;               // HS_ED25519_POOL_PARTITIONS overrides (read at init; measurement aid)
 // Several node processes on one GPU (the reference's `fab local` runs four node processes on one host,
 // benchmark/benchmark/local.py:94-104).  Every process brings its own pools - 16 narrow + 4 wide stream contexts - and
@@ -887,8 +888,10 @@ extern "C" int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_
     const unsigned cus = (unsigned)prop.multiProcessorCount;
     if (nparts > cus) return fail(HS_ED25519_E_ARG, "ctx_create_partition: more partitions than CUs");
     std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-    // contiguous slices: measured best (16 x 16 CUs: 29.3 M verifies/s; CU c -> partition c mod 16: 19.4 M;
-    // 20 / 24 / 28 slices, which are not aligned to the 32-CU XCDs: 8-12 M) - profiles/r1_stream_sweep.txt
+    // contiguous ranges of mask bits: measured best (16 x 16 CUs: 29.3 M verifies/s; CU c -> partition c mod 16: 19.4 M;
+    // 20 / 24 / 28 slices: 8-12 M) - profiles/r1_stream_sweep.txt.  Round 6 found why (profiles/r6_u_cu_mask_probe.md): the
+    // mask's bits are dealt round robin over the eight XCDs, so a contiguous range is the same share of every XCD, a range
+    // whose length is no multiple of eight is lopsided, and a strided mask that leaves an XCD empty is not applied at all.
     const unsigned lo = (unsigned)((uint64_t)cus * part / nparts), hi = (unsigned)((uint64_t)cus * (part + 1) / nparts);
     for (unsigned c = lo; c < hi; c++) mask[c / 32] |= 1u << (c % 32);
     return ctx_new(out, max_batch, 0, mask.data(), (uint32_t)mask.size());
