@@ -107,7 +107,9 @@ struct dev_state {
     int live[2] = {0, 0};
     unsigned part_busy[64] = {0};            // narrow contexts in flight per CU slice (pool_get balances over the slices)
     unsigned lane_busy[64] = {0};            // narrow contexts in flight per stream of the pool (an idle stream before a queued one)
-    std::vector<std::shared_ptr<stream_box>> lanes;   // the narrow pool's streams, by lane
+    // the narrow pool's streams, by lane.  On the heap, and freed by hs_ed25519_shutdown only: a process that exits without
+    // shutting the engine down leaks them - like the pooled contexts - instead of calling into the HIP runtime from a static destructor
+    std::vector<std::shared_ptr<stream_box>> *lanes = nullptr;
     unsigned cus = 0;                        // compute units (for the narrow pool's CU masks)
     // hs_ed25519_autotune: kernel time of the two eight-lane cold forms on a canned 6,667-signature batch on THIS device
     // ([0] k_verify_fused8, [1] k_verify_fused8h; 0 = not measured) and the faster one (-1 = not measured: the split form)

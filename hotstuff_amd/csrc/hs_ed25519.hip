@@ -1117,7 +1117,7 @@ extern "C" void hs_ed25519_shutdown(void) {
             for (hs_ed25519_ctx *c : d.free_ctx[k]) hs_ed25519_ctx_destroy(c);
             d.free_ctx[k].clear(); d.live[k] = 0;
         }
-        d.lanes.clear();
+        delete d.lanes; d.lanes = nullptr;
         free_base_tables(d);
         // tickets still outstanding keep their group alive; its context is destroyed when they are waited on
     }

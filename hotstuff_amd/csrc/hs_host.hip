@@ -141,10 +141,11 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
     std::lock_guard<std::mutex> creating(s_create_mu);
     if (k == 1 && cus >= kPoolPartitions) {      // a stream confined to slice `part` of the tenant's CUs
         lk.lock();
-        bool need = g_init.load() && slot < (int)g_devs.size() && g_devs[slot].lanes.empty();
+        bool need = g_init.load() && slot < (int)g_devs.size() && !g_devs[slot].lanes;
         lk.unlock();
         if (need && hipSetDevice(ordinal) == hipSuccess) {
-            std::vector<std::shared_ptr<stream_box>> boxes((size_t)(kMaxPool[1] > 0 ? kMaxPool[1] : 1));
+            auto *made = new (std::nothrow) std::vector<std::shared_ptr<stream_box>>((size_t)(kMaxPool[1] > 0 ? kMaxPool[1] : 1));
+            std::vector<std::shared_ptr<stream_box>> none, &boxes = made ? *made : none;
             for (size_t l = 0; l < boxes.size(); l++) {
                 const std::vector<uint32_t> mask = slice_mask((unsigned)l % kPoolPartitions);
                 hipStream_t st = nullptr;
@@ -154,12 +155,13 @@ int hs::pool_get(hs_ed25519_ctx **out, int slot, size_t n, bool nowait) {
                 boxes[l]->s = st; boxes[l]->device = ordinal;
             }
             lk.lock();
-            if (g_init.load() && slot < (int)g_devs.size() && g_devs[slot].lanes.empty()) g_devs[slot].lanes.swap(boxes);
+            if (made && g_init.load() && slot < (int)g_devs.size() && !g_devs[slot].lanes) { g_devs[slot].lanes = made; made = nullptr; }
             lk.unlock();
+            delete made;       // (the engine was shut down meanwhile: the streams go with it)
         }
         std::shared_ptr<stream_box> share;
         lk.lock();
-        if (g_init.load() && slot < (int)g_devs.size() && lane < g_devs[slot].lanes.size()) share = g_devs[slot].lanes[lane];
+        if (g_init.load() && slot < (int)g_devs.size() && g_devs[slot].lanes && lane < g_devs[slot].lanes->size()) share = (*g_devs[slot].lanes)[lane];
         lk.unlock();
         const std::vector<uint32_t> mask = slice_mask(part);
         if (share) rc = ctx_new(&c, 64, slot, mask.data(), (uint32_t)mask.size(), share);
