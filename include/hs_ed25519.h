@@ -86,7 +86,13 @@ void hs_ed25519_ctx_destroy(hs_ed25519_ctx *ctx);
 /* Like hs_ed25519_ctx_create, but the context's own stream is restricted to partition `part`
  * of `nparts` equal contiguous slices of the GPU's compute units (CU-masked stream), so that
  * small batches in flight on different contexts occupy disjoint CUs.  Pass stream = NULL to
- * hs_ed25519_verify_device to use it; hs_ed25519_ctx_stream returns the hipStream_t. */
+ * hs_ed25519_verify_device to use it; hs_ed25519_ctx_stream returns the hipStream_t.
+ * (A slice is the same share of EVERY XCD: the mask's bits are dealt round robin over the XCDs; `nparts` should divide
+ * CUs / 8.)  The ORDER of creation matters on MI355X: create the contexts one after the other, context j on partition
+ * j mod nparts - consecutively created streams sit on different pipes of the command processor, so the streams of one
+ * slice then share a pipe; with consecutive contexts on the SAME partition, or contexts created by several threads at once,
+ * a launch that cannot place its wavefronts yet stalls the queues of other slices (sixteen streams on four slices:
+ * 85 - 88 M verifies/s instead of 103 - 104 M, profiles/r6_x_lane_map.md).  The host API's pools do this themselves. */
 int hs_ed25519_ctx_create_partition(hs_ed25519_ctx **out, size_t max_batch, unsigned part, unsigned nparts);
 void *hs_ed25519_ctx_stream(hs_ed25519_ctx *ctx);
 int hs_ed25519_verify_device(hs_ed25519_ctx *ctx, const uint8_t *d_digests, size_t digest_stride,
