@@ -997,6 +997,18 @@ def summarise_extras(cfg, detail, pmc):
             cfg.setdefault("cpu_cores", cpu["cores"])
         elif "error" in cpu:
             cfg["cpu_tc_error"] = cpu["error"][:120]
+    ce = detail.get("callers_either_side", {})
+    if "error" in ce:
+        cfg["callers_error"] = ce["error"][:120]
+    elif ce:
+        # SURVEY 8f rows 1, 2 through the C++ twin (include/hotstuff_crypto.hpp), N = 10,000, committee registered: the leader's
+        # 6,667 votes of a round arriving one by one (reference: one strict verification each on the Core task,
+        # consensus/src/core.rs:203-225), and 200 timeouts that embed the same high_qc (reference: one verify_batch each,
+        # messages.rs:261-263).  The reference's side is DERIVED from this run's own CPU rows (oracle ports), and says so.
+        cfg.update({"vote_ingest_qc_ms": round(ce["vote_ingest_ms"], 3), "vote_ingest_engine_calls": ce["vote_ingest_engine_calls"],
+                    "timeout_storm_200_ms": round(ce["timeout_storm_ms"], 3), "timeout_storm_qc_verifies": ce["qc_cache_misses"]})
+        if "cpu_qc_verify_batch_p50_ms_one_core" in cfg:
+            cfg["cpu_timeout_storm_200_ms_derived"] = round(200 * cfg["cpu_qc_verify_batch_p50_ms_one_core"], 1)
     mp = detail.get("multi_process", {})
     for r_ in mp.get("rows", []) if isinstance(mp, dict) else []:
         if r_.get("processes") == 4 and r_.get("tenancy_hint") and "value" in r_:
@@ -1647,6 +1659,7 @@ def main():
             for key, fn in (("streamed_rounds", lambda: streamed_rounds(_lib, synth)),
                             ("qc_verify_latency", lambda: qc_latency(_lib, torch, synth, dev)),
                             ("tc_verify_latency", lambda: tc_latency(_lib, torch, dev)),
+                            ("callers_either_side", lambda: _lib.callers_bench(10000, 200)),
                             ("rlc_ab", lambda: rlc_ab(_lib, torch, synth, dev)),
                             ("small_batch_crossover", lambda: small_batch_crossover(_lib, synth)),
                             ("multi_process", lambda: mp_early if mp_early is not None else multi_process(n))):
@@ -1673,6 +1686,8 @@ def main():
                                  ("cpu_tc_verify_p50_ms_one_core", "tc_verify_p50_ms_one_core"), ("cpu_tc_verify_p50_ms_all_cores", "tc_verify_p50_ms_all_cores")):
                     if src in cfg:
                         out["cpu_baseline"][dst] = cfg[src]
+                if "vote_ingest_qc_ms" in cfg and out["cpu_baseline"].get("one_core"):      # the reference's vote path: q single strict verifications
+                    cfg["cpu_vote_ingest_ms_derived"] = round(1e3 * cfg.get("qc_signatures", 6667) / out["cpu_baseline"]["one_core"], 1)
             except Exception as e:
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ---- multi-GPU extras, AFTER the headline is complete.  Each runs under a deadline on rank 0: if a collective or

@@ -311,9 +311,7 @@ class PinnedBuffer:
 _loadgen = None
 
 
-def loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, inflight, batches_per_launch, seconds):
-    """tools/libhs_loadgen.so (a measurement aid over the public C ABI, not part of the product library): native
-    host threads drive the host-pointer API.  Pointers are raw addresses.  Returns (calls, p50_ms, elapsed_s)."""
+def _loadgen_lib():
     global _loadgen
     if _loadgen is None:
         path = os.path.join(os.path.dirname(_HERE), "tools", "libhs_loadgen.so")
@@ -326,12 +324,33 @@ def loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, i
                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         g.hs_loadgen.restype = ctypes.c_int
         _loadgen = g
+    return _loadgen
+
+
+def loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, inflight, batches_per_launch, seconds):
+    """tools/libhs_loadgen.so (a measurement aid over the public C ABI, not part of the product library): native
+    host threads drive the host-pointer API.  Pointers are raw addresses.  Returns (calls, p50_ms, elapsed_s)."""
+    _loadgen_lib()
     calls, p50, el = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
     rc = _loadgen.hs_loadgen(ks, digests, digest_stride, pks, sigs, n, nbatches, mode, threads, inflight, batches_per_launch, seconds,
                              ctypes.byref(calls), ctypes.byref(p50), ctypes.byref(el))
     if rc != 0:
         raise EngineError("hs_loadgen failed (%d): %s" % (rc, last_error()))
     return calls.value, p50.value, el.value
+
+
+def callers_bench(validators=10000, timeouts=200):
+    """tools/libhs_loadgen.so hs_callers_bench: the C++ twin's VoteIngest and VerifiedQCCache at N validators (a measurement
+    aid like loadgen).  Returns a dict of milliseconds and counts."""
+    loadgen_lib = _loadgen_lib()
+    out = (ctypes.c_double * 6)()
+    loadgen_lib.hs_callers_bench.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    loadgen_lib.hs_callers_bench.restype = ctypes.c_int
+    rc = loadgen_lib.hs_callers_bench(int(validators), int(timeouts), out)
+    if rc != 0:
+        raise EngineError("hs_callers_bench failed (%d): %s" % (rc, last_error()))
+    return {"vote_ingest_ms": out[0], "vote_ingest_engine_calls": int(out[1]), "timeout_storm_ms": out[2], "qc_cache_misses": int(out[3]),
+            "qc_cache_hits": int(out[4]), "qc_verify_ms_uncached": out[5]}
 
 
 def set_rlc_key(key):

@@ -48,6 +48,8 @@ for l in open(sys.argv[1]):
         g("qc_verify_p50_ms_cold_alternating"), g("qc_verify_p50_ms_key_cache_alternating"), g("streamed_cold_signatures_per_s"), g("streamed_key_cache_signatures_per_s"),
         g("committee_cached_verifies_per_s"), g("cached_qc_66667_kernel_ms"), g("cached_qc_66667_hbm_frac"), g("sq_verify_cached_lane2r_states_over_wave_cycles"),
         g("sq_verify_cached_lane2r_wait_any"), g("sq_verify_cached_lane2r_wait_inst_any"), g("sq_verify_cached_lane2r_active_any"), g("sq_verify_cached_lane2r_wave_cycles")))
+    print("callers either side, N = 10,000 (C++ twin): vote ingest -> QC %s ms in %s engine call(s) (reference, derived: %s ms on one core) | 200 timeouts with one high_qc %s ms, %s QC verification(s) (reference, derived: %s ms)" % (
+        g("vote_ingest_qc_ms"), g("vote_ingest_engine_calls"), g("cpu_vote_ingest_ms_derived"), g("timeout_storm_200_ms"), g("timeout_storm_qc_verifies"), g("cpu_timeout_storm_200_ms_derived")))
     print("first 24 config keys:", list(c)[:24])
     print("cpu", j.get("cpu_baseline", {}).get("value"), "detail", j.get("detail_file"), "config keys", len(c))
 PY

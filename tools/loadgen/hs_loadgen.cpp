@@ -111,3 +111,61 @@ extern "C" int hs_loadgen(const hs_ed25519_keyset *ks, const uint8_t *digests, s
     if (elapsed_s_out) *elapsed_s_out = el;
     return 0;
 }
+
+// ---- the callers either side of the path, timed through the C++ twin of the reference's interface -----------
+// hs_callers_bench: a committee of `validators` (keys and signatures made on the GPU through the C ABI), its keys registered;
+//   (1) vote ingest (consensus/src/core.rs:203-225 + aggregator.rs:74-94, batched: include/hotstuff_crypto.hpp VoteIngest): the
+//       q = floor(2N/3) + 1 votes of one round arrive one by one; wall time from the first vote to the QC, and the engine calls it took;
+//   (2) timeout storm (messages.rs:250-265, core.rs:227-238): `timeouts` timeouts of one view change, each embedding the SAME high_qc,
+//       through VerifiedQCCache: the embedded certificate is verified once, the rest are fingerprint hits.  (The timeouts' own
+//       signatures - one strict single each, which the shim keeps on dalek - are not part of this figure.)
+// out[0] = ingest ms, out[1] = ingest engine calls, out[2] = storm ms, out[3] = cache misses, out[4] = cache hits, out[5] = one uncached
+// QC::verify of the same certificate in ms (what the reference pays PER TIMEOUT, on the GPU instead of the CPU).  Returns 0 or < 0.
+#include "../../include/hotstuff_crypto.hpp"
+extern "C" int hs_callers_bench(unsigned validators, unsigned timeouts, double *out) {
+    using namespace hotstuff;
+    if (!out || validators < 4 || hs_ed25519_device_count() <= 0) return -100;
+    const size_t N = validators, q = 2 * N / 3 + 1;
+    std::vector<uint8_t> seeds(32 * N), pks(32 * N), secrets(64 * N), sigs(64 * q);
+    for (size_t i = 0; i < N; i++) for (int j = 0; j < 32; j++) seeds[32 * i + j] = (uint8_t)((i * 2654435761u + 97u * (unsigned)j + 13u) >> (8 * (j & 3)));
+    if (hs_ed25519_public_keys(seeds.data(), N, pks.data()) != 0) return -1;
+    for (size_t i = 0; i < N; i++) { memcpy(&secrets[64 * i], &seeds[32 * i], 32); memcpy(&secrets[64 * i + 32], &pks[32 * i], 32); }
+    Committee committee;
+    std::vector<PublicKey> names(N);
+    for (size_t i = 0; i < N; i++) { memcpy(names[i].b.data(), &pks[32 * i], 32); committee.authorities[names[i]] = 1; }
+    if (!committee.cache_keys()) return -2;
+    Vote proto; proto.round = 7;
+    for (int j = 0; j < 32; j++) proto.hash.b[j] = (uint8_t)(3 * j + 1);
+    const Digest vd = proto.digest();
+    if (hs_ed25519_sign_batch(secrets.data(), vd.b.data(), 0, q, sigs.data()) != 0) return -3;
+    std::vector<Vote> votes(q, proto);
+    for (size_t i = 0; i < q; i++) { votes[i].author = names[i]; votes[i].signature = Signature::from_bytes(&sigs[64 * i]); }
+    std::unique_ptr<QC> qc;
+    size_t calls = 0;
+    for (int rep = 0; rep < 3; rep++) {          // the last repetition is the one reported (pools, workspaces, tables warm)
+        VoteIngest ing(committee);
+        qc.reset();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < q && !qc; i++) {
+            VoteIngest::Outcome o = ing.add_vote(votes[i]);
+            if (!o.status.is_ok()) return -4;
+            if (o.qc) qc = std::move(o.qc);
+        }
+        out[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        calls = ing.verify_calls;
+        if (!qc || qc->votes.size() != q) return -5;
+    }
+    out[1] = (double)calls;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int reps = 20;
+        for (int i = 0; i < reps; i++) if (qc->verify(committee).is_err()) return -6;
+        out[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    VerifiedQCCache cache;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned t = 0; t < timeouts; t++) if (cache.verify(*qc, committee).is_err()) return -7;
+    out[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    out[3] = (double)cache.misses; out[4] = (double)cache.hits;
+    return 0;
+}
