@@ -173,6 +173,23 @@ int main(int argc, char **argv) {
         const ConsensusResult r = q.verify(committee);
         CHECK("verify_qc_unknown_authority (key cache)", r.is_err() && r.err.kind == ConsensusError::UnknownAuthority);
     }
+    {   // the structural loop of a registered committee (one hash lookup per vote, round 6) returns the reference's errors in its order
+        QC q = qc();
+        q.votes.pop_back();
+        const auto again = q.votes[0];
+        q.votes.push_back(again);
+        const ConsensusResult r = q.verify(committee);
+        CHECK("verify_qc_authority_reuse (key cache)", r.is_err() && r.err.kind == ConsensusError::AuthorityReuse && r.err.name == again.first);
+        QC few = qc();
+        few.votes.pop_back();
+        const ConsensusResult r2 = few.verify(committee);
+        CHECK("verify_qc_insufficient_stake (key cache)", r2.is_err() && r2.err.kind == ConsensusError::QCRequiresQuorum);
+        QC both = qc();                                    // a stranger first, a repeated member after it: the stranger is what is reported
+        both.votes[0].first = x.unknown;
+        both.votes[2] = both.votes[1];
+        const ConsensusResult r3 = both.verify(committee);
+        CHECK("a stranger before a repeated member is UnknownAuthority (key cache)", r3.is_err() && r3.err.kind == ConsensusError::UnknownAuthority && r3.err.name == x.unknown);
+    }
     CHECK("verify_valid_tc (key cache)", tc().verify(committee).is_ok());
     {
         TC t = tc();

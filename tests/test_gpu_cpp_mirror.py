@@ -70,7 +70,7 @@ def _run(tmp_path):
 def test_reference_test_cases_through_the_cpp_mirror(tmp_path):
     assert torch.cuda.is_available()
     rc, cases = _run(tmp_path)
-    assert len(cases) == 56, cases
+    assert len(cases) == 59, cases
     assert rc == 0 and all(cases.values()), [k for k, v in cases.items() if not v]
 
 
@@ -89,6 +89,9 @@ def test_cpp_mirror_builds_and_never_says_ok_without_a_gpu(tmp_path):
                  "calls below the threshold go to the embedder's CPU path when one is set",
                  "without a CPU path every call goes to the GPU"):
         assert cases[name], name
+    for name in ("verify_qc_authority_reuse (key cache)", "verify_qc_insufficient_stake (key cache)",
+                 "a stranger before a repeated member is UnknownAuthority (key cache)"):
+        assert cases[name], name          # (no GPU: the key set cannot be registered, the plain loop answers - the same errors)
     for name in ("verify_valid_signature", "verify_valid_batch", "verify_valid_qc", "verify_valid_tc",
                  "committee.cache_keys()", "verify_valid_qc (key cache)", "verify_valid_tc (key cache)",
                  "Vote::verify valid", "Block::verify valid (signature + embedded QC)",
